@@ -1,0 +1,46 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CASES = os.path.join(GOLDEN, "cases")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def case_names(include_errors=False, include_edthr=False):
+    out = []
+    for n in sorted(os.listdir(CASES)):
+        if n.startswith("err_") and not include_errors:
+            continue
+        if "edthr" in n and not include_edthr:
+            continue
+        out.append(n)
+    return out
+
+
+def load_case(name):
+    d = os.path.join(CASES, name)
+    with open(os.path.join(d, "params.json")) as f:
+        meta = json.load(f)
+    meta["reads"] = os.path.join(GOLDEN, meta["inputs"][0])
+    meta["monomers"] = os.path.join(GOLDEN, meta["inputs"][1])
+    with open(os.path.join(d, "raw.tsv"), "rb") as f:
+        meta["raw"] = f.read()
+    meta["name"] = name
+    return meta
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import binding
+    binding.build()
+    return binding

@@ -1,0 +1,71 @@
+"""The CPU oracle (oracle/sd_oracle.c) against the reference's own outputs.
+
+Pins the oracle: every committed fixture under tests/golden/cases/ is the stdout of the REAL
+reference binary (tests/golden/make_golden.py); the reference's own golden file pins columns 1-4.
+"""
+import hashlib
+import os
+
+import pytest
+
+from conftest import GOLDEN, case_names, load_case
+
+
+@pytest.mark.parametrize("name", case_names())
+def test_oracle_matches_reference_binary_output(oracle, name):
+    c = load_case(name)
+    sc = tuple(c["scoring"]) if c["scoring"] else (-1, -1, -1, 1)
+    got = oracle.decompose_files(c["reads"], c["monomers"], threads=4, part=c["part"],
+                                 overlap=c["overlap"], sc=sc)
+    assert hashlib.sha256(got).hexdigest() == c["sha256"]
+    assert got == c["raw"]
+
+
+def test_oracle_vs_reference_own_golden_columns(oracle):
+    """test_data/final_decomposition_fc89af8.tsv (the reference's golden) pins cols 1-4."""
+    td = os.path.join(GOLDEN, "test_data")
+    got = oracle.decompose_files(os.path.join(td, "read.fa"),
+                                 os.path.join(td, "DXZ1_star_monomers.fa"), threads=4)
+    with open(os.path.join(td, "final_decomposition_fc89af8.tsv"), "rb") as f:
+        gold = [ln.split(b"\t")[:4] for ln in f.read().splitlines()]
+    mine = [ln.split(b"\t")[:4] for ln in got.splitlines()]
+    assert mine == gold
+
+
+@pytest.mark.parametrize("name", case_names(include_errors=True))
+def test_oracle_error_cases(oracle, name):
+    if not name.startswith("err_"):
+        pytest.skip("not an error case")
+    c = load_case(name)
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.decompose_files(c["reads"], c["monomers"])
+    assert e.value.code == 255
+    assert e.value.msg.strip() == c["stderr_tail"][0].strip()
+
+
+def test_chunk_plan_examples(oracle):
+    # SURVEY Appendix A.2 [verified against the reference]
+    assert len(oracle.chunk_plan(5499)) == 1
+    assert oracle.chunk_plan(5500) == [(0, 5500), (5000, 500)]
+    p = oracle.chunk_plan(50000)
+    assert len(p) == 10 and [l for _, l in p] == [5500] * 9 + [5000]
+    assert len(oracle.chunk_plan(94871)) == 19
+    assert oracle.chunk_plan(100) == [(0, 100)]
+    assert oracle.chunk_plan(0) == []
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref",
+                                                    "dp")), reason="reference binary not built")
+def test_oracle_vs_live_reference_random(oracle, tmp_path):
+    """Fresh random inputs through the live reference binary (container only)."""
+    from stringdecomposer_amd import synth
+    mn, ms = synth.make_monomers(12, seed=123)
+    rn, rs = synth.make_reads(ms, 2, read_len=6200, seed=123)
+    rf, mf = str(tmp_path / "r.fa"), str(tmp_path / "m.fa")
+    synth.write_fasta(rf, rn, rs)
+    synth.write_fasta(mf, mn, ms)
+    for sc in [None, (-1, -1, -2, 2)]:
+        rc, out, _ = oracle.run_ref_dp(rf, mf, 4, sc=sc)
+        assert rc == 0
+        got = oracle.decompose_files(rf, mf, threads=4, sc=sc or (-1, -1, -1, 1))
+        assert got == out
