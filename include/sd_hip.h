@@ -1,0 +1,155 @@
+/*
+ * sd_hip.h -- C-ABI of libsd_hip.so: the MI355X-native StringDecomposer DP hot path.
+ *
+ * Drop-in boundary.  The reference crosses from Python into native code exactly once, by running
+ * its `dp` binary as a subprocess with stdout redirected to <out>_raw.tsv:
+ *     stringdecomposer/main.py:194   subprocess.run([SD_BIN, sequences, monomers, num_threads,
+ *                                     batch_size, overlap, ins, dels, mm, match, str(ed_thr)], stdout=f)
+ *     stringdecomposer/src/main.cpp:374-402   (argv contract of that binary)
+ * This header is what an FFI for that call binds instead (INTEGRATION.md shows the ctypes stub).
+ * Plain C types only; no torch/HIP types in any signature (a HIP stream is passed as void*).
+ *
+ * There is NO CPU fallback behind these entry points: every compute call needs a gfx950 device
+ * and fails with SD_ERR_NO_DEVICE otherwise.
+ */
+#ifndef SD_HIP_H
+#define SD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------- */
+#define SD_OK 0
+#define SD_ERR_IO 2           /* cannot open / write a file                                      */
+#define SD_ERR_FORMAT 3       /* malformed FASTA (no header, header without name)                */
+#define SD_ERR_PARAM 4        /* bad parameter                                                   */
+#define SD_ERR_EMPTY 6        /* empty read or monomer (the reference segfaults, main.cpp:115)   */
+#define SD_ERR_INTERNAL 7
+#define SD_ERR_NO_DEVICE 8    /* no usable HIP device: the product path never falls back to CPU  */
+#define SD_ERR_UNSUPPORTED 9  /* input outside what the device kernels support (documented)      */
+#define SD_ERR_HIP 10         /* a HIP runtime call failed (message in errbuf)                   */
+#define SD_ERR_SYMBOL 255     /* undefined symbol in a sequence: reference exit(-1), main.cpp:335 */
+
+/* ---- parameters: the argv of the reference binary (main.cpp:374-402) ----------------------- */
+typedef struct sd_params {
+    int32_t ins, del, mismatch, match; /* argv[6..9]; defaults -1,-1,-1,1 (main.cpp:380)          */
+    int32_t part_size;                 /* argv[4] (-b/--batch-size, main.py:212): chunk step, bp   */
+    int32_t overlap;                   /* argv[5] (-v/--overlap,   main.py:216)                    */
+    int32_t ed_thr;                    /* argv[10] (--ed_thr): -1 = off; >=0 not supported yet     */
+    int32_t threads;                   /* argv[3] (-t): host threads for parse / format            */
+    int32_t device;                    /* HIP device ordinal                                      */
+    int32_t kernel;                    /* 0 auto, 1 generic int32 workgroup kernel, 2 fast packed-int16 wave kernel */
+    int32_t reserved[6];
+} sd_params;
+
+void sd_params_default(sd_params* p); /* -1,-1,-1,1 / 5000 / 500 / -1 / 1 / 0 / auto */
+
+/* One monomer alignment = one raw TSV row (MonomerAlignment, main.cpp:37-49), chunk-local or
+ * read-global coordinates depending on the call.  score = dp at the monomer end minus the
+ * between-monomers score at its start (main.cpp:255), always integral. */
+typedef struct sd_rec {
+    int32_t tmpl;  /* template index: 0..M-1 monomers in file order, M..2M-1 their reverse complements */
+    int32_t start;
+    int32_t end;
+    int32_t score;
+} sd_rec;
+
+const char* sd_version(void);
+int sd_device_count(void);           /* number of visible HIP devices (0 if none / no runtime)   */
+void sd_free(void* p);               /* frees anything this library returned                     */
+
+/* ---- one-shot entry points (replace main.py:194) ------------------------------------------- */
+
+/* reads.fa + monomers.fa -> raw TSV file, byte-identical to `dp ... > raw_tsv_out`
+ * (SaveBatch, main.cpp:272-285; reads in input order).  Error text for bad symbols equals the
+ * reference's stderr line (main.cpp:335). */
+int sd_decompose_files(const char* reads_fa, const char* monomers_fa, const sd_params* p,
+                       const char* raw_tsv_out, char* errbuf, size_t errlen);
+
+/* In-memory variant: monomers WITHOUT reverse complements (appended here as main.cpp:364-371).
+ * *tsv is malloc'ed (sd_free). */
+int sd_decompose(const char* const* read_names, const char* const* read_seqs,
+                 const int64_t* read_lens, int32_t n_reads, const char* const* mono_names,
+                 const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono,
+                 const sd_params* p, char** tsv, size_t* tsv_len, char* errbuf, size_t errlen);
+
+/* ---- engine: device-resident batches (what bench.py and the parity tests drive) ------------ */
+typedef struct sd_engine sd_engine;
+
+/* Templates = monomers followed by their reverse complements (built here).  Uploads the template
+ * tables to HBM and picks the kernel family (p->kernel). */
+int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mono_seqs,
+                     const int32_t* mono_lens, int32_t n_mono, char* errbuf, size_t errlen);
+void sd_engine_destroy(sd_engine* e);
+
+/* Chunk the reads (main.cpp:70-81), pack them 2-bit (+N mask) and copy them to HBM.
+ * Replaces any previously loaded batch.  Returns the chunk count via *n_chunks. */
+int sd_engine_load_reads(sd_engine* e, const char* const* read_seqs, const int64_t* read_lens,
+                         int32_t n_reads, int64_t* n_chunks, char* errbuf, size_t errlen);
+
+/* One pass of the hot path over the loaded batch: DP fill + traceback + record compaction, all
+ * on `hip_stream` (a hipStream_t cast to void*, NULL = default stream).  Asynchronous. */
+int sd_engine_run(sd_engine* e, void* hip_stream, char* errbuf, size_t errlen);
+
+/* Wait for the last run and copy the compact records to the host.  rec_off has n_chunks+1
+ * entries; chunk c owns recs[rec_off[c] .. rec_off[c+1]) in read order, chunk-local coordinates.
+ * Both arrays are malloc'ed (sd_free). */
+int sd_engine_fetch(sd_engine* e, sd_rec** recs, int64_t** rec_off, char* errbuf, size_t errlen);
+
+/* Per-read assembly of fetched records: chunk offsets added (main.cpp:109-111) and the seam merge
+ * PostProcessing (main.cpp:287-302) applied; read r owns rows[row_off[r] .. row_off[r+1]). */
+int sd_engine_assemble(sd_engine* e, const sd_rec* recs, const int64_t* rec_off, sd_rec** rows,
+                       int64_t** row_off, char* errbuf, size_t errlen);
+
+/* HIP-event timings (ms) of the last completed sd_engine_run, measured on its stream:
+ * [0] fill kernel(s)  [1] traceback kernel(s)  [2] compaction  [3] whole run.  */
+int sd_engine_timings(sd_engine* e, float ms[4]);
+
+/* Static facts about the engine / loaded batch (for roofline arithmetic in bench.py):
+ * [0] n_templates [1] sum of template lengths [2] n_chunks [3] sum of chunk rows
+ * [4] kernel family actually used (1 generic, 2 fast) [5] cells-per-lane parameter P (fast) or Q
+ * [6] bytes of HBM workspace allocated [7] number of fill launches per run */
+int sd_engine_info(sd_engine* e, int64_t info[8]);
+
+/* ---- host-side pieces of the path, exported for CPU-only tests ----------------------------- */
+
+/* chunk plan of one read (main.cpp:70-81): up to cap (offset,len) pairs; returns the count */
+int32_t sd_chunk_plan(int64_t read_len, int32_t part_size, int32_t overlap, int64_t* off,
+                      int32_t* len, int32_t cap);
+/* PostProcessing seam merge (main.cpp:287-302), in place; returns the new count */
+int32_t sd_seam_merge(sd_rec* recs, int32_t n);
+/* SaveBatch text of one read's rows (main.cpp:272-285); *txt malloc'ed (sd_free) */
+int sd_format_rows(const char* read_name, const char* const* tmpl_names, const sd_rec* rows,
+                   int32_t n_rows, char** txt, size_t* txt_len);
+/* FASTA validation + load with the reference's semantics (main.cpp:314-346).  Arrays malloc'ed,
+ * free with sd_fasta_free. */
+typedef struct sd_fasta {
+    int32_t n;
+    char** names;
+    char** seqs;
+    int64_t* lens;
+    int32_t has_n;
+} sd_fasta;
+int sd_fasta_load(const char* path, sd_fasta* out, char* errbuf, size_t errlen);
+void sd_fasta_free(sd_fasta* f);
+
+/* ---- post-processing helper (host): identity of a read segment vs a template ---------------
+ * What main.py:29-60 (edist + aai) obtains from python-edlib: unit-cost global alignment
+ * (edlib mode "NW", task "path"), number of '=' columns and total CIGAR columns.  Traceback from
+ * the bottom-right corner with priority up (consume query, 'I') > left (consume target, 'D') >
+ * diagonal, i.e. edlib's obtainAlignmentTraceback (edlib.cpp:945-1150).  Exact for queries below
+ * ~19 kb against ~200-bp targets (above that edlib switches to Hirschberg, edlib.cpp:1186-1190).
+ * matches[i] = columns[i] = 0 and dist[i] = -1 if either sequence is empty (main.py:30-33).
+ * Multi-threaded over pairs (threads >= 1). */
+int sd_nw_identity_batch(const char* const* queries, const int32_t* qlens,
+                         const char* const* targets, const int32_t* tlens, int64_t n_pairs,
+                         int32_t threads, int32_t* dist, int32_t* matches, int32_t* columns);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SD_HIP_H */

@@ -1,0 +1,737 @@
+// sd_engine.hip -- host engine + C-ABI of libsd_hip.so (include/sd_hip.h).
+//
+// Host side of the reference's AlignReadsSet (stringdecomposer/src/main.cpp:67-122): chunk table,
+// device batches, ordered gather, per-read assembly, raw TSV.  The DP itself runs only in the HIP
+// kernels (sd_generic.hip, sd_fast.hip); there is no CPU implementation of it in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/sd_hip.h"
+#include "sd_device.hpp"
+#include "sd_fast.hpp"
+#include "sd_host.hpp"
+#include "sd_kernels.hpp"
+
+namespace {
+
+void set_err(char* buf, size_t len, const std::string& m) {
+    if (buf && len) {
+        std::snprintf(buf, len, "%s", m.c_str());
+    }
+}
+
+struct HipFail {
+    std::string msg;
+};
+
+#define SD_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (call);                                                             \
+        if (_e != hipSuccess)                                                               \
+            throw HipFail{std::string(#call) + ": " + hipGetErrorString(_e)};               \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void free_() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count) {
+        free_();
+        if (count == 0) count = 1;
+        SD_HIP(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        n = count;
+    }
+    void upload(const std::vector<T>& h) {
+        alloc(h.size());
+        if (!h.empty()) SD_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+    size_t bytes() const { return n * sizeof(T); }
+    ~DevBuf() { free_(); }
+};
+
+}  // namespace
+
+struct sd_engine {
+    sd_params p{};
+    int device = 0;
+    sd::ScoreArgs sc{};
+    // templates (monomers + reverse complements, main.cpp:364-371)
+    std::vector<std::string> tseq;
+    std::vector<int32_t> tlen, toff;
+    int T = 0;
+    int64_t sumL = 0;
+    int Lmax = 0;
+    int family = 0;  // 1 generic, 2 fast
+
+    // generic family
+    int Q = 0, threads = 0, rowBytes = 0;
+    DevBuf<uint8_t> d_tmeta;
+    DevBuf<int32_t> d_tend_kd, d_tend_j, d_toff, d_tlen;
+    DevBuf<uint8_t> d_ptr;
+    size_t ptr_budget = 0;
+    std::vector<std::pair<int, int>> subs;  // [begin, end) chunk ranges of the pointer workspace
+
+    // fast family
+    sd::FastPlan fplan;
+    DevBuf<uint32_t> d_ftable;       // LDS image of the (mm - del) table
+    DevBuf<uint32_t> d_flane;        // per-lane constants
+    DevBuf<uint16_t> d_fslot;        // slot of template cell (j,k) in the lane layout
+    DevBuf<uint8_t> d_ftcodes;       // base code of template cell (j,k)
+    DevBuf<uint32_t> d_fckpt;        // checkpoints
+    DevBuf<int32_t> d_fckbase;       // per-checkpoint rebase values
+
+    // batch
+    std::vector<sd::ChunkDesc> chunks;
+    std::vector<int32_t> chunk_read;
+    std::vector<int64_t> chunk_off;
+    std::vector<int32_t> read_nchunks;
+    int32_t n_reads = 0;
+    int64_t rows = 0;
+    DevBuf<sd::ChunkDesc> d_chunks;
+    DevBuf<uint32_t> d_bases2, d_nmask;
+    DevBuf<int32_t> d_B, d_argB, d_cnt;
+    DevBuf<sd::DevRec> d_recs, d_dense;
+    DevBuf<int64_t> d_roff;
+    int64_t dense_cap = 0;
+
+    // run state
+    hipStream_t last_stream = nullptr;
+    bool ran = false;
+    std::vector<hipEvent_t> ev_fill, ev_trace;  // pairs
+    hipEvent_t ev_run0 = nullptr, ev_run1 = nullptr, ev_cmp0 = nullptr, ev_cmp1 = nullptr;
+    int fill_launches = 0;
+
+    ~sd_engine() {
+        for (hipEvent_t e : ev_fill) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_trace) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ev_run0, ev_run1, ev_cmp0, ev_cmp1})
+            if (e) (void)hipEventDestroy(e);
+    }
+
+    size_t workspace_bytes() const {
+        return d_tmeta.bytes() + d_tend_kd.bytes() + d_tend_j.bytes() + d_ptr.bytes() +
+               d_ftable.bytes() + d_flane.bytes() + d_fslot.bytes() + d_ftcodes.bytes() + d_fckpt.bytes() +
+               d_fckbase.bytes() + d_chunks.bytes() + d_bases2.bytes() + d_nmask.bytes() +
+               d_B.bytes() + d_argB.bytes() + d_cnt.bytes() + d_recs.bytes() + d_dense.bytes() +
+               d_roff.bytes();
+    }
+};
+
+namespace {
+
+int device_count_checked() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void ensure_events(std::vector<hipEvent_t>& v, size_t pairs) {
+    while (v.size() < 2 * pairs) {
+        hipEvent_t e;
+        SD_HIP(hipEventCreate(&e));
+        v.push_back(e);
+    }
+}
+
+int validate_params(const sd_params* p, std::string& err) {
+    if (!p) { err = "null params"; return SD_ERR_PARAM; }
+    if (p->part_size <= 0) { err = "part_size must be > 0"; return SD_ERR_PARAM; }
+    if (p->overlap < 0) { err = "overlap must be >= 0"; return SD_ERR_PARAM; }
+    if (p->ed_thr > -1) {
+        err = "--ed_thr >= 0 (per-chunk monomer prefilter, main.cpp:128-149) is not supported by the device path yet";
+        return SD_ERR_UNSUPPORTED;
+    }
+    return SD_OK;
+}
+
+// Everything must stay above the reference's INF = -1e6 sentinel (main.cpp:156), which makes its
+// `> INF` guards vacuous, and below 2^24 so that its float arithmetic on scores is exact.
+int check_score_range(const sd_params& p, int Lmax, std::string& err) {
+    auto a = [](int v) { return (int64_t)(v < 0 ? -v : v); };
+    const int64_t n = (int64_t)p.part_size + p.overlap;
+    const int64_t ms = std::max(std::max(a(p.ins), a(p.match)), a(p.mismatch));
+    const int64_t bound = n * ms + (int64_t)Lmax * a(p.del) + a(p.mismatch);
+    if (bound >= 1000000) {
+        err = "scores x chunk length reach the reference's INF sentinel (-1e6): unsupported";
+        return SD_ERR_UNSUPPORTED;
+    }
+    return SD_OK;
+}
+
+void build_generic_tables(sd_engine* e) {
+    const int Q = e->Q;
+    const int64_t need = (e->sumL + Q - 1) / Q;
+    int threads = (int)((need + 63) / 64 * 64);
+    if (threads < 64) threads = 64;
+    e->threads = threads;
+    const int64_t cells = (int64_t)threads * Q;
+    e->rowBytes = (int)(cells / 4);
+    std::vector<uint8_t> meta((size_t)cells, (uint8_t)(7 | sd::CELL_START));
+    std::vector<int32_t> kd((size_t)cells, 0), tj((size_t)cells, 0);
+    for (int j = 0; j < e->T; ++j) {
+        for (int k = 0; k < e->tlen[j]; ++k) {
+            const size_t x = (size_t)e->toff[j] + k;
+            uint8_t m = (uint8_t)sd::base_code(e->tseq[j][k]);
+            if (k == 0) m |= sd::CELL_START;
+            if (k == e->tlen[j] - 1) {
+                m |= sd::CELL_END;
+                kd[x] = (e->tlen[j] - 1) * e->sc.del;
+                tj[x] = j;
+            }
+            meta[x] = m;
+        }
+    }
+    e->d_tmeta.upload(meta);
+    e->d_tend_kd.upload(kd);
+    e->d_tend_j.upload(tj);
+}
+
+}  // namespace
+
+extern "C" {
+
+void sd_params_default(sd_params* p) {
+    std::memset(p, 0, sizeof *p);
+    p->ins = -1; p->del = -1; p->mismatch = -1; p->match = 1;
+    p->part_size = 5000; p->overlap = 500; p->ed_thr = -1; p->threads = 1; p->device = 0;
+    p->kernel = 0;
+}
+
+const char* sd_version(void) { return "stringdecomposer_amd 0.1.0 (gfx950)"; }
+
+int sd_device_count(void) { return device_count_checked(); }
+
+void sd_free(void* p) { std::free(p); }
+
+int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mono_seqs,
+                     const int32_t* mono_lens, int32_t n_mono, char* errbuf, size_t errlen) {
+    if (!out) return SD_ERR_PARAM;
+    *out = nullptr;
+    std::string err;
+    int rc = validate_params(p, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    if (n_mono <= 0) { set_err(errbuf, errlen, "no monomers"); return SD_ERR_PARAM; }
+    std::unique_ptr<sd_engine> e(new sd_engine);
+    e->p = *p;
+    e->sc = sd::ScoreArgs{p->ins, p->del, p->mismatch, p->match};
+    e->T = 2 * n_mono;
+    e->tseq.resize((size_t)e->T);
+    for (int j = 0; j < n_mono; ++j) {
+        if (mono_lens[j] <= 0) { set_err(errbuf, errlen, "ERROR: empty monomer sequence"); return SD_ERR_EMPTY; }
+        e->tseq[j].assign(mono_seqs[j], (size_t)mono_lens[j]);
+        rc = sd::check_alphabet("<monomer>", mono_seqs[j], mono_lens[j], err);
+        if (rc) { set_err(errbuf, errlen, err); return rc; }
+        if (!sd::reverse_complement(e->tseq[j], e->tseq[(size_t)n_mono + j])) {
+            set_err(errbuf, errlen, "map::at");
+            return SD_ERR_SYMBOL;
+        }
+    }
+    e->tlen.resize((size_t)e->T);
+    e->toff.resize((size_t)e->T + 1);
+    e->toff[0] = 0;
+    for (int j = 0; j < e->T; ++j) {
+        e->tlen[j] = (int32_t)e->tseq[j].size();
+        e->toff[j + 1] = e->toff[j] + e->tlen[j];
+        e->Lmax = std::max(e->Lmax, (int)e->tlen[j]);
+    }
+    e->sumL = e->toff[e->T];
+    rc = check_score_range(*p, e->Lmax, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+
+    if (device_count_checked() <= 0) {
+        set_err(errbuf, errlen, "no HIP device available (libsd_hip has no CPU fallback)");
+        return SD_ERR_NO_DEVICE;
+    }
+    try {
+        SD_HIP(hipSetDevice(p->device));
+        e->device = p->device;
+        // kernel family
+        int family = p->kernel;
+        std::string why;
+        const bool fast_ok = sd::fast_plan_build(e->tseq, e->sc, p->part_size + p->overlap, e->fplan, why);
+        if (family == 0) family = fast_ok ? 2 : 1;
+        if (family == 2 && !fast_ok) {
+            set_err(errbuf, errlen, "fast kernel family not applicable: " + why);
+            return SD_ERR_UNSUPPORTED;
+        }
+        if (family != 1 && family != 2) { set_err(errbuf, errlen, "bad kernel family"); return SD_ERR_PARAM; }
+        e->family = family;
+        e->d_toff.upload(e->toff);
+        e->d_tlen.upload(e->tlen);
+        if (family == 1) {
+            e->Q = sd::generic_pick_q(e->sumL);
+            if (e->Q < 0) {
+                set_err(errbuf, errlen, "template set too large for the generic kernel (> 32768 cells)");
+                return SD_ERR_UNSUPPORTED;
+            }
+            build_generic_tables(e.get());
+        } else {
+            e->d_ftable.upload(e->fplan.table);
+            e->d_flane.upload(e->fplan.lane_consts);
+            e->d_fslot.upload(e->fplan.slot_of);
+            e->d_ftcodes.upload(e->fplan.tcodes);
+        }
+        SD_HIP(hipEventCreate(&e->ev_run0));
+        SD_HIP(hipEventCreate(&e->ev_run1));
+        SD_HIP(hipEventCreate(&e->ev_cmp0));
+        SD_HIP(hipEventCreate(&e->ev_cmp1));
+    } catch (const HipFail& f) {
+        set_err(errbuf, errlen, f.msg);
+        return SD_ERR_HIP;
+    }
+    *out = e.release();
+    return SD_OK;
+}
+
+void sd_engine_destroy(sd_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    delete e;
+}
+
+int sd_engine_load_reads(sd_engine* e, const char* const* read_seqs, const int64_t* read_lens,
+                         int32_t n_reads, int64_t* n_chunks, char* errbuf, size_t errlen) {
+    if (!e) return SD_ERR_PARAM;
+    e->ran = false;
+    e->chunks.clear();
+    e->chunk_read.clear();
+    e->chunk_off.clear();
+    e->read_nchunks.assign((size_t)std::max(n_reads, 0), 0);
+    e->n_reads = n_reads;
+    // chunk table (main.cpp:70-81) + 2-bit packing
+    std::vector<uint32_t> bases2, nmask;
+    uint64_t row0 = 0;
+    for (int32_t r = 0; r < n_reads; ++r) {
+        const char* s = read_seqs[r];
+        const int64_t len = read_lens[r];
+        int cnt = sd::chunk_plan(len, e->p.part_size, e->p.overlap, [&](int64_t off, int32_t l) {
+            sd::ChunkDesc cd{};
+            cd.woff = (uint32_t)bases2.size();
+            cd.n = l;
+            cd.noff = -1;
+            cd.row0 = row0;
+            row0 += (uint64_t)l;
+            const size_t words = ((size_t)l + 15) / 16;
+            const size_t w0 = bases2.size();
+            bases2.resize(w0 + words, 0u);
+            bool has_n = false;
+            for (int32_t i = 0; i < l; ++i) {
+                const int code = sd::base_code(s[off + i]);
+                if (code == 4) has_n = true;
+                else bases2[w0 + (size_t)(i >> 4)] |= (uint32_t)code << (2 * (i & 15));
+            }
+            if (has_n) {
+                cd.noff = (int32_t)nmask.size();
+                const size_t nw = ((size_t)l + 31) / 32;
+                const size_t n0 = nmask.size();
+                nmask.resize(n0 + nw, 0u);
+                for (int32_t i = 0; i < l; ++i)
+                    if (s[off + i] == 'N') nmask[n0 + (size_t)(i >> 5)] |= 1u << (i & 31);
+            }
+            e->chunks.push_back(cd);
+            e->chunk_read.push_back(r);
+            e->chunk_off.push_back(off);
+        });
+        if (cnt == 0) {
+            set_err(errbuf, errlen, "ERROR: Sequence #" + std::to_string(r) + " is empty");
+            return SD_ERR_EMPTY;
+        }
+        e->read_nchunks[(size_t)r] = cnt;
+    }
+    e->rows = (int64_t)row0;
+    const size_t C = e->chunks.size();
+    if (n_chunks) *n_chunks = (int64_t)C;
+    if (bases2.size() >= (1ull << 31)) {
+        set_err(errbuf, errlen, "batch too large: split the reads into smaller groups");
+        return SD_ERR_UNSUPPORTED;
+    }
+    try {
+        SD_HIP(hipSetDevice(e->device));
+        const int64_t nck = e->family == 2 ? sd::fast_ckpt_rows_total(e->fplan, e->chunks) : 0;
+        e->d_chunks.upload(e->chunks);
+        e->d_bases2.upload(bases2);
+        e->d_nmask.upload(nmask);
+        e->d_B.alloc((size_t)e->rows + C);
+        e->d_argB.alloc((size_t)e->rows + C);
+        e->d_cnt.alloc(C);
+        e->d_roff.alloc(C + 1);
+        e->d_recs.alloc((size_t)e->rows);
+        e->dense_cap = std::max<int64_t>(4096, e->rows / 16);
+        e->d_dense.alloc((size_t)e->dense_cap);
+        e->subs.clear();
+        if (e->family == 1) {
+            // pointer workspace: sub-batches of consecutive chunks within the budget
+            size_t free_b = 0, total_b = 0;
+            SD_HIP(hipMemGetInfo(&free_b, &total_b));
+            size_t budget = std::min<size_t>(free_b / 2, (size_t)48 << 30);
+            size_t max_sub = 0, cur = 0;
+            int begin = 0;
+            for (size_t c = 0; c < C; ++c) {
+                const size_t need = (size_t)e->chunks[c].n * (size_t)e->rowBytes;
+                if (cur + need > budget && cur > 0) {
+                    e->subs.emplace_back(begin, (int)c);
+                    max_sub = std::max(max_sub, cur);
+                    begin = (int)c;
+                    cur = 0;
+                }
+                cur += need;
+            }
+            if (C > 0) { e->subs.emplace_back(begin, (int)C); max_sub = std::max(max_sub, cur); }
+            e->d_ptr.alloc(max_sub);
+            ensure_events(e->ev_fill, e->subs.size());
+            ensure_events(e->ev_trace, e->subs.size());
+        } else {
+            e->d_fckpt.alloc((size_t)nck * (size_t)e->fplan.P * 64);
+            e->d_fckbase.alloc((size_t)nck + 1);
+            ensure_events(e->ev_fill, 1);
+            ensure_events(e->ev_trace, 1);
+        }
+    } catch (const HipFail& f) {
+        set_err(errbuf, errlen, f.msg);
+        return SD_ERR_HIP;
+    }
+    return SD_OK;
+}
+
+int sd_engine_run(sd_engine* e, void* hip_stream, char* errbuf, size_t errlen) {
+    if (!e) return SD_ERR_PARAM;
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    const int C = (int)e->chunks.size();
+    try {
+        SD_HIP(hipSetDevice(e->device));
+        SD_HIP(hipEventRecord(e->ev_run0, st));
+        e->fill_launches = 0;
+        if (C > 0) {
+            if (e->family == 1) {
+                for (size_t s = 0; s < e->subs.size(); ++s) {
+                    const int b = e->subs[s].first, n_sub = e->subs[s].second - b;
+                    const uint64_t row0_base = e->chunks[(size_t)b].row0;
+                    SD_HIP(hipEventRecord(e->ev_fill[2 * s], st));
+                    sd::launch_generic_fill(e->Q, e->threads, n_sub, st, e->d_chunks.p, b,
+                                            e->d_bases2.p, e->d_nmask.p, e->d_tmeta.p,
+                                            e->d_tend_kd.p, e->d_tend_j.p, e->sc, e->rowBytes,
+                                            e->d_ptr.p, row0_base, e->d_B.p, e->d_argB.p);
+                    SD_HIP(hipEventRecord(e->ev_fill[2 * s + 1], st));
+                    SD_HIP(hipEventRecord(e->ev_trace[2 * s], st));
+                    sd::launch_generic_trace(n_sub, st, e->d_chunks.p, b, e->d_ptr.p, row0_base,
+                                             e->rowBytes, e->d_B.p, e->d_argB.p, e->d_toff.p,
+                                             e->d_tlen.p, e->d_recs.p, e->d_cnt.p);
+                    SD_HIP(hipEventRecord(e->ev_trace[2 * s + 1], st));
+                    ++e->fill_launches;
+                }
+            } else {
+                SD_HIP(hipEventRecord(e->ev_fill[0], st));
+                sd::launch_fast_fill(e->fplan, st, e->d_chunks.p, C, e->d_bases2.p, e->d_nmask.p,
+                                     e->d_ftable.p, e->d_flane.p, e->sc, e->d_B.p, e->d_argB.p,
+                                     e->d_fckpt.p, e->d_fckbase.p);
+                SD_HIP(hipEventRecord(e->ev_fill[1], st));
+                SD_HIP(hipEventRecord(e->ev_trace[0], st));
+                sd::launch_fast_trace(e->fplan, st, e->d_chunks.p, C, e->d_bases2.p, e->d_nmask.p,
+                                      e->d_fslot.p, e->d_ftcodes.p, e->d_flane.p, e->d_toff.p,
+                                      e->d_tlen.p, e->sc, e->d_B.p, e->d_argB.p, e->d_fckpt.p,
+                                      e->d_fckbase.p, e->d_recs.p, e->d_cnt.p);
+                SD_HIP(hipEventRecord(e->ev_trace[1], st));
+                e->fill_launches = 1;
+            }
+            SD_HIP(hipEventRecord(e->ev_cmp0, st));
+            sd::launch_compact(st, e->d_chunks.p, C, e->d_cnt.p, e->d_roff.p, e->d_recs.p,
+                               e->d_dense.p, e->dense_cap, true);
+            SD_HIP(hipEventRecord(e->ev_cmp1, st));
+        }
+        SD_HIP(hipEventRecord(e->ev_run1, st));
+        SD_HIP(hipGetLastError());
+    } catch (const HipFail& f) {
+        set_err(errbuf, errlen, f.msg);
+        return SD_ERR_HIP;
+    }
+    e->last_stream = st;
+    e->ran = true;
+    return SD_OK;
+}
+
+int sd_engine_fetch(sd_engine* e, sd_rec** recs, int64_t** rec_off, char* errbuf, size_t errlen) {
+    if (!e || !recs || !rec_off) return SD_ERR_PARAM;
+    *recs = nullptr;
+    *rec_off = nullptr;
+    if (!e->ran) { set_err(errbuf, errlen, "sd_engine_fetch before sd_engine_run"); return SD_ERR_PARAM; }
+    const size_t C = e->chunks.size();
+    try {
+        SD_HIP(hipSetDevice(e->device));
+        SD_HIP(hipStreamSynchronize(e->last_stream));
+        int64_t* off = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * (C + 1)));
+        off[0] = 0;
+        if (C > 0) SD_HIP(hipMemcpy(off, e->d_roff.p, sizeof(int64_t) * (C + 1), hipMemcpyDeviceToHost));
+        const int64_t total = C > 0 ? off[C] : 0;
+        if (total > e->dense_cap) {
+            e->dense_cap = total;
+            e->d_dense.alloc((size_t)total);
+            sd::launch_compact(e->last_stream, e->d_chunks.p, (int)C, e->d_cnt.p, e->d_roff.p,
+                               e->d_recs.p, e->d_dense.p, e->dense_cap, false);
+            SD_HIP(hipStreamSynchronize(e->last_stream));
+        }
+        sd_rec* out = static_cast<sd_rec*>(std::malloc(sizeof(sd_rec) * (size_t)std::max<int64_t>(total, 1)));
+        static_assert(sizeof(sd_rec) == sizeof(sd::DevRec), "record layout");
+        if (total > 0) SD_HIP(hipMemcpy(out, e->d_dense.p, sizeof(sd_rec) * (size_t)total, hipMemcpyDeviceToHost));
+        *recs = out;
+        *rec_off = off;
+    } catch (const HipFail& f) {
+        set_err(errbuf, errlen, f.msg);
+        return SD_ERR_HIP;
+    }
+    return SD_OK;
+}
+
+int sd_engine_assemble(sd_engine* e, const sd_rec* recs, const int64_t* rec_off, sd_rec** rows,
+                       int64_t** row_off, char* errbuf, size_t errlen) {
+    (void)errbuf; (void)errlen;
+    if (!e || !rows || !row_off) return SD_ERR_PARAM;
+    std::vector<sd_rec> all;
+    std::vector<int64_t> offs((size_t)e->n_reads + 1, 0);
+    std::vector<sd_rec> batch;
+    size_t c = 0;
+    for (int32_t r = 0; r < e->n_reads; ++r) {
+        batch.clear();
+        for (int a = 0; a < e->read_nchunks[(size_t)r]; ++a, ++c) {
+            const int32_t add = (int32_t)e->chunk_off[c];  // main.cpp:109-111
+            for (int64_t x = rec_off[c]; x < rec_off[c + 1]; ++x) {
+                sd_rec t = recs[x];
+                t.start += add;
+                t.end += add;
+                batch.push_back(t);
+            }
+        }
+        sd::seam_merge(batch);  // main.cpp:116
+        all.insert(all.end(), batch.begin(), batch.end());
+        offs[(size_t)r + 1] = (int64_t)all.size();
+    }
+    sd_rec* o = static_cast<sd_rec*>(std::malloc(sizeof(sd_rec) * std::max<size_t>(all.size(), 1)));
+    if (!all.empty()) std::memcpy(o, all.data(), sizeof(sd_rec) * all.size());
+    int64_t* ro = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * offs.size()));
+    std::memcpy(ro, offs.data(), sizeof(int64_t) * offs.size());
+    *rows = o;
+    *row_off = ro;
+    return SD_OK;
+}
+
+int sd_engine_timings(sd_engine* e, float ms[4]) {
+    if (!e || !e->ran) return SD_ERR_PARAM;
+    ms[0] = ms[1] = ms[2] = ms[3] = 0.f;
+    if (hipSetDevice(e->device) != hipSuccess) return SD_ERR_HIP;
+    if (hipEventSynchronize(e->ev_run1) != hipSuccess) return SD_ERR_HIP;
+    const size_t pairs = e->family == 1 ? e->subs.size() : (e->chunks.empty() ? 0 : 1);
+    for (size_t s = 0; s < pairs; ++s) {
+        float a = 0.f, b = 0.f;
+        (void)hipEventElapsedTime(&a, e->ev_fill[2 * s], e->ev_fill[2 * s + 1]);
+        (void)hipEventElapsedTime(&b, e->ev_trace[2 * s], e->ev_trace[2 * s + 1]);
+        ms[0] += a;
+        ms[1] += b;
+    }
+    if (!e->chunks.empty()) (void)hipEventElapsedTime(&ms[2], e->ev_cmp0, e->ev_cmp1);
+    (void)hipEventElapsedTime(&ms[3], e->ev_run0, e->ev_run1);
+    return SD_OK;
+}
+
+int sd_engine_info(sd_engine* e, int64_t info[8]) {
+    if (!e) return SD_ERR_PARAM;
+    info[0] = e->T;
+    info[1] = e->sumL;
+    info[2] = (int64_t)e->chunks.size();
+    info[3] = e->rows;
+    info[4] = e->family;
+    info[5] = e->family == 1 ? e->Q : e->fplan.P;
+    info[6] = (int64_t)e->workspace_bytes();
+    info[7] = e->family == 1 ? (int64_t)e->subs.size() : 1;
+    return SD_OK;
+}
+
+// -------------------------------------------------------------------------------------------
+// one-shot entry points
+// -------------------------------------------------------------------------------------------
+static int decompose_impl(const std::vector<sd::Seq>& reads, const std::vector<sd::Seq>& monos,
+                          const sd_params* p, std::string& tsv, std::string& err) {
+    if (monos.empty()) { err = "no monomers"; return SD_ERR_PARAM; }
+    for (const sd::Seq& r : reads)
+        if (r.seq.empty()) { err = "ERROR: Sequence " + r.name + " is empty"; return SD_ERR_EMPTY; }
+    std::vector<const char*> mseq;
+    std::vector<int32_t> mlen;
+    std::vector<std::string> tnames;
+    for (const sd::Seq& m : monos) {
+        mseq.push_back(m.seq.data());
+        mlen.push_back((int32_t)m.seq.size());
+        tnames.push_back(m.name);
+    }
+    for (const sd::Seq& m : monos) tnames.push_back(m.name + "'");  // main.cpp:367
+    char eb[1024] = {0};
+    sd_engine* eng = nullptr;
+    int rc = sd_engine_create(&eng, p, mseq.data(), mlen.data(), (int32_t)monos.size(), eb, sizeof eb);
+    if (rc) { err = eb; return rc; }
+    // groups of reads bounded by rows so that device buffers stay moderate
+    const int64_t row_budget = (int64_t)768 << 20;
+    size_t r0 = 0;
+    while (r0 < reads.size() && rc == SD_OK) {
+        int64_t rows = 0;
+        size_t r1 = r0;
+        while (r1 < reads.size() && (r1 == r0 || rows + (int64_t)reads[r1].seq.size() * 11 / 10 <= row_budget)) {
+            rows += (int64_t)reads[r1].seq.size() * 11 / 10;
+            ++r1;
+        }
+        std::vector<const char*> rs;
+        std::vector<int64_t> rl;
+        for (size_t r = r0; r < r1; ++r) { rs.push_back(reads[r].seq.data()); rl.push_back((int64_t)reads[r].seq.size()); }
+        int64_t nch = 0;
+        rc = sd_engine_load_reads(eng, rs.data(), rl.data(), (int32_t)rs.size(), &nch, eb, sizeof eb);
+        if (rc == SD_OK) rc = sd_engine_run(eng, nullptr, eb, sizeof eb);
+        sd_rec* recs = nullptr; int64_t* roff = nullptr;
+        if (rc == SD_OK) rc = sd_engine_fetch(eng, &recs, &roff, eb, sizeof eb);
+        sd_rec* rows_o = nullptr; int64_t* row_off = nullptr;
+        if (rc == SD_OK) rc = sd_engine_assemble(eng, recs, roff, &rows_o, &row_off, eb, sizeof eb);
+        if (rc == SD_OK) {
+            for (size_t r = r0; r < r1; ++r) {
+                const int64_t a = row_off[r - r0], b = row_off[r - r0 + 1];
+                sd::format_rows(tsv, reads[r].name.data(), reads[r].name.size(), tnames, rows_o + a, (size_t)(b - a));
+            }
+        }
+        std::free(recs); std::free(roff); std::free(rows_o); std::free(row_off);
+        r0 = r1;
+    }
+    if (rc) err = eb;
+    sd_engine_destroy(eng);
+    return rc;
+}
+
+int sd_decompose(const char* const* read_names, const char* const* read_seqs,
+                 const int64_t* read_lens, int32_t n_reads, const char* const* mono_names,
+                 const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono,
+                 const sd_params* p, char** tsv, size_t* tsv_len, char* errbuf, size_t errlen) {
+    if (!tsv || !tsv_len) return SD_ERR_PARAM;
+    *tsv = nullptr;
+    *tsv_len = 0;
+    std::string err;
+    std::vector<sd::Seq> reads((size_t)std::max(n_reads, 0)), monos((size_t)std::max(n_mono, 0));
+    for (int32_t r = 0; r < n_reads; ++r) {
+        reads[(size_t)r].name = read_names[r];
+        reads[(size_t)r].seq.assign(read_seqs[r], (size_t)read_lens[r]);
+        int rc = sd::check_alphabet(read_names[r], read_seqs[r], read_lens[r], err);
+        if (rc) { set_err(errbuf, errlen, err); return rc; }
+    }
+    for (int32_t m = 0; m < n_mono; ++m) {
+        monos[(size_t)m].name = mono_names[m];
+        monos[(size_t)m].seq.assign(mono_seqs[m], (size_t)mono_lens[m]);
+        int rc = sd::check_alphabet(mono_names[m], mono_seqs[m], mono_lens[m], err);
+        if (rc) { set_err(errbuf, errlen, err); return rc; }
+    }
+    std::string out;
+    int rc = decompose_impl(reads, monos, p, out, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    char* o = static_cast<char*>(std::malloc(out.size() + 1));
+    std::memcpy(o, out.data(), out.size());
+    o[out.size()] = 0;
+    *tsv = o;
+    *tsv_len = out.size();
+    return SD_OK;
+}
+
+int sd_decompose_files(const char* reads_fa, const char* monomers_fa, const sd_params* p,
+                       const char* raw_tsv_out, char* errbuf, size_t errlen) {
+    std::string err;
+    int rc = validate_params(p, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    std::vector<sd::Seq> reads, monos;
+    bool hn = false;
+    rc = sd::load_fasta(reads_fa, reads, hn, err);       // main.cpp:394
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    rc = sd::load_fasta(monomers_fa, monos, hn, err);    // main.cpp:395
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    std::string out;
+    rc = decompose_impl(reads, monos, p, out, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    FILE* fp = std::fopen(raw_tsv_out, "wb");
+    if (!fp) { set_err(errbuf, errlen, std::string("cannot write ") + raw_tsv_out); return SD_ERR_IO; }
+    const size_t w = std::fwrite(out.data(), 1, out.size(), fp);
+    if (std::fclose(fp) != 0 || w != out.size()) {
+        set_err(errbuf, errlen, std::string("short write to ") + raw_tsv_out);
+        return SD_ERR_IO;
+    }
+    return SD_OK;
+}
+
+// -------------------------------------------------------------------------------------------
+// host-only helpers (CPU tests)
+// -------------------------------------------------------------------------------------------
+int32_t sd_chunk_plan(int64_t read_len, int32_t part_size, int32_t overlap, int64_t* off,
+                      int32_t* len, int32_t cap) {
+    int32_t k = 0;
+    return sd::chunk_plan(read_len, part_size, overlap, [&](int64_t o, int32_t l) {
+        if (k < cap) { if (off) off[k] = o; if (len) len[k] = l; }
+        ++k;
+    });
+}
+
+int32_t sd_seam_merge(sd_rec* recs, int32_t n) {
+    std::vector<sd_rec> v(recs, recs + (n > 0 ? n : 0));
+    sd::seam_merge(v);
+    if (!v.empty()) std::memcpy(recs, v.data(), sizeof(sd_rec) * v.size());
+    return (int32_t)v.size();
+}
+
+int sd_format_rows(const char* read_name, const char* const* tmpl_names, const sd_rec* rows,
+                   int32_t n_rows, char** txt, size_t* txt_len) {
+    if (!txt || !txt_len) return SD_ERR_PARAM;
+    int maxt = -1;
+    for (int32_t i = 0; i < n_rows; ++i) maxt = std::max(maxt, (int)rows[i].tmpl);
+    std::vector<std::string> tn;
+    for (int j = 0; j <= maxt; ++j) tn.emplace_back(tmpl_names[j]);
+    std::string o;
+    sd::format_rows(o, read_name, std::strlen(read_name), tn, rows, (size_t)std::max(n_rows, 0));
+    char* c = static_cast<char*>(std::malloc(o.size() + 1));
+    std::memcpy(c, o.data(), o.size());
+    c[o.size()] = 0;
+    *txt = c;
+    *txt_len = o.size();
+    return SD_OK;
+}
+
+int sd_fasta_load(const char* path, sd_fasta* out, char* errbuf, size_t errlen) {
+    if (!out) return SD_ERR_PARAM;
+    std::memset(out, 0, sizeof *out);
+    std::vector<sd::Seq> v;
+    bool hn = false;
+    std::string err;
+    int rc = sd::load_fasta(path, v, hn, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    out->n = (int32_t)v.size();
+    out->has_n = hn ? 1 : 0;
+    out->names = static_cast<char**>(std::malloc(sizeof(char*) * std::max<size_t>(v.size(), 1)));
+    out->seqs = static_cast<char**>(std::malloc(sizeof(char*) * std::max<size_t>(v.size(), 1)));
+    out->lens = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * std::max<size_t>(v.size(), 1)));
+    for (size_t i = 0; i < v.size(); ++i) {
+        out->names[i] = strdup(v[i].name.c_str());
+        out->seqs[i] = static_cast<char*>(std::malloc(v[i].seq.size() + 1));
+        std::memcpy(out->seqs[i], v[i].seq.data(), v[i].seq.size());
+        out->seqs[i][v[i].seq.size()] = 0;
+        out->lens[i] = (int64_t)v[i].seq.size();
+    }
+    return SD_OK;
+}
+
+void sd_fasta_free(sd_fasta* f) {
+    if (!f) return;
+    for (int32_t i = 0; i < f->n; ++i) { std::free(f->names[i]); std::free(f->seqs[i]); }
+    std::free(f->names);
+    std::free(f->seqs);
+    std::free(f->lens);
+    std::memset(f, 0, sizeof *f);
+}
+
+}  // extern "C"

@@ -1,0 +1,565 @@
+// sd_fast.hip -- fast device path of the DP fill + traceback for gfx950 (MI355X, wave64).
+//
+// Replaces AlignPartClassicDP (reference stringdecomposer/src/main.cpp:151-270) for scorings and
+// template sets that fit the packed-int16 lane layout described in sd_fast.hpp.
+//
+//  sd_fast_fill   one wave per chunk.  Row-synchronous sweep (rows are strictly sequential because
+//                 B_i = max_j dp[i-1][j][L_j-1] feeds every cell of row i, main.cpp:184-193); all
+//                 template cells of a row are processed two per VALU lane-op with v_pk_*_i16, in
+//                 the shifted domain E = D - k*del where the in-row deletion chain is a prefix
+//                 maximum (see sd_generic.hip header).  Per cell pair: 5 packed ops
+//                     u = max(E'[x-1], max(K, B+del));  v = u + (mm-del);  w = E'[x] + ins;
+//                     cand = max(v, w);  run = max(run, cand)
+//                 The cross-lane carry K of the chain is applied lazily (true E = max(local, K)).
+//                 The (mm - del) table of all templates lives in LDS, indexed by the read base.
+//                 Written to HBM per row: B_i and the arg-max virtual lane (8 bytes); every
+//                 FAST_R rows a checkpoint of the row (values relative to a moving base).
+//                 No per-cell back-pointers are stored: the traceback recomputes them.
+//  sd_fast_trace  one wave per chunk.  Walks the reference's traceback (main.cpp:217-269); for
+//                 every monomer instance it recomputes only that template's cells, block by block
+//                 from the checkpoints, derives the reference's priority-encoded moves
+//                 (DEL > INS > DIAG > START) into LDS and follows them.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+
+#include "sd_fast.hpp"
+
+#ifndef SD_USE_DPP
+#define SD_USE_DPP 0
+#endif
+
+namespace sd {
+
+namespace {
+
+constexpr uint32_t NEG2 = 0x80008000u;  // packed {-32768, -32768}
+constexpr int NEG16 = -32768;
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
+}
+__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
+}
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+__device__ __forceinline__ uint32_t pack2(int v) { return ((uint32_t)v & 0xffffu) * 0x10001u; }
+
+// value of lane (l - d), own value for l < d (callers mask those lanes)
+__device__ __forceinline__ uint32_t lane_up(uint32_t x, int d) {
+#if SD_USE_DPP
+    if (d == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+#endif
+    return (uint32_t)__shfl_up((int)x, d);
+}
+
+// max over the wave, valid in every lane (shuffle form) / in lane 63 (DPP form) -> broadcast
+__device__ __forceinline__ int wave_max(int v) {
+#if SD_USE_DPP
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+#else
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
+struct ReadCursor {
+    const uint32_t* w;   // 2-bit words of the chunk
+    const uint32_t* nm;  // N mask words or nullptr
+    __device__ __forceinline__ int code(int i) const {
+        int r = (w[i >> 4] >> (2 * (i & 15))) & 3;
+        if (nm && ((nm[i >> 5] >> (i & 31)) & 1)) r = 4;
+        return r;
+    }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// fill
+// ---------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(512) void sd_fast_fill(
+    const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
+    const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
+    const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int S, int32_t* __restrict__ Bout,
+    int32_t* __restrict__ argV, uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase) {
+    extern __shared__ uint32_t lds[];  // [5][P/4][64][4]
+    constexpr int TBL = 5 * P * 64;
+    for (int idx = threadIdx.x * 4; idx < TBL; idx += blockDim.x * 4)
+        *reinterpret_cast<uint4*>(&lds[idx]) = *reinterpret_cast<const uint4*>(&table[idx]);
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = (int)(blockDim.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * nw + wave;
+    if (c >= n_chunks) return;
+    const ChunkDesc cd = chunks[c];
+    const int n = cd.n;
+    ReadCursor rc{bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr};
+
+    const uint32_t* lc = lane_consts + lane * FAST_LANE_WORDS;
+    const uint32_t ins0 = lc[FLC_INS0];
+    const uint32_t startMask = lc[FLC_STARTMASK];
+    const uint32_t endOff = lc[FLC_ENDOFF];
+    const uint32_t start0 = lc[FLC_START0];
+    uint32_t scanMask[FAST_MAX_SCAN];
+#pragma unroll
+    for (int s = 0; s < FAST_MAX_SCAN; ++s) scanMask[s] = lc[FLC_SCAN0 + s];
+    const uint32_t ins2 = pack2(sc.ins);
+
+    int32_t* Bc = Bout + cd.row0 + (uint64_t)c;
+    int32_t* Vc = argV + cd.row0 + (uint64_t)c;
+    uint32_t* ck = ckpt + (uint64_t)cd.pad * (uint64_t)(P * 64) + lane;
+    int32_t* ckb = ckbase + cd.pad;
+
+    uint32_t L[P];
+    uint32_t tb[P];
+    uint32_t K = NEG2;
+    int base = 0, Brel = 0;
+
+    auto load_table = [&](int r) {
+        const uint32_t* t = lds + r * (P * 64) + lane * 4;
+#pragma unroll
+        for (int c4 = 0; c4 < P / 4; ++c4) {
+            const uint4 q = *reinterpret_cast<const uint4*>(t + c4 * 256);
+            tb[4 * c4 + 0] = q.x; tb[4 * c4 + 1] = q.y; tb[4 * c4 + 2] = q.z; tb[4 * c4 + 3] = q.w;
+        }
+    };
+    // exclusive, template-segmented prefix maximum over the virtual lanes (both planes at once)
+    auto excl_scan = [&](uint32_t a) {
+        uint32_t inc = a;
+#pragma unroll
+        for (int s = 0; s < FAST_MAX_SCAN; ++s) {
+            if (s < S) {
+                const uint32_t t = bfi(scanMask[s], lane_up(inc, 1 << s), NEG2);
+                inc = pk_max(inc, t);
+            }
+        }
+        return bfi(scanMask[0], lane_up(inc, 1), NEG2);
+    };
+    // B_{i+1} (relative) = max over template ends; arg = smallest virtual lane attaining it
+    auto reduce_ends = [&](uint32_t Eend, int row) {
+        const uint32_t val = pk_adds(Eend, endOff);
+        const int lo = (int)(short)(val & 0xffffu);
+        const int hi = (int)val >> 16;
+        const int b = wave_max(max(lo, hi));
+        const unsigned long long mlo = __ballot(lo == b);
+        const unsigned long long mhi = __ballot(hi == b);
+        const int v = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
+        Brel = b;
+        if (lane == 0) {
+            Bc[row] = base + b;
+            Vc[row] = v;
+        }
+    };
+
+    // ---- row 0 (main.cpp:171-182): E[0][k] = max(E[0][k-1], mm_k - del), E[0][0] = mm_0
+    load_table(rc.code(0));
+    L[0] = pk_adds(tb[0], start0);
+#pragma unroll
+    for (int q = 1; q < P; ++q) L[q] = pk_max(L[q - 1], tb[q]);
+    if (n > 1) load_table(rc.code(1));
+    K = excl_scan(L[P - 1]);
+    reduce_ends(pk_max(L[P - 1], K), 1);
+
+    for (int i = 1; i < n; ++i) {
+        if ((i & (FAST_R - 1)) == 0) {
+            // rebase on B_i and checkpoint the (true) row i-1 for the traceback
+            const uint32_t d2 = pack2(Brel);
+            base += Brel;
+            Brel = 0;
+            K = bfi(startMask, NEG2, pk_subs(K, d2));
+            const int q = (i / FAST_R) - 1;
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                L[s] = pk_subs(L[s], d2);
+                ck[(uint64_t)q * (P * 64) + s * 64] = pk_max(L[s], K);
+            }
+            if (lane == 0) ckb[q] = base;
+        }
+        const uint32_t Bd2 = pack2(Brel + sc.del);
+        const uint32_t KB = pk_max(K, Bd2);
+        uint32_t pd = bfi(startMask, NEG2, lane_up(pk_max(L[P - 1], K), 1));
+        uint32_t run = NEG2;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const uint32_t old = L[q];
+            const uint32_t u = pk_max(pd, KB);
+            const uint32_t v = pk_adds(u, tb[q]);
+            const uint32_t w = pk_adds(old, q == 0 ? ins0 : ins2);
+            const uint32_t cand = pk_max(v, w);
+            run = q == 0 ? cand : pk_max(run, cand);
+            L[q] = run;
+            pd = old;
+        }
+        if (i + 1 < n) load_table(rc.code(i + 1));
+        const uint32_t Kins = pk_adds(K, ins2);
+        const uint32_t X = excl_scan(pk_max(L[P - 1], Kins));
+        K = pk_max(Kins, X);
+        reduce_ends(pk_max(L[P - 1], K), i + 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// traceback with per-template recomputation
+// ---------------------------------------------------------------------------------------------
+template <int QK>
+__global__ __launch_bounds__(256) void sd_fast_trace(
+    const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
+    const uint32_t* __restrict__ nmask, const uint16_t* __restrict__ slot_of,
+    const uint8_t* __restrict__ tcodes, const uint32_t* __restrict__ lane_consts,
+    const int32_t* __restrict__ toff, const int32_t* __restrict__ tlen, ScoreArgs sc, int P,
+    const int32_t* __restrict__ B, const int32_t* __restrict__ argV,
+    const uint32_t* __restrict__ ckpt, const int32_t* __restrict__ ckbase,
+    DevRec* __restrict__ recs, int32_t* __restrict__ rec_cnt) {
+    __shared__ uint8_t pt_all[4][FAST_R][64];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + wave;
+    if (c >= n_chunks) return;
+    uint8_t(*pt)[64] = pt_all[wave];
+    const ChunkDesc cd = chunks[c];
+    const int n = cd.n;
+    ReadCursor rc{bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr};
+    const int32_t* Bc = B + cd.row0 + (uint64_t)c;
+    const int32_t* Vc = argV + cd.row0 + (uint64_t)c;
+    DevRec* out = recs + cd.row0;
+    const int ins = sc.ins, del = sc.del;
+    const int mD = sc.match - sc.del, xD = sc.mismatch - sc.del;
+
+    auto tmpl_of = [&](int v) {
+        const uint32_t t = lane_consts[(v & 63) * FAST_LANE_WORDS + FLC_TMPL];
+        return (int)((v >> 6) ? (t >> 16) : (t & 0xffffu));
+    };
+
+    int cnt = 0;
+    int e = n - 1;
+    int j = tmpl_of(Vc[n]);
+    while (true) {
+        const int Lj = tlen[j];
+        const int x0 = toff[j];
+        int code[QK];
+        int slot[QK];
+#pragma unroll
+        for (int q = 0; q < QK; ++q) {
+            const int k = lane * QK + q;
+            code[q] = k < Lj ? (int)tcodes[x0 + k] : 7;
+            slot[q] = k < Lj ? (int)slot_of[x0 + k] : 0;
+        }
+        int i = e, k = Lj - 1;
+        bool stop_row0 = false;
+        while (true) {
+            const int a = i & ~(FAST_R - 1);  // first row of the block
+            int32_t E[QK];
+            int rstart;
+            if (a == 0) {
+                // row 0, main.cpp:171-182
+                const int r = rc.code(0);
+                int32_t run = NEG_INF32;
+                int32_t loc[QK];
+#pragma unroll
+                for (int q = 0; q < QK; ++q) {
+                    const int kk = lane * QK + q;
+                    const int32_t mmd = code[q] == r ? mD : xD;
+                    const int32_t cand = kk == 0 ? mmd + del : mmd;
+                    run = kk == 0 ? cand : max(run, cand);
+                    loc[q] = run;
+                }
+                int32_t v = run;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int32_t v2 = __shfl_up(v, off);
+                    if (lane >= off) v = max(v, v2);
+                }
+                int32_t X = __shfl_up(v, 1);
+                if (lane == 0) X = NEG_INF32;
+                int32_t left = X;
+                uint32_t bits = 0;
+#pragma unroll
+                for (int q = 0; q < QK; ++q) {
+                    const int kk = lane * QK + q;
+                    const int32_t Ef = max(loc[q], X);
+                    const int pc = (kk != 0 && Ef == left) ? 0 : 3;
+                    bits |= (uint32_t)pc << (2 * q);
+                    left = Ef;
+                    E[q] = Ef;
+                }
+                pt[0][lane] = (uint8_t)bits;
+                rstart = 1;
+            } else {
+                const int q0 = a / FAST_R - 1;
+                const int32_t cb = ckbase[cd.pad + q0];
+                const uint32_t* ckq = ckpt + ((uint64_t)cd.pad + q0) * (uint64_t)(P * 64);
+#pragma unroll
+                for (int q = 0; q < QK; ++q) {
+                    const int v = slot[q] & 127, s = slot[q] >> 7;
+                    const uint32_t wv = ckq[s * 64 + (v & 63)];
+                    E[q] = cb + ((v >> 6) ? ((int)wv >> 16) : (int)(short)(wv & 0xffffu));
+                }
+                rstart = a;
+            }
+            for (int r_i = rstart; r_i <= i; ++r_i) {
+                const int r = rc.code(r_i);
+                const int32_t Bi = Bc[r_i];
+                const int32_t Bd = Bi + del;
+                int32_t pdEdge = __shfl_up(E[QK - 1], 1);
+                if (lane == 0) pdEdge = NEG_INF32;
+                int32_t loc[QK];
+                int32_t run = NEG_INF32, pd = pdEdge;
+#pragma unroll
+                for (int q = 0; q < QK; ++q) {
+                    const int kk = lane * QK + q;
+                    const int32_t mmd = code[q] == r ? mD : xD;
+                    const int32_t cand = kk == 0 ? Bd + mmd : max(max(pd, Bd) + mmd, E[q] + ins);
+                    run = kk == 0 ? cand : max(run, cand);
+                    loc[q] = run;
+                    pd = E[q];
+                }
+                int32_t v = run;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int32_t v2 = __shfl_up(v, off);
+                    if (lane >= off) v = max(v, v2);
+                }
+                int32_t X = __shfl_up(v, 1);
+                if (lane == 0) X = NEG_INF32;
+                int32_t left = X;
+                pd = pdEdge;
+                uint32_t bits = 0;
+#pragma unroll
+                for (int q = 0; q < QK; ++q) {
+                    const int kk = lane * QK + q;
+                    const int32_t Ef = max(loc[q], X);
+                    const int32_t old = E[q];
+                    const int32_t mmd = code[q] == r ? mD : xD;
+                    int pc;
+                    if (kk != 0 && Ef == left) pc = 0;                 // DEL   main.cpp:242
+                    else if (Ef == old + ins) pc = 1;                  // INS   main.cpp:245
+                    else if (kk != 0 && Ef == pd + mmd) pc = 2;        // DIAG  main.cpp:249
+                    else pc = 3;                                       // START main.cpp:253
+                    bits |= (uint32_t)pc << (2 * q);
+                    left = Ef;
+                    pd = old;
+                    E[q] = Ef;
+                }
+                pt[r_i - a][lane] = (uint8_t)bits;
+            }
+            // walk inside the block (wave-uniform)
+            bool done = false;
+            while (i >= a) {
+                const int pc = __builtin_amdgcn_readfirstlane((pt[i - a][k / QK] >> (2 * (k % QK))) & 3);
+                if (pc == 0) { --k; }
+                else if (pc == 1) { --i; }
+                else if (pc == 2) { --i; --k; }
+                else { done = true; break; }
+            }
+            if (done) { stop_row0 = (i == 0); break; }
+        }
+        if (lane == 0) {
+            DevRec rec;
+            rec.tmpl = j;
+            rec.start = i;
+            rec.end = e;
+            rec.score = Bc[e + 1] - (stop_row0 ? 0 : Bc[i]);  // main.cpp:255 / 258-262
+            out[cnt] = rec;
+        }
+        ++cnt;
+        if (stop_row0) break;
+        j = tmpl_of(Vc[i]);  // between-monomers hop, main.cpp:228-236
+        e = i - 1;
+    }
+    if (lane == 0) rec_cnt[c] = cnt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host: layout plan
+// ---------------------------------------------------------------------------------------------
+static int code_of(char ch) {
+    switch (ch) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T': return 3;
+        default: return 4;
+    }
+}
+
+bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max_rows,
+                     FastPlan& plan, std::string& why) {
+    (void)max_rows;
+    plan = FastPlan();
+    const int T = (int)tseq.size();
+    int Lmax = 0, Lmin = INT_MAX;
+    for (const std::string& s : tseq) {
+        Lmax = std::max(Lmax, (int)s.size());
+        Lmin = std::min(Lmin, (int)s.size());
+    }
+    if (T <= 0) { why = "no templates"; return false; }
+    if (Lmin < 2) { why = "a template shorter than 2 bp"; return false; }
+    if (sc.ins > 0 || sc.del > 0) { why = "positive gap scores"; return false; }
+    if (T > 65535) { why = "too many templates"; return false; }
+    auto ab = [](int v) { return v < 0 ? -v : v; };
+    const int maxabs = std::max(std::max(ab(sc.ins), ab(sc.del)), std::max(ab(sc.mismatch), ab(sc.match)));
+    if ((int64_t)(3 * Lmax + FAST_R + 4) * maxabs > 8000) { why = "scores too large for int16 cells"; return false; }
+    if (Lmax > 64 * 4) { why = "template longer than 256 bp"; return false; }
+
+    int P = 0, split = 0;
+    for (int p = 4; p <= 64; p += 4) {
+        int used = 0, s = 0;
+        while (s < T && used + ((int)tseq[s].size() + p - 1) / p <= 64) {
+            used += ((int)tseq[s].size() + p - 1) / p;
+            ++s;
+        }
+        int used2 = 0;
+        for (int j = s; j < T; ++j) used2 += ((int)tseq[j].size() + p - 1) / p;
+        if (used2 <= 64) { P = p; split = s; break; }
+    }
+    if (P == 0) { why = "template set does not fit 128 virtual lanes x 64 slots"; return false; }
+
+    plan.P = P;
+    plan.T = T;
+    plan.split = split;
+    plan.Lmax = Lmax;
+    plan.Qk = (Lmax + 63) / 64;
+    plan.vlane0.assign((size_t)T, 0);
+    int Vmax = 1;
+    {
+        int v = 0;
+        for (int j = 0; j < T; ++j) {
+            if (j == split) v = 64;
+            plan.vlane0[(size_t)j] = v;
+            const int V = ((int)tseq[(size_t)j].size() + P - 1) / P;
+            Vmax = std::max(Vmax, V);
+            v += V;
+        }
+    }
+    int S = 0;
+    while ((1 << S) < Vmax - 1) ++S;
+    plan.S = S;
+
+    // per virtual lane: owner template and index inside it
+    std::vector<int> owner(128, -1), uidx(128, 0), nv(128, 0);
+    for (int j = 0; j < T; ++j) {
+        const int V = ((int)tseq[(size_t)j].size() + P - 1) / P;
+        for (int u = 0; u < V; ++u) {
+            owner[(size_t)plan.vlane0[(size_t)j] + u] = j;
+            uidx[(size_t)plan.vlane0[(size_t)j] + u] = u;
+            nv[(size_t)plan.vlane0[(size_t)j] + u] = V;
+        }
+    }
+    auto put = [](uint32_t& w, int plane, int val) {
+        const uint32_t h = (uint32_t)val & 0xffffu;
+        w = plane ? ((w & 0x0000ffffu) | (h << 16)) : ((w & 0xffff0000u) | h);
+    };
+    plan.lane_consts.assign((size_t)64 * FAST_LANE_WORDS, 0u);
+    for (int v = 0; v < 128; ++v) {
+        const int plane = v >> 6, lane = v & 63;
+        uint32_t* lc = &plan.lane_consts[(size_t)lane * FAST_LANE_WORDS];
+        const int j = owner[(size_t)v];
+        const bool start = j < 0 || uidx[(size_t)v] == 0;
+        const bool last = j >= 0 && uidx[(size_t)v] == nv[(size_t)v] - 1;
+        put(lc[FLC_INS0], plane, start ? NEG16 : sc.ins);
+        put(lc[FLC_STARTMASK], plane, start ? 0xffff : 0);
+        put(lc[FLC_ENDOFF], plane, last ? ((int)tseq[(size_t)j].size() - 1) * sc.del : NEG16);
+        for (int s = 0; s < FAST_MAX_SCAN; ++s)
+            put(lc[FLC_SCAN0 + s], plane, (j >= 0 && uidx[(size_t)v] >= (1 << s)) ? 0xffff : 0);
+        put(lc[FLC_TMPL], plane, j >= 0 ? j : 0xffff);
+        put(lc[FLC_START0], plane, (j >= 0 && uidx[(size_t)v] == 0) ? sc.del : 0);
+    }
+    // LDS table image [5][P/4][64][4]
+    plan.table.assign((size_t)5 * P * 64, NEG2);
+    int64_t sumL = 0;
+    for (const std::string& s : tseq) sumL += (int64_t)s.size();
+    plan.slot_of.assign((size_t)sumL, 0);
+    plan.tcodes.assign((size_t)sumL, 0);
+    int64_t x = 0;
+    for (int j = 0; j < T; ++j) {
+        const std::string& s = tseq[(size_t)j];
+        for (int k = 0; k < (int)s.size(); ++k, ++x) {
+            const int v = plan.vlane0[(size_t)j] + k / P, slot = k % P;
+            const int plane = v >> 6, lane = v & 63;
+            const int cd = code_of(s[(size_t)k]);
+            plan.tcodes[(size_t)x] = (uint8_t)cd;
+            plan.slot_of[(size_t)x] = (uint16_t)((slot << 7) | v);
+            for (int b = 0; b < 5; ++b) {
+                const int val = (cd == b ? sc.match : sc.mismatch) - sc.del;
+                uint32_t& w = plan.table[(((size_t)b * (P / 4) + slot / 4) * 64 + lane) * 4 + (slot & 3)];
+                put(w, plane, val);
+            }
+        }
+    }
+    plan.ok = true;
+    return true;
+}
+
+int64_t fast_ckpt_rows_total(const FastPlan& plan, std::vector<ChunkDesc>& chunks) {
+    (void)plan;
+    int64_t tot = 0;
+    for (ChunkDesc& cd : chunks) {
+        cd.pad = (uint32_t)tot;
+        tot += (cd.n - 1) / FAST_R;
+    }
+    return tot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------------
+void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
+                      const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                      const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV,
+                      uint32_t* ckpt, int32_t* ckbase) {
+    const int NW = 8;
+    const int grid = (n_chunks + NW - 1) / NW;
+    const size_t lds = (size_t)5 * plan.P * 64 * sizeof(uint32_t);
+#define SD_FILL(PP)                                                                                \
+    case PP:                                                                                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP>),                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+        hipLaunchKernelGGL(sd_fast_fill<PP>, dim3(grid), dim3(NW * 64), lds, st, chunks, n_chunks, \
+                           bases2, nmask, table, lane_consts, sc, plan.S, B, argV, ckpt, ckbase);  \
+        break;
+    switch (plan.P) {
+        SD_FILL(4) SD_FILL(8) SD_FILL(12) SD_FILL(16) SD_FILL(20) SD_FILL(24) SD_FILL(28) SD_FILL(32)
+        SD_FILL(36) SD_FILL(40) SD_FILL(44) SD_FILL(48) SD_FILL(52) SD_FILL(56) SD_FILL(60) SD_FILL(64)
+        default: break;
+    }
+#undef SD_FILL
+}
+
+void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
+                       const uint32_t* bases2, const uint32_t* nmask, const uint16_t* slot_of,
+                       const uint8_t* tcodes, const uint32_t* lane_consts, const int32_t* toff,
+                       const int32_t* tlen, ScoreArgs sc, const int32_t* B, const int32_t* argV,
+                       const uint32_t* ckpt, const int32_t* ckbase, DevRec* recs,
+                       int32_t* rec_cnt) {
+    const int grid = (n_chunks + 3) / 4;
+#define SD_TRACE(QQ)                                                                              \
+    hipLaunchKernelGGL(sd_fast_trace<QQ>, dim3(grid), dim3(256), 0, st, chunks, n_chunks, bases2, \
+                       nmask, slot_of, tcodes, lane_consts, toff, tlen, sc, plan.P, B, argV, ckpt, \
+                       ckbase, recs, rec_cnt)
+    switch (plan.Qk) {
+        case 1: SD_TRACE(1); break;
+        case 2: SD_TRACE(2); break;
+        case 3: SD_TRACE(3); break;
+        default: SD_TRACE(4); break;
+    }
+#undef SD_TRACE
+}
+
+}  // namespace sd

@@ -1,0 +1,282 @@
+// sd_generic.hip -- generic (fallback) device path: any template set up to 32768 cells, int32
+// arithmetic, any scoring inside the INF bound.  One workgroup per chunk, the flattened template
+// axis blocked over the threads (Q cells per thread, in registers), 2-bit priority-encoded
+// back-pointers written to HBM, pointer-walking traceback.
+//
+// Replaces AlignPartClassicDP (reference stringdecomposer/src/main.cpp:151-270):
+//   fill      main.cpp:171-216   -> sd_generic_fill
+//   traceback main.cpp:217-269   -> sd_generic_trace
+//
+// The recurrence is evaluated in the shifted domain E[i][x] = D[i][x] - k*del (k = position of
+// cell x inside its template), where it loses every dependence on k:
+//   E[i][x] = max( B_i + mm,  E[i-1][x-1] + (mm - del),  E[i-1][x] + ins,  E[i][x-1] )
+// (first term only for k == 0), so the in-row deletion chain is a plain segmented prefix maximum.
+// The four equality tests of the traceback are invariant under the shift, so the 2-bit pointers
+// are exactly the reference's choices, in its priority order DEL > INS > DIAG > START.
+#include <hip/hip_runtime.h>
+
+#include "sd_device.hpp"
+#include "sd_kernels.hpp"
+
+namespace sd {
+
+template <int Q>
+__global__ __launch_bounds__(1024) void sd_generic_fill(
+    const ChunkDesc* __restrict__ chunks, int chunk_begin, const uint32_t* __restrict__ bases2,
+    const uint32_t* __restrict__ nmask, const uint8_t* __restrict__ tmeta,
+    const int32_t* __restrict__ tend_kd, const int32_t* __restrict__ tend_j, ScoreArgs sc,
+    int rowBytes, uint8_t* __restrict__ ptr, uint64_t row0_base, int32_t* __restrict__ Bout,
+    int32_t* __restrict__ argBout) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, nw = blockDim.x >> 6;
+    const int c = chunk_begin + blockIdx.x;
+    const ChunkDesc cd = chunks[c];
+    const int n = cd.n;
+    const int ins = sc.ins;
+    const int mD = sc.match - sc.del, xD = sc.mismatch - sc.del;
+
+    __shared__ int32_t waveV[16];
+    __shared__ int32_t waveF[16];
+    __shared__ long long waveKey[16];
+
+    uint8_t meta[Q];
+    bool anyStart = false;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        meta[q] = tmeta[t * Q + q];
+        anyStart |= (meta[q] & CELL_START) != 0;
+    }
+    int32_t E[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) E[q] = NEG_INF32;
+
+    uint8_t* prow = ptr + (cd.row0 - row0_base) * (uint64_t)rowBytes + (size_t)t * (Q / 4);
+    const uint64_t boff = cd.row0 + (uint64_t)c;  // B / argB have n+1 entries per chunk
+
+    int32_t pdEdge = NEG_INF32;  // final E of cell x0-1 in the previous row
+    int32_t Bi = 0;
+    uint32_t wbits = 0, nbits = 0;
+    for (int i = 0; i < n; ++i) {
+        if ((i & 15) == 0) wbits = bases2[cd.woff + (i >> 4)];
+        int r = (wbits >> (2 * (i & 15))) & 3;
+        if (cd.noff >= 0) {
+            if ((i & 31) == 0) nbits = nmask[cd.noff + (i >> 5)];
+            if ((nbits >> (i & 31)) & 1) r = 4;
+        }
+        const bool row0 = (i == 0);
+        const int32_t Bd = Bi + sc.del;
+
+        // pass A: local (in-thread) prefix maxima
+        int32_t loc[Q];
+        int32_t run = NEG_INF32, pd = pdEdge;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const bool st = (meta[q] & CELL_START) != 0;
+            const int32_t mmd = ((meta[q] & CELL_CODE_MASK) == r) ? mD : xD;
+            int32_t cand;
+            if (row0) cand = st ? mmd + sc.del : mmd;            // main.cpp:171-182
+            else if (st) cand = Bd + mmd;                        // k == 0: start term only
+            else cand = max(max(pd, Bd) + mmd, E[q] + ins);      // start/diag, ins
+            run = st ? cand : max(cand, run);                    // deletion chain
+            loc[q] = run;
+            pd = E[q];
+        }
+        // segmented inclusive max-scan of the thread totals over the workgroup
+        int32_t v = run;
+        int fl = anyStart ? 1 : 0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t v2 = __shfl_up(v, off);
+            const int f2 = __shfl_up(fl, off);
+            if (lane >= off) {
+                if (!fl) v = max(v, v2);
+                fl |= f2;
+            }
+        }
+        if (lane == 63) { waveV[w] = v; waveF[w] = fl; }
+        __syncthreads();
+        int32_t cw = NEG_INF32;
+        for (int w2 = 0; w2 < w; ++w2) cw = waveF[w2] ? waveV[w2] : max(cw, waveV[w2]);
+        const int32_t S = fl ? v : max(v, cw);
+        int32_t Sprev = __shfl_up(S, 1);
+        if (lane == 0) Sprev = cw;  // final E of cell x0-1 in THIS row
+
+        // pass B: apply the carry, derive the pointers, collect template-end values
+        int32_t left = Sprev;
+        pd = pdEdge;
+        bool before = true;
+        uint64_t codes = 0;
+        long long best = (long long)NEG_INF32 * 4294967296LL;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const bool st = (meta[q] & CELL_START) != 0;
+            if (st) before = false;
+            const int32_t Ef = before ? max(loc[q], Sprev) : loc[q];
+            const int32_t old = E[q];  // E[i-1][x]
+            const int32_t mmd = ((meta[q] & CELL_CODE_MASK) == r) ? mD : xD;
+            int pc;
+            if (!st && Ef == left) pc = 0;                          // DEL   main.cpp:242
+            else if (!row0 && Ef == old + ins) pc = 1;          // INS   main.cpp:245 (k==0 too)
+            else if (!row0 && !st && Ef == pd + mmd) pc = 2;        // DIAG  main.cpp:249
+            else pc = 3;                                            // START main.cpp:253 / STOP
+            codes |= (uint64_t)pc << (2 * q);
+            if (meta[q] & CELL_END) {
+                const int x = t * Q + q;
+                const long long key = (long long)(Ef + tend_kd[x]) * 4294967296LL +
+                                      (long long)(0x7fffffff - tend_j[x]);
+                best = max(best, key);
+            }
+            left = Ef;
+            pd = old;
+            E[q] = Ef;
+        }
+        pdEdge = Sprev;
+        {
+            uint8_t* p = prow + (size_t)i * rowBytes;
+            if (Q == 4) *p = (uint8_t)codes;
+            else if (Q == 8) *reinterpret_cast<uint16_t*>(p) = (uint16_t)codes;
+            else if (Q == 16) *reinterpret_cast<uint32_t*>(p) = (uint32_t)codes;
+            else *reinterpret_cast<uint64_t*>(p) = codes;
+        }
+        // B_{i+1} = max over template ends, first template on ties (main.cpp:184-186, 230-236)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) best = max(best, __shfl_xor(best, off));
+        if (lane == 0) waveKey[w] = best;
+        __syncthreads();
+        long long kb = waveKey[0];
+        for (int w2 = 1; w2 < nw; ++w2) kb = max(kb, waveKey[w2]);
+        Bi = (int32_t)(kb >> 32);
+        if (t == 0) {
+            Bout[boff + i + 1] = Bi;
+            argBout[boff + i + 1] = 0x7fffffff - (int32_t)(kb & 0xffffffffLL);
+        }
+    }
+}
+
+// Pointer-walking traceback (main.cpp:217-269).  One thread per chunk.
+__global__ void sd_generic_trace(const ChunkDesc* __restrict__ chunks, int chunk_begin,
+                                 int n_sub, const uint8_t* __restrict__ ptr, uint64_t row0_base,
+                                 int rowBytes, const int32_t* __restrict__ B,
+                                 const int32_t* __restrict__ argB, const int32_t* __restrict__ toff,
+                                 const int32_t* __restrict__ tlen, DevRec* __restrict__ recs,
+                                 int32_t* __restrict__ rec_cnt) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sub) return;
+    const int c = chunk_begin + s;
+    const ChunkDesc cd = chunks[c];
+    const int n = cd.n;
+    const uint8_t* p0 = ptr + (cd.row0 - row0_base) * (uint64_t)rowBytes;
+    const int32_t* Bc = B + cd.row0 + (uint64_t)c;
+    const int32_t* Ac = argB + cd.row0 + (uint64_t)c;
+    DevRec* out = recs + cd.row0;
+    int cnt = 0;
+    int i = n - 1, j = Ac[n], k = tlen[j] - 1, open_end = i;
+    while (true) {
+        const int x = toff[j] + k;
+        const int pc = (p0[(size_t)i * rowBytes + (x >> 2)] >> (2 * (x & 3))) & 3;
+        if (pc == 0) { --k; }
+        else if (pc == 1) { --i; }
+        else if (pc == 2) { --i; --k; }
+        else {
+            DevRec r;
+            r.tmpl = j;
+            r.start = i;
+            r.end = open_end;
+            r.score = Bc[open_end + 1] - (i != 0 ? Bc[i] : 0);  // main.cpp:255 / 258-262
+            out[cnt++] = r;
+            if (i == 0) break;
+            j = Ac[i];        // between-monomers hop, main.cpp:228-236
+            i = i - 1;
+            k = tlen[j] - 1;
+            open_end = i;
+        }
+    }
+    rec_cnt[c] = cnt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------------------------
+int generic_pick_q(int64_t sum_len) {
+    const int qs[4] = {4, 8, 16, 32};
+    for (int q : qs)
+        if ((sum_len + q - 1) / q <= 1024) return q;
+    return -1;
+}
+
+void launch_generic_fill(int Q, int threads, int grid, hipStream_t st, const ChunkDesc* chunks,
+                         int chunk_begin, const uint32_t* bases2, const uint32_t* nmask,
+                         const uint8_t* tmeta, const int32_t* tend_kd, const int32_t* tend_j,
+                         ScoreArgs sc, int rowBytes, uint8_t* ptr, uint64_t row0_base, int32_t* B,
+                         int32_t* argB) {
+#define SD_LAUNCH(QQ)                                                                            \
+    hipLaunchKernelGGL(sd_generic_fill<QQ>, dim3(grid), dim3(threads), 0, st, chunks, chunk_begin, \
+                       bases2, nmask, tmeta, tend_kd, tend_j, sc, rowBytes, ptr, row0_base, B, argB)
+    switch (Q) {
+        case 4: SD_LAUNCH(4); break;
+        case 8: SD_LAUNCH(8); break;
+        case 16: SD_LAUNCH(16); break;
+        default: SD_LAUNCH(32); break;
+    }
+#undef SD_LAUNCH
+}
+
+void launch_generic_trace(int n_sub, hipStream_t st, const ChunkDesc* chunks, int chunk_begin,
+                          const uint8_t* ptr, uint64_t row0_base, int rowBytes, const int32_t* B,
+                          const int32_t* argB, const int32_t* toff, const int32_t* tlen,
+                          DevRec* recs, int32_t* rec_cnt) {
+    const int bs = 64;
+    hipLaunchKernelGGL(sd_generic_trace, dim3((n_sub + bs - 1) / bs), dim3(bs), 0, st, chunks,
+                       chunk_begin, n_sub, ptr, row0_base, rowBytes, B, argB, toff, tlen, recs,
+                       rec_cnt);
+}
+
+// ---------------------------------------------------------------------------------------------
+// record compaction, shared by both kernel families
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sd_scan_counts(const int32_t* __restrict__ cnt, int n,
+                                                       int64_t* __restrict__ roff) {
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t base_s;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) base_s = 0;
+    __syncthreads();
+    for (int b = 0; b < n; b += 1024) {
+        const int idx = b + t;
+        const int64_t v = idx < n ? cnt[idx] : 0;
+        int64_t s = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t s2 = __shfl_up(s, off);
+            if (lane >= off) s += s2;
+        }
+        if (lane == 63) wsum[w] = s;
+        __syncthreads();
+        int64_t pre = base_s;
+        for (int w2 = 0; w2 < w; ++w2) pre += wsum[w2];
+        if (idx < n) roff[idx] = pre + s - v;
+        __syncthreads();
+        if (t == 1023) base_s = pre + s;
+        __syncthreads();
+    }
+    if (t == 0) roff[n] = base_s;
+}
+
+__global__ void sd_compact(const ChunkDesc* __restrict__ chunks, const int32_t* __restrict__ cnt,
+                           const int64_t* __restrict__ roff, const DevRec* __restrict__ recs,
+                           DevRec* __restrict__ out, int64_t out_cap) {
+    const int c = blockIdx.x;
+    const int k = cnt[c];
+    if (roff[c] + k > out_cap) return;  // host re-runs the compaction with a larger buffer
+    const DevRec* src = recs + chunks[c].row0;
+    DevRec* dst = out + roff[c];
+    for (int a = threadIdx.x; a < k; a += blockDim.x) dst[a] = src[k - 1 - a];  // reverse, main.cpp:268
+}
+
+void launch_compact(hipStream_t st, const ChunkDesc* chunks, int n_chunks, const int32_t* cnt,
+                    int64_t* roff, const DevRec* recs, DevRec* out, int64_t out_cap, bool scan) {
+    if (scan) hipLaunchKernelGGL(sd_scan_counts, dim3(1), dim3(1024), 0, st, cnt, n_chunks, roff);
+    hipLaunchKernelGGL(sd_compact, dim3(n_chunks), dim3(64), 0, st, chunks, cnt, roff, recs, out,
+                       out_cap);
+}
+
+}  // namespace sd

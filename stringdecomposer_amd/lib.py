@@ -1,0 +1,324 @@
+"""ctypes binding of libsd_hip.so (include/sd_hip.h).
+
+This is the call that replaces the reference's subprocess boundary
+(stringdecomposer/main.py:194: subprocess.run([SD_BIN, ...], stdout=raw_file)).  The library has
+no CPU fallback; a missing library or a missing GPU is a loud error.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+# SD_HIP_LIB lets a developer A/B an alternative build of the same library (never a CPU path)
+LIB_PATH = os.environ.get("SD_HIP_LIB") or os.path.join(HERE, "csrc", "libsd_hip.so")
+
+SD_OK = 0
+SD_ERR_IO = 2
+SD_ERR_FORMAT = 3
+SD_ERR_PARAM = 4
+SD_ERR_EMPTY = 6
+SD_ERR_INTERNAL = 7
+SD_ERR_NO_DEVICE = 8
+SD_ERR_UNSUPPORTED = 9
+SD_ERR_HIP = 10
+SD_ERR_SYMBOL = 255
+
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST = 0, 1, 2
+
+EXPORTS = [
+    "sd_params_default", "sd_version", "sd_device_count", "sd_free", "sd_decompose_files",
+    "sd_decompose", "sd_engine_create", "sd_engine_destroy", "sd_engine_load_reads",
+    "sd_engine_run", "sd_engine_fetch", "sd_engine_assemble", "sd_engine_timings",
+    "sd_engine_info", "sd_chunk_plan", "sd_seam_merge", "sd_format_rows", "sd_fasta_load",
+    "sd_fasta_free", "sd_nw_identity_batch",
+]
+
+
+class SdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libsd_hip rc=%d: %s" % (code, msg))
+        self.code = code
+        self.msg = msg
+
+
+class Params(C.Structure):
+    _fields_ = [("ins", C.c_int32), ("del_", C.c_int32), ("mismatch", C.c_int32),
+                ("match", C.c_int32), ("part_size", C.c_int32), ("overlap", C.c_int32),
+                ("ed_thr", C.c_int32), ("threads", C.c_int32), ("device", C.c_int32),
+                ("kernel", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
+class Rec(C.Structure):
+    _fields_ = [("tmpl", C.c_int32), ("start", C.c_int32), ("end", C.c_int32),
+                ("score", C.c_int32)]
+
+
+class Fasta(C.Structure):
+    _fields_ = [("n", C.c_int32), ("names", C.POINTER(C.c_char_p)),
+                ("seqs", C.POINTER(C.c_void_p)), ("lens", C.POINTER(C.c_int64)),
+                ("has_n", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Load libsd_hip.so.  Raises (never silently falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise SdError(SD_ERR_INTERNAL,
+                      "%s is missing: build it with `make -C stringdecomposer_amd/csrc` "
+                      "(or python -c 'import __graft_entry__ as g; g.build()')" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    L.sd_params_default.argtypes = [P(Params)]
+    L.sd_version.restype = C.c_char_p
+    L.sd_device_count.restype = C.c_int
+    L.sd_free.argtypes = [C.c_void_p]
+    L.sd_decompose_files.argtypes = [C.c_char_p, C.c_char_p, P(Params), C.c_char_p, C.c_char_p, C.c_size_t]
+    L.sd_decompose.argtypes = [P(C.c_char_p), P(C.c_char_p), P(C.c_int64), C.c_int32, P(C.c_char_p),
+                               P(C.c_char_p), P(C.c_int32), C.c_int32, P(Params), P(C.c_void_p),
+                               P(C.c_size_t), C.c_char_p, C.c_size_t]
+    L.sd_engine_create.argtypes = [P(C.c_void_p), P(Params), P(C.c_char_p), P(C.c_int32), C.c_int32,
+                                   C.c_char_p, C.c_size_t]
+    L.sd_engine_destroy.argtypes = [C.c_void_p]
+    L.sd_engine_load_reads.argtypes = [C.c_void_p, P(C.c_char_p), P(C.c_int64), C.c_int32,
+                                       P(C.c_int64), C.c_char_p, C.c_size_t]
+    L.sd_engine_run.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.sd_engine_fetch.argtypes = [C.c_void_p, P(P(Rec)), P(P(C.c_int64)), C.c_char_p, C.c_size_t]
+    L.sd_engine_assemble.argtypes = [C.c_void_p, P(Rec), P(C.c_int64), P(P(Rec)), P(P(C.c_int64)),
+                                     C.c_char_p, C.c_size_t]
+    L.sd_engine_timings.argtypes = [C.c_void_p, P(C.c_float)]
+    L.sd_engine_info.argtypes = [C.c_void_p, P(C.c_int64)]
+    L.sd_chunk_plan.restype = C.c_int32
+    L.sd_chunk_plan.argtypes = [C.c_int64, C.c_int32, C.c_int32, P(C.c_int64), P(C.c_int32), C.c_int32]
+    L.sd_seam_merge.restype = C.c_int32
+    L.sd_seam_merge.argtypes = [P(Rec), C.c_int32]
+    L.sd_format_rows.argtypes = [C.c_char_p, P(C.c_char_p), P(Rec), C.c_int32, P(C.c_void_p), P(C.c_size_t)]
+    L.sd_fasta_load.argtypes = [C.c_char_p, P(Fasta), C.c_char_p, C.c_size_t]
+    L.sd_fasta_free.argtypes = [P(Fasta)]
+    L.sd_nw_identity_batch.argtypes = [P(C.c_char_p), P(C.c_int32), P(C.c_char_p), P(C.c_int32),
+                                       C.c_int64, C.c_int32, P(C.c_int32), P(C.c_int32), P(C.c_int32)]
+    _lib = L
+    return L
+
+
+def _b(s):
+    return s if isinstance(s, bytes) else s.encode()
+
+
+def _strs(seq):
+    arr = (C.c_char_p * max(len(seq), 1))()
+    for i, s in enumerate(seq):
+        arr[i] = _b(s)
+    return arr
+
+
+def make_params(scoring=(-1, -1, -1, 1), part_size=5000, overlap=500, ed_thr=-1, threads=1,
+                device=0, kernel=KERNEL_AUTO):
+    L = load()
+    p = Params()
+    L.sd_params_default(C.byref(p))
+    p.ins, p.del_, p.mismatch, p.match = [int(x) for x in scoring]
+    p.part_size, p.overlap, p.ed_thr = int(part_size), int(overlap), int(ed_thr)
+    p.threads, p.device, p.kernel = int(threads), int(device), int(kernel)
+    return p
+
+
+def device_count():
+    return load().sd_device_count()
+
+
+def decompose_files(reads_fa, monomers_fa, raw_tsv_out, **kw):
+    """reads.fa + monomers.fa -> raw TSV file (the bytes `dp` would print on stdout)."""
+    L = load()
+    p = make_params(**kw)
+    err = C.create_string_buffer(4096)
+    rc = L.sd_decompose_files(os.fsencode(reads_fa), os.fsencode(monomers_fa), C.byref(p),
+                              os.fsencode(raw_tsv_out), err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+
+
+def decompose(read_names, read_seqs, mono_names, mono_seqs, **kw):
+    """In-memory variant -> raw TSV bytes."""
+    L = load()
+    p = make_params(**kw)
+    err = C.create_string_buffer(4096)
+    rs = [_b(s) for s in read_seqs]
+    ms = [_b(s) for s in mono_seqs]
+    rl = (C.c_int64 * max(len(rs), 1))(*[len(s) for s in rs])
+    ml = (C.c_int32 * max(len(ms), 1))(*[len(s) for s in ms])
+    out = C.c_void_p()
+    ln = C.c_size_t()
+    rc = L.sd_decompose(_strs(read_names), _strs(rs), rl, len(rs), _strs(mono_names), _strs(ms), ml,
+                        len(ms), C.byref(p), C.byref(out), C.byref(ln), err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+    data = C.string_at(out, ln.value)
+    L.sd_free(out)
+    return data
+
+
+class Engine:
+    """Device-resident batches: create (templates) -> load_reads -> run -> fetch -> assemble."""
+
+    def __init__(self, mono_seqs, **kw):
+        self.L = load()
+        self.params = make_params(**kw)
+        self._err = C.create_string_buffer(4096)
+        ms = [_b(s) for s in mono_seqs]
+        ml = (C.c_int32 * max(len(ms), 1))(*[len(s) for s in ms])
+        self.h = C.c_void_p()
+        rc = self.L.sd_engine_create(C.byref(self.h), C.byref(self.params), _strs(ms), ml, len(ms),
+                                     self._err, 4096)
+        self._check(rc)
+        self.n_chunks = 0
+        self.n_reads = 0
+
+    def _check(self, rc):
+        if rc != SD_OK:
+            raise SdError(rc, self._err.value.decode(errors="replace"))
+
+    def close(self):
+        if self.h:
+            self.L.sd_engine_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_reads(self, read_seqs):
+        rs = [_b(s) for s in read_seqs]
+        self._keep = rs
+        rl = (C.c_int64 * max(len(rs), 1))(*[len(s) for s in rs])
+        n = C.c_int64()
+        self._check(self.L.sd_engine_load_reads(self.h, _strs(rs), rl, len(rs), C.byref(n), self._err, 4096))
+        self.n_chunks = n.value
+        self.n_reads = len(rs)
+        return n.value
+
+    def run(self, stream=None):
+        self._check(self.L.sd_engine_run(self.h, C.c_void_p(stream or 0), self._err, 4096))
+
+    def fetch_raw(self):
+        recs = C.POINTER(Rec)()
+        off = C.POINTER(C.c_int64)()
+        self._check(self.L.sd_engine_fetch(self.h, C.byref(recs), C.byref(off), self._err, 4096))
+        return recs, off
+
+    def fetch(self):
+        """-> list over chunks of [(tmpl, start, end, score), ...] (chunk-local coordinates)."""
+        recs, off = self.fetch_raw()
+        out = []
+        for c in range(self.n_chunks):
+            out.append([(recs[x].tmpl, recs[x].start, recs[x].end, recs[x].score)
+                        for x in range(off[c], off[c + 1])])
+        self.L.sd_free(recs)
+        self.L.sd_free(off)
+        return out
+
+    def rows(self):
+        """run results assembled per read -> list over reads of [(tmpl, start, end, score), ...]."""
+        recs, off = self.fetch_raw()
+        rows = C.POINTER(Rec)()
+        roff = C.POINTER(C.c_int64)()
+        self._check(self.L.sd_engine_assemble(self.h, recs, off, C.byref(rows), C.byref(roff), self._err, 4096))
+        out = []
+        for r in range(self.n_reads):
+            out.append([(rows[x].tmpl, rows[x].start, rows[x].end, rows[x].score)
+                        for x in range(roff[r], roff[r + 1])])
+        for p in (recs, off, rows, roff):
+            self.L.sd_free(p)
+        return out
+
+    def total_rows(self):
+        """Number of assembled rows (cheap check used by bench.py)."""
+        recs, off = self.fetch_raw()
+        n = off[self.n_chunks]
+        self.L.sd_free(recs)
+        self.L.sd_free(off)
+        return n
+
+    def timings(self):
+        ms = (C.c_float * 4)()
+        rc = self.L.sd_engine_timings(self.h, ms)
+        if rc != SD_OK:
+            raise SdError(rc, "sd_engine_timings")
+        return {"fill_ms": ms[0], "trace_ms": ms[1], "compact_ms": ms[2], "run_ms": ms[3]}
+
+    def info(self):
+        v = (C.c_int64 * 8)()
+        self.L.sd_engine_info(self.h, v)
+        return {"n_templates": v[0], "sum_template_len": v[1], "n_chunks": v[2], "rows": v[3],
+                "family": {1: "generic", 2: "fast"}.get(v[4], "?"), "cells_per_lane": v[5],
+                "workspace_bytes": v[6], "fill_launches": v[7]}
+
+
+def format_rows(read_name, tmpl_names, rows):
+    L = load()
+    arr = (Rec * max(len(rows), 1))()
+    for i, r in enumerate(rows):
+        arr[i] = Rec(*[int(x) for x in r])
+    out = C.c_void_p()
+    ln = C.c_size_t()
+    rc = L.sd_format_rows(_b(read_name), _strs(tmpl_names), arr, len(rows), C.byref(out), C.byref(ln))
+    if rc != SD_OK:
+        raise SdError(rc, "sd_format_rows")
+    data = C.string_at(out, ln.value)
+    L.sd_free(out)
+    return data
+
+
+def chunk_plan(length, part=5000, overlap=500):
+    L = load()
+    n = L.sd_chunk_plan(length, part, overlap, None, None, 0)
+    off = (C.c_int64 * max(n, 1))()
+    ln = (C.c_int32 * max(n, 1))()
+    L.sd_chunk_plan(length, part, overlap, off, ln, n)
+    return [(off[i], ln[i]) for i in range(n)]
+
+
+def seam_merge(recs):
+    L = load()
+    arr = (Rec * max(len(recs), 1))()
+    for i, r in enumerate(recs):
+        arr[i] = Rec(*[int(x) for x in r])
+    m = L.sd_seam_merge(arr, len(recs))
+    return [(arr[i].tmpl, arr[i].start, arr[i].end, arr[i].score) for i in range(m)]
+
+
+def fasta_load(path):
+    """-> (names, seqs, has_n) with the reference binary's FASTA semantics (main.cpp:314-346)."""
+    L = load()
+    f = Fasta()
+    err = C.create_string_buffer(4096)
+    rc = L.sd_fasta_load(os.fsencode(path), C.byref(f), err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+    names = [f.names[i].decode() for i in range(f.n)]
+    seqs = [C.string_at(f.seqs[i], f.lens[i]) for i in range(f.n)]
+    has_n = bool(f.has_n)
+    L.sd_fasta_free(C.byref(f))
+    return names, seqs, has_n
+
+
+def nw_identity_batch(queries, targets, threads=1):
+    """[(dist, matches, columns)] of unit-cost NW alignments (main.py:29-60 semantics)."""
+    L = load()
+    n = len(queries)
+    q = [_b(s) for s in queries]
+    t = [_b(s) for s in targets]
+    ql = (C.c_int32 * max(n, 1))(*[len(s) for s in q])
+    tl = (C.c_int32 * max(n, 1))(*[len(s) for s in t])
+    d = (C.c_int32 * max(n, 1))()
+    m = (C.c_int32 * max(n, 1))()
+    c = (C.c_int32 * max(n, 1))()
+    rc = L.sd_nw_identity_batch(_strs(q), ql, _strs(t), tl, n, threads, d, m, c)
+    if rc != SD_OK:
+        raise SdError(rc, "sd_nw_identity_batch")
+    return [(d[i], m[i], c[i]) for i in range(n)]

@@ -1,0 +1,324 @@
+#!/usr/bin/env python3
+"""Drop-in command line of StringDecomposer on MI355X.
+
+Mirrors the reference driver stringdecomposer/main.py (same positional arguments, options,
+defaults, output files and log line), with the one process boundary of the reference --
+`subprocess.run([SD_BIN, ...], stdout=raw_file)` at main.py:194 -- replaced by a ctypes call into
+libsd_hip.so (HIP kernels for gfx950).  Post-processing of the raw TSV into
+final_decomposition.tsv / _alt.tsv follows main.py:29-184 without Bio / python-edlib / pandas.
+
+Documented difference: the reference CLI silently ignores -s/--scoring (it always launches the
+binary with 10 arguments, and main.cpp:381 parses scores only when argc == 10, i.e. 9 arguments).
+Here -s is honoured (the documented intent, README / main.py:210); pass --ref-compat to reproduce
+the reference CLI's effective behaviour (default scores whatever -s says).
+"""
+import argparse
+import logging
+import os
+import pathlib
+import sys
+
+import numpy as np
+
+from . import lib
+
+CUR_DIR = os.path.dirname(os.path.abspath(__file__))
+LOGREG_FILE = os.path.join(CUR_DIR, "models", "ont_logreg_model.txt")
+# main.py:25-26 -- intercept, coef(identity), coef(identity - second best)
+DEFAULT_LR = [-31.48494996, 0.41784018, 0.69186882]
+
+
+def _lr_coef():
+    if os.path.isfile(LOGREG_FILE):
+        with open(LOGREG_FILE) as f:
+            return list(map(float, f.readline().strip().split()))
+    return list(DEFAULT_LR)
+
+
+def get_logger(filename, logger_name="StringDecomposer", level=logging.INFO, filemode="a", stdout=True):
+    """py/standard_logger.py:5-28."""
+    logger = logging.getLogger(logger_name)
+    logger.setLevel(level)
+    for h in list(logger.handlers):
+        logger.removeHandler(h)
+    fh = logging.FileHandler(filename, mode=filemode)
+    formatter = logging.Formatter("%(asctime)s - %(name)s - %(levelname)s - %(message)s")
+    fh.setFormatter(formatter)
+    logger.addHandler(fh)
+    if stdout:
+        sh = logging.StreamHandler(sys.stdout)
+        sh.setFormatter(formatter)
+        logger.addHandler(sh)
+    return logger
+
+
+class Record:
+    """The three SeqRecord attributes main.py uses: .id/.name (first header token) and .seq."""
+    __slots__ = ("id", "name", "seq")
+
+    def __init__(self, rid, seq, name=None):
+        self.id = rid
+        self.name = name if name is not None else rid
+        self.seq = seq
+
+
+def read_fasta(filename):
+    """Bio.SeqIO.parse(filename, 'fasta') + .upper() (main.py:63-74): id = first word of the
+    title, sequence = remaining lines with whitespace removed, upper-cased."""
+    recs = []
+    name, chunks = None, []
+    with open(filename) as f:
+        for line in f:
+            if line.startswith(">"):
+                if name is not None:
+                    recs.append(Record(name, "".join(chunks).upper()))
+                title = line[1:].rstrip()
+                name = title.split(None, 1)[0] if title.split() else ""
+                chunks = []
+            elif name is not None:
+                chunks.append("".join(line.split()))
+    if name is not None:
+        recs.append(Record(name, "".join(chunks).upper()))
+    return recs
+
+
+def load_fasta(filename, tp="list"):
+    recs = read_fasta(filename)
+    if tp == "map":
+        d = {}
+        for r in recs:
+            if r.id in d:
+                raise ValueError("Duplicate key '%s'" % r.id)
+            d[r.id] = r
+        return d
+    return recs
+
+
+_COMP = str.maketrans("ACGTNacgtn", "TGCANtgcan")
+
+
+def add_rc_monomers(monomers):
+    """main.py:81-86: interleaved m0, m0', m1, m1', ..."""
+    res = []
+    for m in monomers:
+        res.append(m)
+        res.append(Record(m.id + "'", m.seq.translate(_COMP)[::-1], m.name + "'"))
+    return res
+
+
+def convert_to_homo(seq):
+    """main.py:87-92: homopolymer compression."""
+    res = []
+    prev = None
+    for c in seq:
+        if c != prev:
+            res.append(c)
+            prev = c
+    return "".join(res)
+
+
+def _strip_star(p):
+    return p[:-1] if p.endswith("*") else p
+
+
+def aai_batch(pairs, threads):
+    """main.py:38-60 for a list of (query, target): percent identity from the NW alignment."""
+    q = [_strip_star(a) for a, _ in pairs]
+    t = [_strip_star(b) for _, b in pairs]
+    res = lib.nw_identity_batch(q, t, threads=threads)
+    out = []
+    for ed, matches, cols in res:
+        if ed == -1:
+            out.append(0)
+        else:
+            a = 0.0
+            a += matches       # sum of the '=' run lengths (integers; exact in a double)
+            a /= cols
+            out.append(a * 100)
+    return out
+
+
+def classify(reads_mapping, coef):
+    """main.py:95-104 (pandas DataFrame.dot == numpy dot over [1, score, score - second_best])."""
+    if not reads_mapping:
+        return reads_mapping
+    s = np.array([float(r["score"]) for r in reads_mapping], dtype=np.float64)
+    s2 = np.array([float(r["second_best_score"]) for r in reads_mapping], dtype=np.float64)
+    X = np.stack([np.ones_like(s), s, s - s2], axis=1)
+    y = X.dot(np.array(coef, dtype=np.float64)) > 0
+    for i, r in enumerate(reads_mapping):
+        if not y[i]:
+            r["q"] = "?"
+    return reads_mapping
+
+
+def convert_read(decomposition, read, monomers, light, threads, coef):
+    """main.py:107-150."""
+    res = []
+    if light:
+        by_name = {}
+        for m in monomers:
+            by_name[m.name] = m  # the reference keeps the last monomer of a given name
+        pairs = [(read.seq[d["start"]:d["end"] + 1], by_name[d["m"]].seq) for d in decomposition]
+        scores = aai_batch(pairs, threads)
+        for d, sc in zip(decomposition, scores):
+            res.append({"m": d["m"], "start": str(d["start"]), "end": str(d["end"]), "score": sc,
+                        "second_best": "None", "second_best_score": -1,
+                        "homo_best": "None", "homo_best_score": -1,
+                        "homo_second_best": "None", "homo_second_best_score": -1,
+                        "alt": {}, "q": "+"})
+    else:
+        homo_m = [convert_to_homo(m.seq) for m in monomers]
+        pairs = []
+        for d in decomposition:
+            seg = read.seq[d["start"]:d["end"] + 1]
+            hseg = convert_to_homo(seg)
+            for m in monomers:
+                pairs.append((seg, m.seq))
+            for hm in homo_m:
+                pairs.append((hseg, hm))
+        vals = aai_batch(pairs, threads)
+        T = len(monomers)
+        for i, d in enumerate(decomposition):
+            base = i * 2 * T
+            scores = {}
+            for x, m in enumerate(monomers):
+                scores[m.name] = vals[base + x]
+            monomer = d["m"]
+            secondbest, secondbest_score = None, -1
+            for m in scores:
+                if m != monomer:
+                    if not secondbest or secondbest_score < scores[m]:
+                        secondbest, secondbest_score = m, scores[m]
+            homo_scores = [[m.name, vals[base + T + x]] for x, m in enumerate(monomers)]
+            homo_scores = sorted(homo_scores, key=lambda x: -x[1])
+            res.append({"m": monomer, "start": str(d["start"]), "end": str(d["end"]),
+                        "score": scores[monomer],
+                        "second_best": str(secondbest), "second_best_score": secondbest_score,
+                        "homo_best": homo_scores[0][0], "homo_best_score": homo_scores[0][1],
+                        "homo_second_best": homo_scores[1][0], "homo_second_best_score": homo_scores[1][1],
+                        "alt": scores, "q": "+"})
+    return classify(res, coef)
+
+
+def print_read(fout, fout_alt, dec, read, monomers, identity_th, light, threads, coef):
+    """main.py:153-165."""
+    dec = convert_read(dec, read, monomers, light, threads, coef)
+    for d in dec:
+        if d["score"] >= identity_th:
+            fout.write("\t".join([read.name, d["m"], d["start"], d["end"], "{:.2f}".format(d["score"]),
+                                  d["second_best"], "{:.2f}".format(d["second_best_score"]),
+                                  d["homo_best"], "{:.2f}".format(d["homo_best_score"]),
+                                  d["homo_second_best"], "{:.2f}".format(d["homo_second_best_score"]),
+                                  d["q"]]) + "\n")
+            for a in d["alt"]:
+                star = "*" if a == d["m"] else "-"
+                fout_alt.write("\t".join([read.name, a, d["start"], d["end"],
+                                          "{:.2f}".format(d["alt"][a]), star]) + "\n")
+
+
+def convert_tsv(decomposition, reads, monomers, outfile, identity_th, light, threads=1):
+    """main.py:168-184."""
+    coef = _lr_coef()
+    with open(outfile[:-len(".tsv")] + "_alt.tsv", "w") as fout_alt:
+        with open(outfile, "w") as fout:
+            cur_dec = []
+            prev_read = None
+            for ln in decomposition.split("\n")[:-1]:
+                read, monomer, start, end = ln.split("\t")[:4]
+                read = read.split()[0]
+                monomer = monomer.split()[0]
+                if read != prev_read and prev_read is not None:
+                    print_read(fout, fout_alt, cur_dec, reads[prev_read], monomers, identity_th, light, threads, coef)
+                    cur_dec = []
+                prev_read = read
+                cur_dec.append({"m": monomer, "start": int(start), "end": int(end)})
+            if len(cur_dec) > 0:
+                print_read(fout, fout_alt, cur_dec, reads[prev_read], monomers, identity_th, light, threads, coef)
+
+
+def run(sequences, monomers, num_threads, scoring, batch_size, raw_file, ed_thr, overlap, logger,
+        ref_compat=False, device=0, kernel=0):
+    """main.py:186-197 with the subprocess replaced by libsd_hip.so."""
+    ins, dels, mm, match = [int(x) for x in scoring.split(",")]
+    if ref_compat:
+        ins, dels, mm, match = -1, -1, -1, 1  # what the reference binary does with 10 argv (main.cpp:381)
+    try:
+        lib.load()
+    except lib.SdError as e:
+        logger.info("The HIP library of String Decomposer is not available. Did you forget to run `make`? Aborting. (%s)" % e.msg)
+        sys.exit(1)
+    logger.info(" ".join(["Run", lib.LIB_PATH, "with parameters", sequences, monomers, str(num_threads),
+                          str(batch_size), str(overlap), scoring]))
+    lib.decompose_files(sequences, monomers, raw_file, scoring=(ins, dels, mm, match),
+                        part_size=int(batch_size), overlap=int(overlap), ed_thr=int(ed_thr),
+                        threads=int(num_threads), device=device, kernel=kernel)
+    with open(raw_file, "r") as f:
+        raw_decomposition = "".join(f.readlines())
+    return raw_decomposition
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description="Decomposes string into blocks alphabet")
+    parser.add_argument("sequences", help="fasta-file with long reads or genomic sequences")
+    parser.add_argument("monomers", help="fasta-file with monomers")
+    parser.add_argument("-t", "--threads", help="number of threads (by default 1)", default="1", required=False)
+    parser.add_argument("-o", "--out-dir", help="output directory (by default .)", default=".", required=False)
+    parser.add_argument("--out-file", help='output tsv-file (by default "final_decomposition")',
+                        default="final_decomposition", required=False)
+    parser.add_argument("-i", "--min-identity",
+                        help="only monomer alignments with percent identity >= MIN_IDENTITY are printed (by default MIN_IDENTITY=0)",
+                        type=int, default=0, required=False)
+    parser.add_argument("-s", "--scoring",
+                        help='set scoring scheme for SD in the format "insertion,deletion,mismatch,match" (by default "-1,-1,-1,1")',
+                        default="-1,-1,-1,1", required=False)
+    parser.add_argument("-b", "--batch-size", help="set size of the batch in parallelization (by default 5000)",
+                        type=str, default="5000", required=False)
+    parser.add_argument("--second-best", dest="second_best",
+                        help="generate second best monomer and homopolymer scores", action="store_true")
+    parser.add_argument("--ed_thr",
+                        help="align only monomers with edit distance less then ed_thr for each segment (by default align all monomers)",
+                        default=-1, type=int, required=False)
+    parser.add_argument("-v", "--overlap", help="set size of batch overlap (by default 500)", type=str,
+                        default="500", required=False)
+    # opt-in extras of this build (never change defaults)
+    parser.add_argument("--ref-compat", action="store_true",
+                        help="reproduce the reference CLI exactly: -s/--scoring is ignored (default scores)")
+    parser.add_argument("--device", type=int, default=0, help="HIP device ordinal (by default 0)")
+    parser.add_argument("--kernel", choices=["auto", "generic", "fast"], default="auto",
+                        help="device kernel family (by default auto)")
+    args = parser.parse_args(argv)
+    pathlib.Path(args.out_dir).mkdir(parents=True, exist_ok=True)
+
+    logfn = os.path.join(args.out_dir, "stringdecomposer.log")
+    logger = get_logger(logfn, logger_name="StringDecomposer")
+    logger.info(f"cmd: {sys.argv}")
+
+    raw_decomp_fn = os.path.join(args.out_dir, args.out_file + "_raw.tsv")
+    kernel = {"auto": 0, "generic": 1, "fast": 2}[args.kernel]
+    try:
+        raw_decomposition = run(args.sequences, args.monomers, args.threads, args.scoring, args.batch_size,
+                                raw_decomp_fn, args.ed_thr, args.overlap, logger,
+                                ref_compat=args.ref_compat, device=args.device, kernel=kernel)
+    except lib.SdError as e:
+        # the reference dies with CalledProcessError after the binary printed its message on stderr
+        sys.stderr.write(e.msg + "\n")
+        logger.info("String Decomposer failed: " + e.msg)
+        sys.exit(e.code if 0 < e.code < 256 else 1)
+    logger.info("Saved raw decomposition to " + raw_decomp_fn)
+
+    reads = load_fasta(args.sequences, "map")
+    monomers = load_fasta(args.monomers)
+    monomers = add_rc_monomers(monomers)
+    logger.info("Transforming raw alignments...")
+
+    convert_tsv_fn = os.path.join(args.out_dir, args.out_file + ".tsv")
+    convert_tsv(raw_decomposition, reads, monomers, convert_tsv_fn, int(args.min_identity),
+                not args.second_best, threads=max(1, int(args.threads)))
+    logger.info("Transformation finished. Results can be found in " + convert_tsv_fn)
+
+    logger.info("Thank you for using StringDecomposer!")
+
+
+if __name__ == "__main__":
+    main()

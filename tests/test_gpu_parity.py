@@ -1,0 +1,137 @@
+"""Parity of the HIP path (through the C-ABI of libsd_hip.so) against
+  * the committed golden fixtures = stdout of the real reference binary, and
+  * the CPU oracle on fresh seeded inputs,
+bit-exact (integer / index work).  Runs only on a real MI355X: `pytest -m gpu`."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import GOLDEN, ROOT, case_names, load_case
+
+from stringdecomposer_amd import lib, synth
+
+pytestmark = pytest.mark.gpu
+
+FAMILIES = [("generic", lib.KERNEL_GENERIC), ("fast", lib.KERNEL_FAST)]
+
+
+def _decompose_case(c, kernel, tmp_path):
+    sc = tuple(c["scoring"]) if c["scoring"] else (-1, -1, -1, 1)
+    out = str(tmp_path / "raw.tsv")
+    lib.decompose_files(c["reads"], c["monomers"], out, scoring=sc, part_size=c["part"],
+                        overlap=c["overlap"], kernel=kernel)
+    with open(out, "rb") as f:
+        return f.read()
+
+
+@pytest.mark.parametrize("fam", FAMILIES, ids=[f[0] for f in FAMILIES])
+@pytest.mark.parametrize("name", case_names())
+def test_golden_fixture_raw_tsv(name, fam, tmp_path):
+    c = load_case(name)
+    try:
+        got = _decompose_case(c, fam[1], tmp_path)
+    except lib.SdError as e:
+        if fam[0] == "fast" and e.code == lib.SD_ERR_UNSUPPORTED:
+            pytest.skip("fast family not applicable: " + e.msg)
+        raise
+    assert hashlib.sha256(got).hexdigest() == c["sha256"], "raw TSV differs from the reference binary's"
+    assert got == c["raw"]
+
+
+def test_auto_family_picks_fast_for_default_config(tmp_path):
+    c = load_case("td_default")
+    mn, ms = synth.make_monomers(12, seed=1)
+    e = lib.Engine(ms)
+    assert e.info()["family"] == "fast"
+    e.close()
+    assert _decompose_case(c, lib.KERNEL_AUTO, tmp_path) == c["raw"]
+
+
+@pytest.mark.parametrize("name", case_names(include_errors=True))
+def test_error_cases(name, tmp_path):
+    if not name.startswith("err_"):
+        pytest.skip("not an error case")
+    c = load_case(name)
+    with pytest.raises(lib.SdError) as e:
+        _decompose_case(c, lib.KERNEL_AUTO, tmp_path)
+    assert e.value.code == lib.SD_ERR_SYMBOL
+    assert e.value.msg.strip() == c["stderr_tail"][0].strip()
+
+
+def test_empty_read_is_an_error_not_a_crash():
+    mn, ms = synth.make_monomers(12, seed=1)
+    with pytest.raises(lib.SdError) as e:
+        lib.decompose(["a", "b"], [b"ACGT", b""], mn, ms)
+    assert e.value.code == lib.SD_ERR_EMPTY
+
+
+@pytest.mark.parametrize("fam", FAMILIES, ids=[f[0] for f in FAMILIES])
+@pytest.mark.parametrize("sc", [(-1, -1, -1, 1), (-2, -3, -4, 2), (-1, -2, -1, 1), (0, 0, 0, 1), (-3, -1, -2, 3)])
+def test_chunk_level_vs_oracle(oracle, fam, sc):
+    """Engine-level: chunk-local records (template, start, end, score) vs AlignPartClassicDP."""
+    mn, ms = synth.make_monomers(12, seed=21)
+    tm = [m.decode() for m in ms] + [synth.revcomp_bytes(m).decode() for m in ms]
+    rn, rs = synth.make_reads(ms, 6, read_len=2300, seed=31)
+    lens = [2300, 1, 37, 640, 1999, 2048]
+    rs = [s[:L] for s, L in zip(rs, lens)]
+    e = lib.Engine(ms, scoring=sc, part_size=5000, overlap=500, kernel=fam[1])
+    assert e.load_reads(rs) == len(rs)
+    e.run()
+    got = e.fetch()
+    e.close()
+    for s, g in zip(rs, got):
+        exp = oracle.align_chunk(s.decode(), tm, sc)
+        assert g == [(t, a, b, int(v)) for (t, a, b, v) in exp]
+
+
+@pytest.mark.parametrize("fam", FAMILIES, ids=[f[0] for f in FAMILIES])
+def test_random_reads_vs_oracle_full_pipeline(oracle, fam):
+    mn, ms = synth.make_monomers(12, seed=77)
+    rn, rs = synth.make_reads(ms, 3, read_len=12345, seed=78)
+    got = lib.decompose(rn, rs, mn, ms, kernel=fam[1])
+    exp = oracle.decompose(rn, rs, mn, ms, threads=8)
+    assert got == exp
+
+
+def test_families_agree_at_bench_scale():
+    """Size-independent property at BASELINE config-2 read length: both kernel families (independent
+    implementations: stored back-pointers vs checkpoint + recomputation) give identical rows, the
+    rows tile each read without gaps inside a chunk and every score is bounded by its span."""
+    mn, ms = synth.make_monomers(12, seed=1)
+    rn, rs = synth.make_reads(ms, 24, read_len=50000, seed=1)
+    res = {}
+    for name, k in FAMILIES:
+        e = lib.Engine(ms, kernel=k)
+        assert e.load_reads(rs) == 240
+        e.run()
+        res[name] = e.fetch()
+        e.close()
+    assert res["fast"] == res["generic"]
+    for chunk in res["fast"]:
+        assert chunk[0][1] == 0
+        for a, b in zip(chunk, chunk[1:]):
+            assert b[1] == a[2] + 1
+        for (t, s, en, sc) in chunk:
+            assert 0 <= t < 24 and s <= en and sc <= en - s + 1 + 174
+
+
+def test_cli_end_to_end_reference_golden(tmp_path):
+    """The reference's own integration test (reference Makefile:16-19): CLI with --second-best on
+    test_data, grep the log line, diff final_decomposition.tsv against the golden file."""
+    td = os.path.join(GOLDEN, "test_data")
+    out = str(tmp_path / "out")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "stringdecomposer"),
+                        os.path.join(td, "read.fa"), os.path.join(td, "DXZ1_star_monomers.fa"),
+                        "-o", out, "--second-best", "-t", "4"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    assert p.returncode == 0, p.stdout.decode()
+    with open(os.path.join(out, "stringdecomposer.log")) as f:
+        assert "Thank you for using StringDecomposer!" in f.read()
+    with open(os.path.join(out, "final_decomposition.tsv"), "rb") as f, \
+            open(os.path.join(td, "final_decomposition_fc89af8.tsv"), "rb") as g:
+        assert f.read() == g.read()
+    with open(os.path.join(out, "final_decomposition_raw.tsv"), "rb") as f:
+        assert f.read() == load_case("td_default")["raw"]

@@ -1,0 +1,183 @@
+"""CPU-only checks of the product library: it loads, exports the whole C-ABI of include/sd_hip.h,
+and its host-side pieces (chunk plan, seam merge, TSV formatting, FASTA ingest, NW identity,
+final-TSV post-processing) agree with the oracle / the reference's golden files.
+No device compute happens here."""
+import ctypes
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import CASES, GOLDEN, ROOT, case_names, load_case
+
+from stringdecomposer_amd import lib, main as sdmain, synth
+
+
+def test_library_loads_and_exports_header_symbols():
+    L = lib.load()
+    with open(os.path.join(ROOT, "include", "sd_hip.h")) as f:
+        hdr = f.read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sd_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(lib.EXPORTS)
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.sd_version()
+
+
+def test_no_cpu_fallback_without_device():
+    if lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    mn, ms = synth.make_monomers(12, seed=1)
+    with pytest.raises(lib.SdError) as e:
+        lib.Engine(ms)
+    assert e.value.code == lib.SD_ERR_NO_DEVICE
+    with pytest.raises(lib.SdError) as e:
+        lib.decompose(["r"], [b"ACGT" * 10], mn, ms)
+    assert e.value.code == lib.SD_ERR_NO_DEVICE
+
+
+def test_param_validation_is_host_side():
+    mn, ms = synth.make_monomers(2, seed=1)
+    with pytest.raises(lib.SdError) as e:
+        lib.Engine(ms, ed_thr=10)
+    assert e.value.code == lib.SD_ERR_UNSUPPORTED
+    with pytest.raises(lib.SdError) as e:
+        lib.Engine(ms, part_size=0)
+    assert e.value.code == lib.SD_ERR_PARAM
+    with pytest.raises(lib.SdError) as e:
+        lib.Engine([b"ACGTX"])
+    assert e.value.code == lib.SD_ERR_SYMBOL
+    with pytest.raises(lib.SdError) as e:
+        lib.Engine(ms, scoring=(-1000, -1, -1, 1))  # reaches the reference's INF sentinel
+    assert e.value.code == lib.SD_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("length", [0, 1, 2, 499, 500, 501, 4999, 5000, 5001, 5499, 5500, 5501,
+                                    10499, 10500, 50000, 94871])
+@pytest.mark.parametrize("po", [(5000, 500), (700, 100), (333, 77), (100, 0), (10, 500)])
+def test_chunk_plan_matches_oracle(oracle, length, po):
+    assert lib.chunk_plan(length, *po) == oracle.chunk_plan(length, *po)
+
+
+def test_seam_merge_matches_oracle(oracle):
+    st = synth.Stream(5, 5)
+    for trial in range(200):
+        n = int(st.below(1, 40)[0])
+        recs, pos = [], 0
+        for _ in range(n):
+            a = pos + int(st.below(1, 200)[0]) - 60
+            b = a + int(st.below(1, 260)[0])
+            recs.append((int(st.below(1, 24)[0]), a, b, int(st.below(1, 300)[0]) - 100))
+            pos = b
+        got = lib.seam_merge(recs)
+        exp = [(t, s, e, int(sc)) for (t, s, e, sc) in oracle.postprocess([(t, s, e, float(sc)) for t, s, e, sc in recs])]
+        assert got == exp
+
+
+def test_format_rows_matches_reference_text():
+    c = load_case("td_default")
+    lines = c["raw"].decode().splitlines()
+    read_name = lines[0].split("\t")[0]
+    names = sorted({ln.split("\t")[1] for ln in lines})
+    rows = []
+    for ln in lines:
+        f = ln.split("\t")
+        rows.append((names.index(f[1]), int(f[2]), int(f[3]), int(float(f[4]))))
+    assert lib.format_rows(read_name, names, rows) == c["raw"]
+    # negative scores / zero
+    txt = lib.format_rows("r", ["m"], [(0, 0, 0, -166), (0, 1, 5, 0)])
+    assert txt == b"r\tm\t0\t0\t-166.000000\t0\t0\nr\tm\t1\t5\t0.000000\t1\t4\n"
+
+
+def test_fasta_load_semantics(tmp_path):
+    p = tmp_path / "a.fa"
+    p.write_bytes(b">r1 some description\nACGT\n\nNNAC\n>r2\tx\nGG\n")
+    names, seqs, has_n = lib.fasta_load(str(p))
+    assert names == ["r1", "r2"] and seqs == [b"ACGTNNAC", b"GG"] and has_n
+    for name in case_names(include_errors=True):
+        if not name.startswith("err_"):
+            continue
+        c = load_case(name)
+        with pytest.raises(lib.SdError) as e:
+            lib.fasta_load(c["reads"])
+        assert e.value.code == lib.SD_ERR_SYMBOL
+        assert e.value.msg.strip() == c["stderr_tail"][0].strip()
+    with pytest.raises(lib.SdError) as e:
+        lib.fasta_load(str(tmp_path / "missing.fa"))
+    assert e.value.code == lib.SD_ERR_IO
+
+
+def _rand_seq(st, n):
+    return bytes(b"ACGT"[i] for i in st.below(n, 4))
+
+
+def test_nw_identity_matches_oracle_and_edlib(oracle):
+    st = synth.Stream(9, 9)
+    qs, ts = [], []
+    for trial in range(300):
+        L = int(st.below(1, 230)[0]) + 1
+        t = synth._ACGT[st.below(L, 4)].tobytes()
+        mode = trial % 4
+        if mode == 0:
+            codes = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), np.frombuffer(t, dtype=np.uint8))
+            q = synth._to_ascii(synth.mutate(codes, st, 0.1, 0.05, 0.05)) or b"A"
+        elif mode == 1:
+            q = synth._ACGT[st.below(int(st.below(1, 300)[0]) + 1, 4)].tobytes()   # unrelated
+        elif mode == 2:
+            q = t[: max(1, L // 2)]
+        else:
+            q = t[::-1]
+        qs.append(q)
+        ts.append(t)
+    qs += [b"", b"ACGT", b"A" * 700, b"ACGT" * 40]
+    ts += [b"ACGT", b"", b"A" * 170, b"TGCA" * 40]
+    got = lib.nw_identity_batch(qs, ts, threads=3)
+    for q, t, g in zip(qs, ts, got):
+        assert g == oracle.nw_identity(q, t), (q, t)
+    if os.path.isfile(oracle.REF_EDLIB):
+        ed = ctypes.CDLL(oracle.REF_EDLIB)
+
+        class Cfg(ctypes.Structure):
+            _fields_ = [("k", ctypes.c_int), ("mode", ctypes.c_int), ("task", ctypes.c_int),
+                        ("eq", ctypes.c_void_p), ("neq", ctypes.c_int)]
+
+        class Res(ctypes.Structure):
+            _fields_ = [("status", ctypes.c_int), ("editDistance", ctypes.c_int),
+                        ("endLocations", ctypes.POINTER(ctypes.c_int)),
+                        ("startLocations", ctypes.POINTER(ctypes.c_int)),
+                        ("numLocations", ctypes.c_int),
+                        ("alignment", ctypes.POINTER(ctypes.c_ubyte)),
+                        ("alignmentLength", ctypes.c_int), ("alphabetLength", ctypes.c_int)]
+
+        ed.edlibAlign.restype = Res
+        ed.edlibAlign.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, Cfg]
+        ed.edlibFreeAlignResult.argtypes = [Res]
+        for q, t, g in zip(qs, ts, got):
+            if not q or not t:
+                continue
+            r = ed.edlibAlign(q, len(q), t, len(t), Cfg(-1, 0, 2, None, 0))   # NW, path
+            m = sum(1 for i in range(r.alignmentLength) if r.alignment[i] == 0)
+            assert (r.editDistance, m, r.alignmentLength) == g
+            ed.edlibFreeAlignResult(r)
+
+
+def test_final_tsv_postprocessing_reproduces_reference_golden(tmp_path):
+    """The reference's own golden file (made with --second-best, reference Makefile:17-19)."""
+    c = load_case("td_default")
+    td = os.path.join(GOLDEN, "test_data")
+    reads = sdmain.load_fasta(os.path.join(td, "read.fa"), "map")
+    mons = sdmain.add_rc_monomers(sdmain.load_fasta(os.path.join(td, "DXZ1_star_monomers.fa")))
+    out = str(tmp_path / "final_decomposition.tsv")
+    sdmain.convert_tsv(c["raw"].decode(), reads, mons, out, 0, False, threads=4)
+    with open(out, "rb") as f, open(os.path.join(td, "final_decomposition_fc89af8.tsv"), "rb") as g:
+        assert f.read() == g.read()
+    # light mode: sha recorded from the unmodified reference CLI
+    sdmain.convert_tsv(c["raw"].decode(), reads, mons, out, 0, True, threads=2)
+    with open(out, "rb") as f:
+        assert hashlib.sha256(f.read()).hexdigest() == \
+            "de9d4cc554051d842022f0a75db18a7d4ce7b3aa97af9cadc6ef960c7ea8ee85"
+    assert os.path.getsize(out[:-4] + "_alt.tsv") == 0
