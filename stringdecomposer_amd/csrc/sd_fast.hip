@@ -27,7 +27,7 @@
 #include "sd_fast.hpp"
 
 #ifndef SD_USE_DPP
-#define SD_USE_DPP 0
+#define SD_USE_DPP 1
 #endif
 
 namespace sd {
@@ -91,14 +91,19 @@ struct ReadCursor {
 // ---------------------------------------------------------------------------------------------
 // fill
 // ---------------------------------------------------------------------------------------------
+// Stored state of a wave after row i: S[x] = E[i][x] - base - tp*ins  (tp = rows since the last
+// rebase), so that the insertion move costs nothing:
+//   S_new[x] = max( max(S[x-1], B_i + del - tp*ins) + (mm - del - ins),  S[x],  S_new[x-1] )
+// i.e. 4 packed ops per cell pair: u = max(pd, KB); v = u + tbl; cand = max(v, old); run = max(run, cand).
 template <int P>
-__global__ __launch_bounds__(512) void sd_fast_fill(
+__global__ __launch_bounds__(512, 4) void sd_fast_fill(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
-    const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int S, int32_t* __restrict__ Bout,
+    const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int H, int32_t* __restrict__ Bout,
     int32_t* __restrict__ argV, uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase) {
-    extern __shared__ uint32_t lds[];  // [5][P/4][64][4]
-    constexpr int TBL = 5 * P * 64;
+    constexpr int P4 = (P + 3) & ~3;
+    extern __shared__ uint32_t lds[];  // [5][P4/4][64][4]
+    constexpr int TBL = 5 * P4 * 64;
     for (int idx = threadIdx.x * 4; idx < TBL; idx += blockDim.x * 4)
         *reinterpret_cast<uint4*>(&lds[idx]) = *reinterpret_cast<const uint4*>(&table[idx]);
     __syncthreads();
@@ -113,13 +118,10 @@ __global__ __launch_bounds__(512) void sd_fast_fill(
     ReadCursor rc{bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr};
 
     const uint32_t* lc = lane_consts + lane * FAST_LANE_WORDS;
-    const uint32_t ins0 = lc[FLC_INS0];
     const uint32_t startMask = lc[FLC_STARTMASK];
+    const uint32_t contMask = lc[FLC_CONTMASK];
     const uint32_t endOff = lc[FLC_ENDOFF];
-    const uint32_t start0 = lc[FLC_START0];
-    uint32_t scanMask[FAST_MAX_SCAN];
-#pragma unroll
-    for (int s = 0; s < FAST_MAX_SCAN; ++s) scanMask[s] = lc[FLC_SCAN0 + s];
+    const uint32_t row0adj = lc[FLC_ROW0];
     const uint32_t ins2 = pack2(sc.ins);
 
     int32_t* Bc = Bout + cd.row0 + (uint64_t)c;
@@ -128,31 +130,27 @@ __global__ __launch_bounds__(512) void sd_fast_fill(
     int32_t* ckb = ckbase + cd.pad;
 
     uint32_t L[P];
-    uint32_t tb[P];
+    uint32_t tb[P4];
     uint32_t K = NEG2;
-    int base = 0, Brel = 0;
+    int base = 0, Brel = 0, tp = 0;
+    int accB = 0, accV = 0;  // B / arg-max of the last <=64 rows, one row per lane
 
     auto load_table = [&](int r) {
-        const uint32_t* t = lds + r * (P * 64) + lane * 4;
+        const uint32_t* t = lds + r * (P4 * 64) + lane * 4;
 #pragma unroll
-        for (int c4 = 0; c4 < P / 4; ++c4) {
+        for (int c4 = 0; c4 < P4 / 4; ++c4) {
             const uint4 q = *reinterpret_cast<const uint4*>(t + c4 * 256);
             tb[4 * c4 + 0] = q.x; tb[4 * c4 + 1] = q.y; tb[4 * c4 + 2] = q.z; tb[4 * c4 + 3] = q.w;
         }
     };
-    // exclusive, template-segmented prefix maximum over the virtual lanes (both planes at once)
+    // exclusive, template-segmented prefix maximum over the virtual lanes (both planes at once):
+    // H = Vmax-1 carry hops of one lane each (DPP wave_shr:1)
     auto excl_scan = [&](uint32_t a) {
         uint32_t inc = a;
-#pragma unroll
-        for (int s = 0; s < FAST_MAX_SCAN; ++s) {
-            if (s < S) {
-                const uint32_t t = bfi(scanMask[s], lane_up(inc, 1 << s), NEG2);
-                inc = pk_max(inc, t);
-            }
-        }
-        return bfi(scanMask[0], lane_up(inc, 1), NEG2);
+        for (int h = 1; h < H; ++h) inc = pk_max(a, bfi(contMask, lane_up(inc, 1), NEG2));
+        return H > 0 ? bfi(contMask, lane_up(inc, 1), NEG2) : NEG2;
     };
-    // B_{i+1} (relative) = max over template ends; arg = smallest virtual lane attaining it
+    // B_{row} (relative to base) = max over template ends; arg = smallest virtual lane attaining it
     auto reduce_ends = [&](uint32_t Eend, int row) {
         const uint32_t val = pk_adds(Eend, endOff);
         const int lo = (int)(short)(val & 0xffffu);
@@ -161,29 +159,38 @@ __global__ __launch_bounds__(512) void sd_fast_fill(
         const unsigned long long mlo = __ballot(lo == b);
         const unsigned long long mhi = __ballot(hi == b);
         const int v = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
-        Brel = b;
-        if (lane == 0) {
-            Bc[row] = base + b;
-            Vc[row] = v;
+        Brel = b + tp * sc.ins;
+        const int slot = (row - 1) & 63;
+        const bool mine = lane == slot;
+        accB = mine ? base + Brel : accB;
+        accV = mine ? v : accV;
+        if (slot == 63 || row == n) {
+            if (lane <= slot) {
+                Bc[row - slot + lane] = accB;
+                Vc[row - slot + lane] = accV;
+            }
         }
     };
 
     // ---- row 0 (main.cpp:171-182): E[0][k] = max(E[0][k-1], mm_k - del), E[0][0] = mm_0
     load_table(rc.code(0));
-    L[0] = pk_adds(tb[0], start0);
+    L[0] = pk_adds(tb[0], row0adj);
 #pragma unroll
-    for (int q = 1; q < P; ++q) L[q] = pk_max(L[q - 1], tb[q]);
+    for (int q = 1; q < P; ++q) L[q] = pk_max(L[q - 1], pk_adds(tb[q], ins2));
     if (n > 1) load_table(rc.code(1));
     K = excl_scan(L[P - 1]);
-    reduce_ends(pk_max(L[P - 1], K), 1);
+    uint32_t Eend = pk_max(L[P - 1], K);
+    reduce_ends(Eend, 1);
 
     for (int i = 1; i < n; ++i) {
         if ((i & (FAST_R - 1)) == 0) {
-            // rebase on B_i and checkpoint the (true) row i-1 for the traceback
-            const uint32_t d2 = pack2(Brel);
+            // rebase on B_i, fold the row offset tp*ins back in, checkpoint the (true) row i-1
+            const uint32_t d2 = pack2(Brel - tp * sc.ins);
             base += Brel;
             Brel = 0;
+            tp = 0;
             K = bfi(startMask, NEG2, pk_subs(K, d2));
+            Eend = pk_subs(Eend, d2);
             const int q = (i / FAST_R) - 1;
 #pragma unroll
             for (int s = 0; s < P; ++s) {
@@ -192,26 +199,41 @@ __global__ __launch_bounds__(512) void sd_fast_fill(
             }
             if (lane == 0) ckb[q] = base;
         }
-        const uint32_t Bd2 = pack2(Brel + sc.del);
-        const uint32_t KB = pk_max(K, Bd2);
-        uint32_t pd = bfi(startMask, NEG2, lane_up(pk_max(L[P - 1], K), 1));
-        uint32_t run = NEG2;
+        const uint32_t KB = pk_max(K, pack2(Brel + sc.del - tp * sc.ins));
+        const uint32_t pd0 = bfi(startMask, NEG2, lane_up(Eend, 1));
+        const uint32_t w0 = bfi(startMask, NEG2, L[0]);
+        uint32_t u_[P], v_[P], c_[P];
+        uint32_t run = 0;
+        // software-pipelined over the slots so that no packed op consumes the result of the
+        // instruction right before it (gfx950 needs a wait state there)
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const uint32_t old = L[q];
-            const uint32_t u = pk_max(pd, KB);
-            const uint32_t v = pk_adds(u, tb[q]);
-            const uint32_t w = pk_adds(old, q == 0 ? ins0 : ins2);
-            const uint32_t cand = pk_max(v, w);
-            run = q == 0 ? cand : pk_max(run, cand);
-            L[q] = run;
-            pd = old;
+        for (int s = 0; s < P + 3; ++s) {
+            if (s >= 3) {
+                const int q = s - 3;
+                run = q == 0 ? c_[0] : pk_max(run, c_[q]);
+                L[q] = run;
+            }
+            if (s >= 2 && s - 2 < P) {
+                const int q = s - 2;
+                c_[q] = pk_max(v_[q], q == 0 ? w0 : L[q]);
+            }
+            if (s >= 1 && s - 1 < P) {
+                const int q = s - 1;
+                v_[q] = pk_adds(u_[q], tb[q]);
+            }
+            if (s < P) {
+                const int q = s;
+                u_[q] = pk_max(q == 0 ? pd0 : L[q - 1], KB);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (i + 1 < n) load_table(rc.code(i + 1));
-        const uint32_t Kins = pk_adds(K, ins2);
-        const uint32_t X = excl_scan(pk_max(L[P - 1], Kins));
-        K = pk_max(Kins, X);
-        reduce_ends(pk_max(L[P - 1], K), i + 1);
+        const uint32_t a = pk_max(L[P - 1], K);
+        const uint32_t X = excl_scan(a);
+        K = pk_max(K, X);
+        Eend = pk_max(a, X);
+        ++tp;
+        reduce_ends(Eend, i + 1);
     }
 }
 
@@ -419,7 +441,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     if (Lmax > 64 * 4) { why = "template longer than 256 bp"; return false; }
 
     int P = 0, split = 0;
-    for (int p = 4; p <= 64; p += 4) {
+    for (int p : FAST_P_LIST) {
         int used = 0, s = 0;
         while (s < T && used + ((int)tseq[s].size() + p - 1) / p <= 64) {
             used += ((int)tseq[s].size() + p - 1) / p;
@@ -432,6 +454,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     if (P == 0) { why = "template set does not fit 128 virtual lanes x 64 slots"; return false; }
 
     plan.P = P;
+    plan.P4 = (P + 3) & ~3;
     plan.T = T;
     plan.split = split;
     plan.Lmax = Lmax;
@@ -448,9 +471,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
             v += V;
         }
     }
-    int S = 0;
-    while ((1 << S) < Vmax - 1) ++S;
-    plan.S = S;
+    plan.H = Vmax - 1;
 
     // per virtual lane: owner template and index inside it
     std::vector<int> owner(128, -1), uidx(128, 0), nv(128, 0);
@@ -473,16 +494,15 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         const int j = owner[(size_t)v];
         const bool start = j < 0 || uidx[(size_t)v] == 0;
         const bool last = j >= 0 && uidx[(size_t)v] == nv[(size_t)v] - 1;
-        put(lc[FLC_INS0], plane, start ? NEG16 : sc.ins);
         put(lc[FLC_STARTMASK], plane, start ? 0xffff : 0);
+        put(lc[FLC_CONTMASK], plane, start ? 0 : 0xffff);
         put(lc[FLC_ENDOFF], plane, last ? ((int)tseq[(size_t)j].size() - 1) * sc.del : NEG16);
-        for (int s = 0; s < FAST_MAX_SCAN; ++s)
-            put(lc[FLC_SCAN0 + s], plane, (j >= 0 && uidx[(size_t)v] >= (1 << s)) ? 0xffff : 0);
+        put(lc[FLC_ROW0], plane, (j >= 0 && uidx[(size_t)v] == 0) ? sc.ins + sc.del : sc.ins);
         put(lc[FLC_TMPL], plane, j >= 0 ? j : 0xffff);
-        put(lc[FLC_START0], plane, (j >= 0 && uidx[(size_t)v] == 0) ? sc.del : 0);
     }
-    // LDS table image [5][P/4][64][4]
-    plan.table.assign((size_t)5 * P * 64, NEG2);
+    // LDS table image [5][P4/4][64][4]: (mm - del - ins) per template cell, NEG on padding / idle
+    const int P4 = plan.P4;
+    plan.table.assign((size_t)5 * P4 * 64, NEG2);
     int64_t sumL = 0;
     for (const std::string& s : tseq) sumL += (int64_t)s.size();
     plan.slot_of.assign((size_t)sumL, 0);
@@ -497,8 +517,8 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
             plan.tcodes[(size_t)x] = (uint8_t)cd;
             plan.slot_of[(size_t)x] = (uint16_t)((slot << 7) | v);
             for (int b = 0; b < 5; ++b) {
-                const int val = (cd == b ? sc.match : sc.mismatch) - sc.del;
-                uint32_t& w = plan.table[(((size_t)b * (P / 4) + slot / 4) * 64 + lane) * 4 + (slot & 3)];
+                const int val = (cd == b ? sc.match : sc.mismatch) - sc.del - sc.ins;
+                uint32_t& w = plan.table[(((size_t)b * (P4 / 4) + slot / 4) * 64 + lane) * 4 + (slot & 3)];
                 put(w, plane, val);
             }
         }
@@ -526,17 +546,19 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
                       uint32_t* ckpt, int32_t* ckbase) {
     const int NW = 8;
     const int grid = (n_chunks + NW - 1) / NW;
-    const size_t lds = (size_t)5 * plan.P * 64 * sizeof(uint32_t);
+    const size_t lds = (size_t)5 * plan.P4 * 64 * sizeof(uint32_t);
 #define SD_FILL(PP)                                                                                \
     case PP:                                                                                       \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP>),                \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
         hipLaunchKernelGGL(sd_fast_fill<PP>, dim3(grid), dim3(NW * 64), lds, st, chunks, n_chunks, \
-                           bases2, nmask, table, lane_consts, sc, plan.S, B, argV, ckpt, ckbase);  \
+                           bases2, nmask, table, lane_consts, sc, plan.H, B, argV, ckpt, ckbase);  \
         break;
     switch (plan.P) {
-        SD_FILL(4) SD_FILL(8) SD_FILL(12) SD_FILL(16) SD_FILL(20) SD_FILL(24) SD_FILL(28) SD_FILL(32)
-        SD_FILL(36) SD_FILL(40) SD_FILL(44) SD_FILL(48) SD_FILL(52) SD_FILL(56) SD_FILL(60) SD_FILL(64)
+        SD_FILL(4) SD_FILL(8) SD_FILL(12) SD_FILL(16) SD_FILL(20) SD_FILL(24) SD_FILL(28) SD_FILL(30)
+        SD_FILL(31) SD_FILL(32) SD_FILL(33) SD_FILL(34) SD_FILL(35) SD_FILL(36) SD_FILL(37) SD_FILL(38)
+        SD_FILL(39) SD_FILL(40) SD_FILL(42) SD_FILL(44) SD_FILL(46) SD_FILL(48) SD_FILL(52) SD_FILL(56)
+        SD_FILL(60) SD_FILL(64)
         default: break;
     }
 #undef SD_FILL

@@ -20,33 +20,36 @@
 namespace sd {
 
 constexpr int FAST_R = 32;          // checkpoint / rebase interval (rows)
-constexpr int FAST_MAX_SCAN = 6;    // scan steps available in the lane-constant block
-constexpr int FAST_LANE_WORDS = 12; // dwords of per-lane constants
+constexpr int FAST_LANE_WORDS = 8;  // dwords of per-lane constants
 
 // per-lane constant block (dword index), every dword = packed {lo plane, hi plane} int16
 enum FastLaneConst {
-    FLC_INS0 = 0,     // ins for slot 0 (NEG for the first virtual lane of a template)
-    FLC_STARTMASK,    // 0xffff where the virtual lane starts a template (or is idle)
-    FLC_ENDOFF,       // (L-1)*del on the last virtual lane of a template, NEG elsewhere
-    FLC_SCAN0,        // FLC_SCAN0+s: 0xffff where virtual lane v-2^s belongs to the same template
-    FLC_TMPL = FLC_SCAN0 + FAST_MAX_SCAN,  // template index per plane (for the traceback: vlane -> template)
-    FLC_START0,       // slot-0 adjustment for row 0 (del on start lanes, 0 elsewhere)
+    FLC_STARTMASK = 0, // 0xffff where the virtual lane starts a template (or is idle)
+    FLC_CONTMASK,      // 0xffff where virtual lane v-1 belongs to the same template
+    FLC_ENDOFF,        // (L-1)*del on the last virtual lane of a template, NEG elsewhere
+    FLC_ROW0,          // row-0 adjustment of slot 0: ins+del on start lanes, ins elsewhere
+    FLC_TMPL,          // template index per plane (for the traceback: vlane -> template)
 };
 
 struct FastPlan {
     bool ok = false;
     int P = 0;            // slots per virtual lane
-    int S = 0;            // inclusive-scan steps: 2^S >= Vmax-1
+    int P4 = 0;           // P rounded up to a multiple of 4 (LDS table row)
+    int H = 0;            // carry hops of the cross-lane chain: Vmax-1
     int T = 0;
     int split = 0;        // templates [0,split) in the lo plane
     int Lmax = 0;
     int Qk = 0;           // traceback: template cells per lane = ceil(Lmax/64)
     std::vector<int32_t> vlane0;         // first virtual lane of template j
-    std::vector<uint32_t> table;         // [5][P/4][64][4] packed (mm - del) values, NEG on padding
+    std::vector<uint32_t> table;         // [5][P4/4][64][4] packed (mm - del - ins), NEG on padding
     std::vector<uint32_t> lane_consts;   // [64][FAST_LANE_WORDS]
     std::vector<uint16_t> slot_of;       // per template cell x=toff[j]+k: (slot << 7) | vlane
     std::vector<uint8_t> tcodes;         // per template cell: base code
 };
+
+// slots-per-virtual-lane values the fill kernel is instantiated for
+static const int FAST_P_LIST[] = {4, 8, 12, 16, 20, 24, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39,
+                                  40, 42, 44, 46, 48, 52, 56, 60, 64};
 
 // Builds the plan; returns false (with the reason) when the fast family cannot represent the
 // input exactly (then the generic family is used).
