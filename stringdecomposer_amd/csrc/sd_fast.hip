@@ -49,7 +49,7 @@ __device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
 }
 __device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
-__device__ __forceinline__ uint32_t pack2(int v) { return ((uint32_t)v & 0xffffu) * 0x10001u; }
+__device__ __forceinline__ uint32_t pack2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
 
 // value of lane (l - d), own value for l < d (callers mask those lanes)
 __device__ __forceinline__ uint32_t lane_up(uint32_t x, int d) {
@@ -125,7 +125,6 @@ __global__ __launch_bounds__(512, 4) void sd_fast_fill(
     const uint32_t ins2 = pack2(sc.ins);
 
     int32_t* Bc = Bout + cd.row0 + (uint64_t)c;
-    int32_t* Vc = argV + cd.row0 + (uint64_t)c;
     uint32_t* ck = ckpt + (uint64_t)cd.pad * (uint64_t)(P * 64) + lane;
     int32_t* ckb = ckbase + cd.pad;
 
@@ -133,7 +132,7 @@ __global__ __launch_bounds__(512, 4) void sd_fast_fill(
     uint32_t tb[P4];
     uint32_t K = NEG2;
     int base = 0, Brel = 0, tp = 0;
-    int accB = 0, accV = 0;  // B / arg-max of the last <=64 rows, one row per lane
+    int accBV = 0;  // (B << 7 | arg-max virtual lane) of the last <=64 rows, one row per lane
 
     auto load_table = [&](int r) {
         const uint32_t* t = lds + r * (P4 * 64) + lane * 4;
@@ -161,14 +160,9 @@ __global__ __launch_bounds__(512, 4) void sd_fast_fill(
         const int v = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
         Brel = b + tp * sc.ins;
         const int slot = (row - 1) & 63;
-        const bool mine = lane == slot;
-        accB = mine ? base + Brel : accB;
-        accV = mine ? v : accV;
+        accBV = lane == slot ? (int)(((uint32_t)(base + Brel) << 7) | (uint32_t)v) : accBV;
         if (slot == 63 || row == n) {
-            if (lane <= slot) {
-                Bc[row - slot + lane] = accB;
-                Vc[row - slot + lane] = accV;
-            }
+            if (lane <= slot) Bc[row - slot + lane] = accBV;
         }
     };
 
@@ -177,7 +171,7 @@ __global__ __launch_bounds__(512, 4) void sd_fast_fill(
     L[0] = pk_adds(tb[0], row0adj);
 #pragma unroll
     for (int q = 1; q < P; ++q) L[q] = pk_max(L[q - 1], pk_adds(tb[q], ins2));
-    if (n > 1) load_table(rc.code(1));
+    load_table(rc.code(n > 1 ? 1 : 0));
     K = excl_scan(L[P - 1]);
     uint32_t Eend = pk_max(L[P - 1], K);
     reduce_ends(Eend, 1);
@@ -227,7 +221,7 @@ __global__ __launch_bounds__(512, 4) void sd_fast_fill(
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (i + 1 < n) load_table(rc.code(i + 1));
+        load_table(rc.code(i + 1 < n ? i + 1 : i));  // unconditional: keeps tb[] out of phi copies
         const uint32_t a = pk_max(L[P - 1], K);
         const uint32_t X = excl_scan(a);
         K = pk_max(K, X);
@@ -258,8 +252,9 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
     const ChunkDesc cd = chunks[c];
     const int n = cd.n;
     ReadCursor rc{bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr};
-    const int32_t* Bc = B + cd.row0 + (uint64_t)c;
-    const int32_t* Vc = argV + cd.row0 + (uint64_t)c;
+    const int32_t* BVc = B + cd.row0 + (uint64_t)c;  // (B << 7) | arg-max virtual lane
+    auto Bof = [&](int r) { return BVc[r] >> 7; };
+    auto Vof = [&](int r) { return BVc[r] & 127; };
     DevRec* out = recs + cd.row0;
     const int ins = sc.ins, del = sc.del;
     const int mD = sc.match - sc.del, xD = sc.mismatch - sc.del;
@@ -271,7 +266,7 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
 
     int cnt = 0;
     int e = n - 1;
-    int j = tmpl_of(Vc[n]);
+    int j = tmpl_of(Vof(n));
     while (true) {
         const int Lj = tlen[j];
         const int x0 = toff[j];
@@ -337,7 +332,7 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
             }
             for (int r_i = rstart; r_i <= i; ++r_i) {
                 const int r = rc.code(r_i);
-                const int32_t Bi = Bc[r_i];
+                const int32_t Bi = Bof(r_i);
                 const int32_t Bd = Bi + del;
                 int32_t pdEdge = __shfl_up(E[QK - 1], 1);
                 if (lane == 0) pdEdge = NEG_INF32;
@@ -397,12 +392,12 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
             rec.tmpl = j;
             rec.start = i;
             rec.end = e;
-            rec.score = Bc[e + 1] - (stop_row0 ? 0 : Bc[i]);  // main.cpp:255 / 258-262
+            rec.score = Bof(e + 1) - (stop_row0 ? 0 : Bof(i));  // main.cpp:255 / 258-262
             out[cnt] = rec;
         }
         ++cnt;
         if (stop_row0) break;
-        j = tmpl_of(Vc[i]);  // between-monomers hop, main.cpp:228-236
+        j = tmpl_of(Vof(i));  // between-monomers hop, main.cpp:228-236
         e = i - 1;
     }
     if (lane == 0) rec_cnt[c] = cnt;
