@@ -86,6 +86,37 @@ struct ReadCursor {
     }
 };
 
+// Sequential reader: one scalar load per 16 rows, issued 16 rows ahead of its first use.
+struct ReadStream {
+    const uint32_t* w;
+    const uint32_t* nm;
+    int last;            // n - 1
+    uint32_t cur, nxt;   // words holding rows [16k, 16k+16) and the following 16
+    uint32_t ncur;
+    __device__ __forceinline__ void init(const uint32_t* w_, const uint32_t* nm_, int n) {
+        w = w_; nm = nm_; last = n - 1;
+        cur = w[0];
+        nxt = w[last >= 16 ? 1 : 0];
+        ncur = nm ? nm[0] : 0u;
+    }
+    // code of row i; rows must be requested in non-decreasing order (clamped to the last row)
+    __device__ __forceinline__ int code(int i) {
+        i = i < last ? i : last;
+        int r = (cur >> (2 * (i & 15))) & 3;
+        if (nm && ((ncur >> (i & 31)) & 1)) r = 4;
+        return r;
+    }
+    // call after consuming row i
+    __device__ __forceinline__ void advance(int i) {
+        if ((i & 15) == 15 && i < last) {
+            cur = nxt;
+            const int k = (i >> 4) + 2;
+            nxt = w[(k << 4) <= last ? k : (last >> 4)];
+            if (nm && (i & 31) == 31) ncur = nm[(i >> 5) + 1];
+        }
+    }
+};
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -115,11 +146,13 @@ __global__ __launch_bounds__(512, 4) void sd_fast_fill(
     if (c >= n_chunks) return;
     const ChunkDesc cd = chunks[c];
     const int n = cd.n;
-    ReadCursor rc{bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr};
+    ReadStream rs;
+    rs.init(bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr, n);
 
     const uint32_t* lc = lane_consts + lane * FAST_LANE_WORDS;
     const uint32_t startMask = lc[FLC_STARTMASK];
     const uint32_t contMask = lc[FLC_CONTMASK];
+    const uint32_t cont2Mask = lc[FLC_CONT2];
     const uint32_t endOff = lc[FLC_ENDOFF];
     const uint32_t row0adj = lc[FLC_ROW0];
     const uint32_t ins2 = pack2(sc.ins);
@@ -134,8 +167,12 @@ __global__ __launch_bounds__(512, 4) void sd_fast_fill(
     int base = 0, Brel = 0, tp = 0;
     int accBV = 0;  // (B << 7 | arg-max virtual lane) of the last <=64 rows, one row per lane
 
-    auto load_table = [&](int r) {
-        const uint32_t* t = lds + r * (P4 * 64) + lane * 4;
+    // `after` pins the LDS reads behind the value it names (the last slot of the row being
+    // finished): hoisted above the slot loop they would need a second register set + 35 copies
+    auto load_table = [&](int r, uint32_t& after) {
+        uint32_t off = (uint32_t)(r * (P4 * 64) + lane * 4);
+        asm volatile("" : "+v"(off), "+v"(after));
+        const uint32_t* t = lds + off;
 #pragma unroll
         for (int c4 = 0; c4 < P4 / 4; ++c4) {
             const uint4 q = *reinterpret_cast<const uint4*>(t + c4 * 256);
@@ -146,7 +183,12 @@ __global__ __launch_bounds__(512, 4) void sd_fast_fill(
     // H = Vmax-1 carry hops of one lane each (DPP wave_shr:1)
     auto excl_scan = [&](uint32_t a) {
         uint32_t inc = a;
-        for (int h = 1; h < H; ++h) inc = pk_max(a, bfi(contMask, lane_up(inc, 1), NEG2));
+        if (H == 3 || H == 4) {  // doubling: window of 4 previous lanes (masks keep it inside the template)
+            inc = pk_max(inc, bfi(contMask, lane_up(inc, 1), NEG2));
+            inc = pk_max(inc, bfi(cont2Mask, lane_up(lane_up(inc, 1), 1), NEG2));
+        } else {
+            for (int h = 1; h < H; ++h) inc = pk_max(a, bfi(contMask, lane_up(inc, 1), NEG2));
+        }
         return H > 0 ? bfi(contMask, lane_up(inc, 1), NEG2) : NEG2;
     };
     // B_{row} (relative to base) = max over template ends; arg = smallest virtual lane attaining it
@@ -167,11 +209,14 @@ __global__ __launch_bounds__(512, 4) void sd_fast_fill(
     };
 
     // ---- row 0 (main.cpp:171-182): E[0][k] = max(E[0][k-1], mm_k - del), E[0][0] = mm_0
-    load_table(rc.code(0));
+    uint32_t pin = 0;
+    load_table(rs.code(0), pin);
+    rs.advance(0);
     L[0] = pk_adds(tb[0], row0adj);
 #pragma unroll
     for (int q = 1; q < P; ++q) L[q] = pk_max(L[q - 1], pk_adds(tb[q], ins2));
-    load_table(rc.code(n > 1 ? 1 : 0));
+    load_table(rs.code(1), L[P - 1]);
+    rs.advance(1);
     K = excl_scan(L[P - 1]);
     uint32_t Eend = pk_max(L[P - 1], K);
     reduce_ends(Eend, 1);
@@ -221,7 +266,8 @@ __global__ __launch_bounds__(512, 4) void sd_fast_fill(
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        load_table(rc.code(i + 1 < n ? i + 1 : i));  // unconditional: keeps tb[] out of phi copies
+        load_table(rs.code(i + 1), L[P - 1]);  // unconditional (clamped): keeps tb[] out of phi copies
+        rs.advance(i + 1);
         const uint32_t a = pk_max(L[P - 1], K);
         const uint32_t X = excl_scan(a);
         K = pk_max(K, X);
@@ -494,6 +540,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         put(lc[FLC_ENDOFF], plane, last ? ((int)tseq[(size_t)j].size() - 1) * sc.del : NEG16);
         put(lc[FLC_ROW0], plane, (j >= 0 && uidx[(size_t)v] == 0) ? sc.ins + sc.del : sc.ins);
         put(lc[FLC_TMPL], plane, j >= 0 ? j : 0xffff);
+        put(lc[FLC_CONT2], plane, (j >= 0 && uidx[(size_t)v] >= 2) ? 0xffff : 0);
     }
     // LDS table image [5][P4/4][64][4]: (mm - del - ins) per template cell, NEG on padding / idle
     const int P4 = plan.P4;
