@@ -76,6 +76,22 @@ __device__ __forceinline__ int wave_max(int v) {
 #endif
 }
 
+// value of lane l-1; lane 0 gets -inf
+__device__ __forceinline__ int lane_up_neg(int x) {
+    return __builtin_amdgcn_update_dpp(NEG_INF32, x, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+
+// inclusive prefix maximum over the 64 lanes (DPP row shifts + row broadcasts)
+__device__ __forceinline__ int wave_prefix_max(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return v;
+}
+
 struct ReadCursor {
     const uint32_t* w;   // 2-bit words of the chunk
     const uint32_t* nm;  // N mask words or nullptr
@@ -343,21 +359,13 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
                     run = kk == 0 ? cand : max(run, cand);
                     loc[q] = run;
                 }
-                int32_t v = run;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int32_t v2 = __shfl_up(v, off);
-                    if (lane >= off) v = max(v, v2);
-                }
-                int32_t X = __shfl_up(v, 1);
-                if (lane == 0) X = NEG_INF32;
+                const int32_t X = lane_up_neg(wave_prefix_max(run));
                 int32_t left = X;
                 uint32_t bits = 0;
 #pragma unroll
                 for (int q = 0; q < QK; ++q) {
-                    const int kk = lane * QK + q;
                     const int32_t Ef = max(loc[q], X);
-                    const int pc = (kk != 0 && Ef == left) ? 0 : 3;
+                    const int pc = Ef == left ? 0 : 3;  // k == 0: left = -inf
                     bits |= (uint32_t)pc << (2 * q);
                     left = Ef;
                     E[q] = Ef;
@@ -376,48 +384,40 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
                 }
                 rstart = a;
             }
+            // per-row scalars of the block, one row per lane (read once, then v_readlane per row)
+            const int rl = a + lane;
+            const bool rvalid = rl >= 1 && rl <= i;
+            const int vBd = rvalid ? Bof(rl) + del : 0;
+            const int vR = rvalid ? rc.code(rl) : 0;
             for (int r_i = rstart; r_i <= i; ++r_i) {
-                const int r = rc.code(r_i);
-                const int32_t Bi = Bof(r_i);
-                const int32_t Bd = Bi + del;
-                int32_t pdEdge = __shfl_up(E[QK - 1], 1);
-                if (lane == 0) pdEdge = NEG_INF32;
-                int32_t loc[QK];
+                const int r = __builtin_amdgcn_readlane(vR, r_i - a);
+                const int32_t Bd = __builtin_amdgcn_readlane(vBd, r_i - a);
+                const int32_t pdEdge = lane_up_neg(E[QK - 1]);
+                int32_t loc[QK], w[QK], dg[QK];
                 int32_t run = NEG_INF32, pd = pdEdge;
 #pragma unroll
                 for (int q = 0; q < QK; ++q) {
-                    const int kk = lane * QK + q;
                     const int32_t mmd = code[q] == r ? mD : xD;
-                    const int32_t cand = kk == 0 ? Bd + mmd : max(max(pd, Bd) + mmd, E[q] + ins);
-                    run = kk == 0 ? cand : max(run, cand);
+                    const int32_t v = max(pd, Bd) + mmd;     // start / diag (lane 0: pd = -inf)
+                    dg[q] = pd + mmd;
+                    w[q] = E[q] + ins;
+                    int32_t cand = max(v, w[q]);
+                    if (q == 0) cand = lane == 0 ? v : cand;  // k == 0: start term only
+                    run = q == 0 ? cand : max(run, cand);
                     loc[q] = run;
                     pd = E[q];
                 }
-                int32_t v = run;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int32_t v2 = __shfl_up(v, off);
-                    if (lane >= off) v = max(v, v2);
-                }
-                int32_t X = __shfl_up(v, 1);
-                if (lane == 0) X = NEG_INF32;
+                const int32_t X = lane_up_neg(wave_prefix_max(run));
                 int32_t left = X;
-                pd = pdEdge;
                 uint32_t bits = 0;
 #pragma unroll
                 for (int q = 0; q < QK; ++q) {
-                    const int kk = lane * QK + q;
                     const int32_t Ef = max(loc[q], X);
-                    const int32_t old = E[q];
-                    const int32_t mmd = code[q] == r ? mD : xD;
-                    int pc;
-                    if (kk != 0 && Ef == left) pc = 0;                 // DEL   main.cpp:242
-                    else if (Ef == old + ins) pc = 1;                  // INS   main.cpp:245
-                    else if (kk != 0 && Ef == pd + mmd) pc = 2;        // DIAG  main.cpp:249
-                    else pc = 3;                                       // START main.cpp:253
+                    int pc = Ef == dg[q] ? 2 : 3;   // DIAG  main.cpp:249 / START main.cpp:253
+                    pc = Ef == w[q] ? 1 : pc;       // INS   main.cpp:245 (tested at k == 0 too)
+                    pc = Ef == left ? 0 : pc;       // DEL   main.cpp:242 (k == 0: left = -inf)
                     bits |= (uint32_t)pc << (2 * q);
                     left = Ef;
-                    pd = old;
                     E[q] = Ef;
                 }
                 pt[r_i - a][lane] = (uint8_t)bits;
