@@ -118,6 +118,48 @@ def test_families_agree_at_bench_scale():
             assert 0 <= t < 24 and s <= en and sc <= en - s + 1 + 174
 
 
+def _digest(chunks):
+    h = hashlib.sha256()
+    for ch in chunks:
+        h.update(repr(ch).encode())
+    return h.hexdigest()
+
+
+def test_full_c2_size_families_agree():
+    """BASELINE config 2 at full size (1000 reads x 50 kb = 10 000 chunks, 54.5 M rows): the two
+    independent device implementations agree on every record, and the records satisfy the
+    structural invariants of a decomposition (tiling of each chunk, template range, score bound)."""
+    mn, ms = synth.make_monomers(12, seed=1)
+    rn, rs = synth.make_reads(ms, 1000, read_len=50000, seed=1)
+    dig = {}
+    for name, k in FAMILIES:
+        e = lib.Engine(ms, kernel=k)
+        assert e.load_reads(rs) == 10000
+        e.run()
+        got = e.fetch()
+        e.close()
+        dig[name] = _digest(got)
+        if name == "fast":
+            assert sum(len(c) for c in got) > 300000
+            for ci, chunk in enumerate(got):
+                n = 5500 if ci % 10 != 9 else 5000
+                assert chunk[0][1] == 0 and chunk[-1][2] == n - 1
+                assert all(b[1] == a[2] + 1 for a, b in zip(chunk, chunk[1:]))
+        del got
+    assert dig["fast"] == dig["generic"]
+
+
+def test_single_long_sequence_custom_scoring_vs_oracle(oracle):
+    """BASELINE config 5 in miniature: one long sequence (1.2 Mb -> 240 chunks), custom -s scoring
+    (honoured, as by the reference binary in its 9-argument form), against the oracle."""
+    mn, ms = synth.make_monomers(12, seed=5)
+    rn, rs = synth.make_reads(ms, 1, read_len=1200000, seed=5)
+    sc = (-2, -3, -4, 2)
+    got = lib.decompose(rn, rs, mn, ms, scoring=sc)
+    exp = oracle.decompose(rn, rs, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc)
+    assert got == exp
+
+
 def test_cli_end_to_end_reference_golden(tmp_path):
     """The reference's own integration test (reference Makefile:16-19): CLI with --second-best on
     test_data, grep the log line, diff final_decomposition.tsv against the golden file."""
