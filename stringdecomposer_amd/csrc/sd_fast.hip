@@ -25,115 +25,10 @@
 #include <climits>
 
 #include "sd_fast.hpp"
-
-#ifndef SD_USE_DPP
-#define SD_USE_DPP 1
-#endif
+#include "sd_fast_dev.hpp"
 
 namespace sd {
 
-namespace {
-
-constexpr uint32_t NEG2 = 0x80008000u;  // packed {-32768, -32768}
-constexpr int NEG16 = -32768;
-
-typedef short s2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
-}
-__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
-}
-__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
-}
-__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
-__device__ __forceinline__ uint32_t pack2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
-
-// value of lane (l - d), own value for l < d (callers mask those lanes)
-__device__ __forceinline__ uint32_t lane_up(uint32_t x, int d) {
-#if SD_USE_DPP
-    if (d == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-#endif
-    return (uint32_t)__shfl_up((int)x, d);
-}
-
-// max over the wave, valid in every lane (shuffle form) / in lane 63 (DPP form) -> broadcast
-__device__ __forceinline__ int wave_max(int v) {
-#if SD_USE_DPP
-    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x111, 0xf, 0xf, false));  // row_shr:1
-    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x112, 0xf, 0xf, false));  // row_shr:2
-    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x114, 0xf, 0xf, false));  // row_shr:4
-    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x118, 0xf, 0xf, false));  // row_shr:8
-    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
-    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
-    return __builtin_amdgcn_readlane(v, 63);
-#else
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return __builtin_amdgcn_readfirstlane(v);
-#endif
-}
-
-// value of lane l-1; lane 0 gets -inf
-__device__ __forceinline__ int lane_up_neg(int x) {
-    return __builtin_amdgcn_update_dpp(NEG_INF32, x, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
-}
-
-// inclusive prefix maximum over the 64 lanes (DPP row shifts + row broadcasts)
-__device__ __forceinline__ int wave_prefix_max(int v) {
-    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x111, 0xf, 0xf, false));  // row_shr:1
-    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x112, 0xf, 0xf, false));  // row_shr:2
-    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x114, 0xf, 0xf, false));  // row_shr:4
-    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x118, 0xf, 0xf, false));  // row_shr:8
-    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
-    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
-    return v;
-}
-
-struct ReadCursor {
-    const uint32_t* w;   // 2-bit words of the chunk
-    const uint32_t* nm;  // N mask words or nullptr
-    __device__ __forceinline__ int code(int i) const {
-        int r = (w[i >> 4] >> (2 * (i & 15))) & 3;
-        if (nm && ((nm[i >> 5] >> (i & 31)) & 1)) r = 4;
-        return r;
-    }
-};
-
-// Sequential reader: one scalar load per 16 rows, issued 16 rows ahead of its first use.
-struct ReadStream {
-    const uint32_t* w;
-    const uint32_t* nm;
-    int last;            // n - 1
-    uint32_t cur, nxt;   // words holding rows [16k, 16k+16) and the following 16
-    uint32_t ncur;
-    __device__ __forceinline__ void init(const uint32_t* w_, const uint32_t* nm_, int n) {
-        w = w_; nm = nm_; last = n - 1;
-        cur = w[0];
-        nxt = w[last >= 16 ? 1 : 0];
-        ncur = nm ? nm[0] : 0u;
-    }
-    // code of row i; rows must be requested in non-decreasing order (clamped to the last row)
-    __device__ __forceinline__ int code(int i) {
-        i = i < last ? i : last;
-        int r = (cur >> (2 * (i & 15))) & 3;
-        if (nm && ((ncur >> (i & 31)) & 1)) r = 4;
-        return r;
-    }
-    // call after consuming row i
-    __device__ __forceinline__ void advance(int i) {
-        if ((i & 15) == 15 && i < last) {
-            cur = nxt;
-            const int k = (i >> 4) + 2;
-            nxt = w[(k << 4) <= last ? k : (last >> 4)];
-            if (nm && (i & 31) == 31) ncur = nm[(i >> 5) + 1];
-        }
-    }
-};
-
-}  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // fill
@@ -492,8 +387,18 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         for (int j = s; j < T; ++j) used2 += ((int)tseq[j].size() + p - 1) / p;
         if (used2 <= 64) { P = p; split = s; break; }
     }
-    if (P == 0) { why = "template set does not fit 128 virtual lanes x 64 slots"; return false; }
+    bool wide = false;
+    if (P == 0) {
+        // wide layout: one template per virtual lane
+        if (T > 128) { why = "more than 128 templates"; return false; }
+        for (int p : FAST_WIDE_P_LIST)
+            if (p >= Lmax) { P = p; break; }
+        if (P == 0) { why = "template longer than the widest layout"; return false; }
+        split = std::min(T, 64);
+        wide = true;
+    }
 
+    plan.wide = wide;
     plan.P = P;
     plan.P4 = (P + 3) & ~3;
     plan.T = T;
@@ -542,6 +447,37 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         put(lc[FLC_TMPL], plane, j >= 0 ? j : 0xffff);
         put(lc[FLC_CONT2], plane, (j >= 0 && uidx[(size_t)v] >= 2) ? 0xffff : 0);
     }
+    if (wide) {
+        // int8 table [5][G][2 halves][64 lanes][4 dwords]; dword d of half h of group g holds slots
+        // 16g+8h+2d, +1 as bytes {lo plane, hi plane, lo plane, hi plane}; -128 = transparent padding
+        const int G = P / 16;
+        const int xd = sc.mismatch - sc.del - sc.ins, md = sc.match - sc.del - sc.ins;
+        if (xd < -127 || xd > 127 || md < -127 || md > 127) { why = "scores too large for the int8 table"; return false; }
+        plan.table.assign((size_t)5 * G * 512, 0x80808080u);
+        auto putb = [&](int grp, int v, int slot16, int val) {
+            const int plane = v >> 6, lane = v & 63, h = slot16 >> 3, d = (slot16 & 7) >> 1, odd = slot16 & 1;
+            uint32_t& w = plan.table[(((size_t)grp * 2 + h) * 64 + lane) * 4 + d];
+            const int sh = 16 * odd + 8 * plane;
+            w = (w & ~(0xffu << sh)) | (((uint32_t)val & 0xffu) << sh);
+        };
+        int64_t sumLw = 0;
+        for (const std::string& s : tseq) sumLw += (int64_t)s.size();
+        plan.slot_of.assign((size_t)sumLw, 0);
+        plan.tcodes.assign((size_t)sumLw, 0);
+        int64_t xw = 0;
+        for (int j = 0; j < T; ++j) {
+            const std::string& s = tseq[(size_t)j];
+            const int v = plan.vlane0[(size_t)j];
+            for (int k = 0; k < (int)s.size(); ++k, ++xw) {
+                const int cd = code_of(s[(size_t)k]);
+                plan.tcodes[(size_t)xw] = (uint8_t)cd;
+                plan.slot_of[(size_t)xw] = (uint16_t)((k << 7) | v);
+                for (int b = 0; b < 5; ++b) putb(b * G + k / 16, v, k & 15, cd == b ? md : xd);
+            }
+        }
+        plan.ok = true;
+        return true;
+    }
     // LDS table image [5][P4/4][64][4]: (mm - del - ins) per template cell, NEG on padding / idle
     const int P4 = plan.P4;
     plan.table.assign((size_t)5 * P4 * 64, NEG2);
@@ -588,6 +524,11 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
                       uint32_t* ckpt, int32_t* ckbase) {
     const int NW = 8;
     const int grid = (n_chunks + NW - 1) / NW;
+    if (plan.wide) {
+        launch_fast_fill_wide(plan, st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt,
+                              ckbase);
+        return;
+    }
     const size_t lds = (size_t)5 * plan.P4 * 64 * sizeof(uint32_t);
 #define SD_FILL(PP)                                                                                \
     case PP:                                                                                       \

@@ -34,6 +34,7 @@ enum FastLaneConst {
 
 struct FastPlan {
     bool ok = false;
+    bool wide = false;    // one template per virtual lane, int8 table streamed from LDS (P > 64)
     int P = 0;            // slots per virtual lane
     int P4 = 0;           // P rounded up to a multiple of 4 (LDS table row)
     int H = 0;            // carry hops of the cross-lane chain: Vmax-1
@@ -42,15 +43,17 @@ struct FastPlan {
     int Lmax = 0;
     int Qk = 0;           // traceback: template cells per lane = ceil(Lmax/64)
     std::vector<int32_t> vlane0;         // first virtual lane of template j
-    std::vector<uint32_t> table;         // [5][P4/4][64][4] packed (mm - del - ins), NEG on padding
+    std::vector<uint32_t> table;         // narrow: [5][P4/4][64][4] packed int16 (mm - del - ins), NEG on padding
+                                         // wide:   [5][P/16][2][64][4] dwords of int8 {lo,hi} pairs, -128 on padding
     std::vector<uint32_t> lane_consts;   // [64][FAST_LANE_WORDS]
     std::vector<uint16_t> slot_of;       // per template cell x=toff[j]+k: (slot << 7) | vlane
     std::vector<uint8_t> tcodes;         // per template cell: base code
 };
 
-// slots-per-virtual-lane values the fill kernel is instantiated for
+// slots-per-virtual-lane values the fill kernels are instantiated for
 static const int FAST_P_LIST[] = {4, 8, 12, 16, 20, 24, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39,
                                   40, 42, 44, 46, 48, 52, 56, 60, 64};
+static const int FAST_WIDE_P_LIST[] = {80, 96, 112, 128, 144, 160, 176, 192, 208, 224};
 
 // Builds the plan; returns false (with the reason) when the fast family cannot represent the
 // input exactly (then the generic family is used).
@@ -64,6 +67,12 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
                       const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                       const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV,
                       uint32_t* ckpt, int32_t* ckbase);
+
+// wide variant (sd_fast_wide.hip), called by launch_fast_fill when plan.wide
+void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
+                           const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                           const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt,
+                           int32_t* ckbase);
 
 void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                        const uint32_t* bases2, const uint32_t* nmask, const uint16_t* slot_of,

@@ -1,0 +1,120 @@
+// sd_fast_dev.hpp -- device helpers shared by the fast-family kernels (sd_fast.hip, sd_fast_wide.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdint>
+
+#include "sd_device.hpp"
+
+#ifndef SD_USE_DPP
+#define SD_USE_DPP 1
+#endif
+
+namespace sd {
+
+namespace {
+
+constexpr uint32_t NEG2 = 0x80008000u;  // packed {-32768, -32768}
+constexpr int NEG16 = -32768;
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
+}
+__device__ __forceinline__ uint32_t pk_adds(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
+}
+__device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+__device__ __forceinline__ uint32_t pack2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
+
+// value of lane (l - d), own value for l < d (callers mask those lanes)
+__device__ __forceinline__ uint32_t lane_up(uint32_t x, int d) {
+#if SD_USE_DPP
+    if (d == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+#endif
+    return (uint32_t)__shfl_up((int)x, d);
+}
+
+// max over the wave, valid in every lane (shuffle form) / in lane 63 (DPP form) -> broadcast
+__device__ __forceinline__ int wave_max(int v) {
+#if SD_USE_DPP
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+#else
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
+// value of lane l-1; lane 0 gets -inf
+__device__ __forceinline__ int lane_up_neg(int x) {
+    return __builtin_amdgcn_update_dpp(NEG_INF32, x, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+
+// inclusive prefix maximum over the 64 lanes (DPP row shifts + row broadcasts)
+__device__ __forceinline__ int wave_prefix_max(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return v;
+}
+
+struct ReadCursor {
+    const uint32_t* w;   // 2-bit words of the chunk
+    const uint32_t* nm;  // N mask words or nullptr
+    __device__ __forceinline__ int code(int i) const {
+        int r = (w[i >> 4] >> (2 * (i & 15))) & 3;
+        if (nm && ((nm[i >> 5] >> (i & 31)) & 1)) r = 4;
+        return r;
+    }
+};
+
+// Sequential reader: one scalar load per 16 rows, issued 16 rows ahead of its first use.
+struct ReadStream {
+    const uint32_t* w;
+    const uint32_t* nm;
+    int last;            // n - 1
+    uint32_t cur, nxt;   // words holding rows [16k, 16k+16) and the following 16
+    uint32_t ncur;
+    __device__ __forceinline__ void init(const uint32_t* w_, const uint32_t* nm_, int n) {
+        w = w_; nm = nm_; last = n - 1;
+        cur = w[0];
+        nxt = w[last >= 16 ? 1 : 0];
+        ncur = nm ? nm[0] : 0u;
+    }
+    // code of row i; rows must be requested in non-decreasing order (clamped to the last row)
+    __device__ __forceinline__ int code(int i) {
+        i = i < last ? i : last;
+        int r = (cur >> (2 * (i & 15))) & 3;
+        if (nm && ((ncur >> (i & 31)) & 1)) r = 4;
+        return r;
+    }
+    // call after consuming row i
+    __device__ __forceinline__ void advance(int i) {
+        if ((i & 15) == 15 && i < last) {
+            cur = nxt;
+            const int k = (i >> 4) + 2;
+            nxt = w[(k << 4) <= last ? k : (last >> 4)];
+            if (nm && (i & 31) == 31) ncur = nm[(i >> 5) + 1];
+        }
+    }
+};
+
+}  // namespace
+
+}  // namespace sd

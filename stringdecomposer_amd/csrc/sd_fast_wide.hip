@@ -1,0 +1,197 @@
+// sd_fast_wide.hip -- wide variant of the fast fill for large template sets (up to 128 templates,
+// e.g. the 64-monomer suprachromosomal-family configuration): ONE template per virtual lane
+// (P >= Lmax slots, no cross-lane chain, no lazy carry).
+//
+// The (mm - del - ins) table is int8 ({lo plane, hi plane} byte pairs) so that 128 x 176 cells x
+// 5 read symbols fit the 160 KB LDS; it is streamed 16 slots at a time into a double-buffered
+// 16-register window.  5 VALU ops per cell pair (the add is two SDWA byte adds).  Tail slots behind
+// a template's last cell hold the table byte -128: in the row-shifted domain
+// S_new[last] >= max(S_old[last], KB) - 127, so such a slot is a transparent copy of the last cell
+// and the template end is always read from slot P-1.
+//
+// Same outputs as sd_fast_fill (packed B/arg-max words, checkpoints) -> same traceback kernel.
+// Replaces reference stringdecomposer/src/main.cpp:171-216 like sd_fast_fill does.
+#include <hip/hip_runtime.h>
+
+#include "sd_fast.hpp"
+#include "sd_fast_dev.hpp"
+
+namespace sd {
+
+namespace {
+
+__device__ __forceinline__ uint32_t add_b8(uint32_t u, uint32_t tb, int pair) {
+    uint32_t v;
+    if (pair == 0) {
+        asm("v_add_u16_sdwa %0, %1, sext(%2) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_0" : "=v"(v) : "v"(u), "v"(tb));
+        asm("v_add_u16_sdwa %0, %1, sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_1" : "+v"(v) : "v"(u), "v"(tb));
+    } else {
+        asm("v_add_u16_sdwa %0, %1, sext(%2) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_2" : "=v"(v) : "v"(u), "v"(tb));
+        asm("v_add_u16_sdwa %0, %1, sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_3" : "+v"(v) : "v"(u), "v"(tb));
+    }
+    return v;
+}
+
+}  // namespace
+
+template <int P>
+__global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
+    const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
+    const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
+    const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int32_t* __restrict__ Bout,
+    uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase) {
+    static_assert(P % 16 == 0, "wide variant streams the table 16 slots at a time");
+    constexpr int G = P / 16;
+    extern __shared__ uint32_t lds[];  // [5][G][2 halves][64][4]
+    constexpr int TBL = 5 * G * 512;
+    for (int idx = threadIdx.x * 4; idx < TBL; idx += blockDim.x * 4)
+        *reinterpret_cast<uint4*>(&lds[idx]) = *reinterpret_cast<const uint4*>(&table[idx]);
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = (int)(blockDim.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * nw + wave;
+    if (c >= n_chunks) return;
+    const ChunkDesc cd = chunks[c];
+    const int n = cd.n;
+    ReadStream rs;
+    rs.init(bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr, n);
+
+    const uint32_t* lc = lane_consts + lane * FAST_LANE_WORDS;
+    const uint32_t endOff = lc[FLC_ENDOFF];
+    const uint32_t row0adj = lc[FLC_ROW0];
+    const uint32_t ins2 = pack2(sc.ins);
+
+    int32_t* Bc = Bout + cd.row0 + (uint64_t)c;
+    uint32_t* ck = ckpt + (uint64_t)cd.pad * (uint64_t)(P * 64) + lane;
+    int32_t* ckb = ckbase + cd.pad;
+
+    uint32_t L[P];
+    uint32_t tbg[2][8];  // 16 slots per buffer: dword d holds slots 2d, 2d+1 as {lo,hi,lo,hi} bytes
+    int base = 0, Brel = 0, tp = 0;
+    int accBV = 0;
+
+    auto load_group = [&](int r, int g, int buf, uint32_t& after) {
+        uint32_t off = (uint32_t)((r * G + g) * 512 + lane * 4);
+        asm volatile("" : "+v"(off), "+v"(after));
+        const uint4 q0 = *reinterpret_cast<const uint4*>(lds + off);
+        const uint4 q1 = *reinterpret_cast<const uint4*>(lds + off + 256);
+        tbg[buf][0] = q0.x; tbg[buf][1] = q0.y; tbg[buf][2] = q0.z; tbg[buf][3] = q0.w;
+        tbg[buf][4] = q1.x; tbg[buf][5] = q1.y; tbg[buf][6] = q1.z; tbg[buf][7] = q1.w;
+    };
+    auto reduce_ends = [&](uint32_t Eend, int row) {
+        const uint32_t val = pk_adds(Eend, endOff);
+        const int lo = (int)(short)(val & 0xffffu);
+        const int hi = (int)val >> 16;
+        const int b = wave_max(max(lo, hi));
+        const unsigned long long mlo = __ballot(lo == b);
+        const unsigned long long mhi = __ballot(hi == b);
+        const int v = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
+        Brel = b + tp * sc.ins;
+        const int slot = (row - 1) & 63;
+        accBV = lane == slot ? (int)(((uint32_t)(base + Brel) << 7) | (uint32_t)v) : accBV;
+        if (slot == 63 || row == n) {
+            if (lane <= slot) Bc[row - slot + lane] = accBV;
+        }
+    };
+
+    // ---- row 0 (main.cpp:171-182)
+    {
+        const int r0 = rs.code(0);
+        rs.advance(0);
+        uint32_t pin = 0;
+        uint32_t run = 0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            load_group(r0, g, 0, pin);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int q = 16 * g + s;
+                const uint32_t t16 = add_b8(q == 0 ? row0adj : ins2, tbg[0][s >> 1], s & 1);
+                run = q == 0 ? t16 : pk_max(run, t16);
+                L[q] = run;
+            }
+            pin = run;
+        }
+        reduce_ends(L[P - 1], 1);
+    }
+    int rnext = rs.code(1);  // read symbol of the next row; its group 0 is prefetched into tbg[0]
+    rs.advance(1);
+    load_group(rnext, 0, 0, L[P - 1]);
+    for (int i = 1; i < n; ++i) {
+        const int rcur = rnext;
+        if ((i & (FAST_R - 1)) == 0) {
+            const uint32_t d2 = pack2(Brel - tp * sc.ins);
+            base += Brel;
+            Brel = 0;
+            tp = 0;
+            const int q = (i / FAST_R) - 1;
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                L[s] = pk_subs(L[s], d2);
+                ck[(uint64_t)q * (P * 64) + s * 64] = L[s];
+            }
+            if (lane == 0) ckb[q] = base;
+        }
+        uint32_t KB = pack2(Brel + sc.del - tp * sc.ins);  // kept in a VGPR: see the per-step pin below
+        uint32_t u_[P], v_[P], c_[P];
+        uint32_t run = 0;
+#pragma unroll
+        for (int s = 0; s < P + 3; ++s) {
+            if (s >= 3) {
+                const int q = s - 3;
+                run = q == 0 ? c_[0] : pk_max(run, c_[q]);
+                L[q] = run;
+            }
+            if (s >= 2 && s - 2 < P) {
+                const int q = s - 2;
+                c_[q] = q == 0 ? v_[0] : pk_max(v_[q], L[q]);  // k == 0: start term only
+            }
+            if (s >= 1 && s - 1 < P) {
+                const int q = s - 1;
+                v_[q] = add_b8(u_[q], tbg[(q >> 4) & 1][(q & 15) >> 1], q & 1);
+            }
+            if (s < P) {
+                const int q = s;
+                // every virtual lane starts a template: slot 0 has no diagonal / chain input
+                u_[q] = q == 0 ? KB : pk_max(L[q - 1], KB);
+                // stream the next 16 slots of the table one group ahead of their first use
+                if ((q & 15) == 2 && (q >> 4) + 1 < G) load_group(rcur, (q >> 4) + 1, ((q >> 4) + 1) & 1, u_[q]);
+            }
+            // pin the skew: the next step's inputs (KB) become available only after this step's
+            // chain update, so the compiler cannot batch all u/v first (that needs 2P registers)
+            asm volatile("" : "+v"(KB), "+v"(run));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        rnext = rs.code(i + 1);
+        rs.advance(i + 1);
+        load_group(rnext, 0, 0, L[P - 1]);
+        ++tp;
+        reduce_ends(L[P - 1], i + 1);
+    }
+}
+
+void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
+                           const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                           const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt,
+                           int32_t* ckbase) {
+    const int NW = 8;
+    const int grid = (n_chunks + NW - 1) / NW;
+    const size_t lds = (size_t)5 * (plan.P / 16) * 512 * sizeof(uint32_t);
+#define SD_FILLW(PP)                                                                                 \
+    case PP:                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill_wide<PP>),             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+        hipLaunchKernelGGL(sd_fast_fill_wide<PP>, dim3(grid), dim3(NW * 64), lds, st, chunks,        \
+                           n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt, ckbase);        \
+        break;
+    switch (plan.P) {
+        SD_FILLW(80) SD_FILLW(96) SD_FILLW(112) SD_FILLW(128) SD_FILLW(144) SD_FILLW(160)
+        SD_FILLW(176) SD_FILLW(192) SD_FILLW(208) SD_FILLW(224)
+        default: break;
+    }
+#undef SD_FILLW
+}
+
+}  // namespace sd

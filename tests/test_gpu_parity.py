@@ -160,6 +160,35 @@ def test_single_long_sequence_custom_scoring_vs_oracle(oracle):
     assert got == exp
 
 
+def test_64_monomer_set_wide_layout(oracle):
+    """BASELINE config 4 shape: 64 monomers (128 templates, one per virtual lane, int8 table):
+    chunk-level records vs the oracle, N in the reads, and agreement with the generic family on
+    more chunks than the oracle can cover quickly."""
+    mn, ms = synth.make_monomers(64, seed=11)
+    tm = [m.decode() for m in ms] + [synth.revcomp_bytes(m).decode() for m in ms]
+    rn, rs = synth.make_reads(ms, 3, read_len=900, seed=12)
+    rs = [rs[0], rs[1][:333], rs[2][:40] + b"NNN" + rs[2][43:700]]
+    for sc in [(-1, -1, -1, 1), (-2, -3, -4, 2)]:
+        e = lib.Engine(ms, scoring=sc, kernel=lib.KERNEL_FAST)
+        assert e.info()["cells_per_lane"] >= 176
+        e.load_reads(rs)
+        e.run()
+        got = e.fetch()
+        e.close()
+        for s, g in zip(rs, got):
+            exp = oracle.align_chunk(s.decode(), tm, sc)
+            assert g == [(t, a, b, int(v)) for (t, a, b, v) in exp]
+    rn, rs = synth.make_reads(ms, 8, read_len=50000, seed=13)
+    res = {}
+    for name, k in FAMILIES:
+        e = lib.Engine(ms, kernel=k)
+        e.load_reads(rs)
+        e.run()
+        res[name] = e.fetch()
+        e.close()
+    assert res["fast"] == res["generic"]
+
+
 def test_cli_end_to_end_reference_golden(tmp_path):
     """The reference's own integration test (reference Makefile:16-19): CLI with --second-best on
     test_data, grep the log line, diff final_decomposition.tsv against the golden file."""
