@@ -37,8 +37,11 @@ namespace sd {
 // rebase), so that the insertion move costs nothing:
 //   S_new[x] = max( max(S[x-1], B_i + del - tp*ins) + (mm - del - ins),  S[x],  S_new[x-1] )
 // i.e. 4 packed ops per cell pair: u = max(pd, KB); v = u + tbl; cand = max(v, old); run = max(run, cand).
+#ifndef SD_FILL_NW
+#define SD_FILL_NW 8   // waves (= chunks) per workgroup; two workgroups per CU
+#endif
 template <int P>
-__global__ __launch_bounds__(512, 4) void sd_fast_fill(
+__global__ __launch_bounds__(SD_FILL_NW * 64, SD_FILL_NW / 2) void sd_fast_fill(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int H, int32_t* __restrict__ Bout,
@@ -522,7 +525,7 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
                       const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                       const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV,
                       uint32_t* ckpt, int32_t* ckbase) {
-    const int NW = 8;
+    const int NW = SD_FILL_NW;
     const int grid = (n_chunks + NW - 1) / NW;
     if (plan.wide) {
         launch_fast_fill_wide(plan, st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt,

@@ -63,14 +63,16 @@ __device__ __forceinline__ int lane_up_neg(int x) {
     return __builtin_amdgcn_update_dpp(NEG_INF32, x, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
 }
 
-// inclusive prefix maximum over the 64 lanes (DPP row shifts + row broadcasts)
+// inclusive prefix maximum over the 64 lanes (DPP row shifts + row broadcasts).  `old` = INT_MIN (the identity
+// of max) lets the compiler fold every step
+// into one v_max_i32_dpp.
 __device__ __forceinline__ int wave_prefix_max(int v) {
-    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x111, 0xf, 0xf, false));  // row_shr:1
-    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x112, 0xf, 0xf, false));  // row_shr:2
-    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x114, 0xf, 0xf, false));  // row_shr:4
-    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x118, 0xf, 0xf, false));  // row_shr:8
-    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
-    v = max(v, __builtin_amdgcn_update_dpp(NEG_INF32, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = max(v, __builtin_amdgcn_update_dpp(INT_MIN, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
     return v;
 }
 
