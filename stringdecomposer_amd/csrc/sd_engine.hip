@@ -309,36 +309,20 @@ int sd_engine_load_reads(sd_engine* e, const char* const* read_seqs, const int64
     e->chunk_off.clear();
     e->read_nchunks.assign((size_t)std::max(n_reads, 0), 0);
     e->n_reads = n_reads;
-    // chunk table (main.cpp:70-81) + 2-bit packing
+    // chunk table (main.cpp:70-81), then 2-bit packing of all chunks on the host threads
     std::vector<uint32_t> bases2, nmask;
     uint64_t row0 = 0;
+    size_t words_total = 0;
     for (int32_t r = 0; r < n_reads; ++r) {
-        const char* s = read_seqs[r];
         const int64_t len = read_lens[r];
         int cnt = sd::chunk_plan(len, e->p.part_size, e->p.overlap, [&](int64_t off, int32_t l) {
             sd::ChunkDesc cd{};
-            cd.woff = (uint32_t)bases2.size();
+            cd.woff = (uint32_t)words_total;
             cd.n = l;
             cd.noff = -1;
             cd.row0 = row0;
             row0 += (uint64_t)l;
-            const size_t words = ((size_t)l + 15) / 16;
-            const size_t w0 = bases2.size();
-            bases2.resize(w0 + words, 0u);
-            bool has_n = false;
-            for (int32_t i = 0; i < l; ++i) {
-                const int code = sd::base_code(s[off + i]);
-                if (code == 4) has_n = true;
-                else bases2[w0 + (size_t)(i >> 4)] |= (uint32_t)code << (2 * (i & 15));
-            }
-            if (has_n) {
-                cd.noff = (int32_t)nmask.size();
-                const size_t nw = ((size_t)l + 31) / 32;
-                const size_t n0 = nmask.size();
-                nmask.resize(n0 + nw, 0u);
-                for (int32_t i = 0; i < l; ++i)
-                    if (s[off + i] == 'N') nmask[n0 + (size_t)(i >> 5)] |= 1u << (i & 31);
-            }
+            words_total += ((size_t)l + 15) / 16;
             e->chunks.push_back(cd);
             e->chunk_read.push_back(r);
             e->chunk_off.push_back(off);
@@ -349,13 +333,38 @@ int sd_engine_load_reads(sd_engine* e, const char* const* read_seqs, const int64
         }
         e->read_nchunks[(size_t)r] = cnt;
     }
-    e->rows = (int64_t)row0;
-    const size_t C = e->chunks.size();
-    if (n_chunks) *n_chunks = (int64_t)C;
-    if (bases2.size() >= (1ull << 31)) {
+    if (words_total >= (1ull << 31)) {
         set_err(errbuf, errlen, "batch too large: split the reads into smaller groups");
         return SD_ERR_UNSUPPORTED;
     }
+    bases2.assign(words_total, 0u);
+    {
+        const size_t C0 = e->chunks.size();
+        std::vector<uint8_t> hasn(C0, 0);
+        sd::parallel_for((int64_t)C0, e->p.threads, 16, [&](int64_t c) {
+            const sd::ChunkDesc& cd = e->chunks[(size_t)c];
+            const char* s = read_seqs[e->chunk_read[(size_t)c]] + e->chunk_off[(size_t)c];
+            hasn[(size_t)c] = sd::pack_chunk(s, cd.n, bases2.data() + cd.woff) ? 1 : 0;
+        });
+        size_t nwords = 0;
+        for (size_t c = 0; c < C0; ++c)
+            if (hasn[c]) {
+                e->chunks[c].noff = (int32_t)nwords;
+                nwords += ((size_t)e->chunks[c].n + 31) / 32;
+            }
+        nmask.assign(nwords, 0u);
+        if (nwords)
+            sd::parallel_for((int64_t)C0, e->p.threads, 16, [&](int64_t c) {
+                const sd::ChunkDesc& cd = e->chunks[(size_t)c];
+                if (cd.noff < 0) return;
+                const char* s = read_seqs[e->chunk_read[(size_t)c]] + e->chunk_off[(size_t)c];
+                for (int32_t i = 0; i < cd.n; ++i)
+                    if (s[i] == 'N') nmask[(size_t)cd.noff + (size_t)(i >> 5)] |= 1u << (i & 31);
+            });
+    }
+    e->rows = (int64_t)row0;
+    const size_t C = e->chunks.size();
+    if (n_chunks) *n_chunks = (int64_t)C;
     try {
         SD_HIP(hipSetDevice(e->device));
         const int64_t nck = e->family == 2 ? sd::fast_ckpt_rows_total(e->fplan, e->chunks) : 0;
@@ -597,10 +606,14 @@ static int decompose_impl(const std::vector<sd::Seq>& reads, const std::vector<s
         sd_rec* rows_o = nullptr; int64_t* row_off = nullptr;
         if (rc == SD_OK) rc = sd_engine_assemble(eng, recs, roff, &rows_o, &row_off, eb, sizeof eb);
         if (rc == SD_OK) {
-            for (size_t r = r0; r < r1; ++r) {
-                const int64_t a = row_off[r - r0], b = row_off[r - r0 + 1];
-                sd::format_rows(tsv, reads[r].name.data(), reads[r].name.size(), tnames, rows_o + a, (size_t)(b - a));
-            }
+            std::vector<std::string> parts(r1 - r0);
+            sd::parallel_for((int64_t)(r1 - r0), p->threads, 4, [&](int64_t q) {
+                const size_t r = r0 + (size_t)q;
+                const int64_t a = row_off[q], b = row_off[q + 1];
+                sd::format_rows(parts[(size_t)q], reads[r].name.data(), reads[r].name.size(), tnames,
+                                rows_o + a, (size_t)(b - a));
+            });
+            for (const std::string& part : parts) tsv += part;
         }
         std::free(recs); std::free(roff); std::free(rows_o); std::free(row_off);
         r0 = r1;

@@ -8,7 +8,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -182,6 +184,58 @@ inline void format_rows(std::string& o, const char* read_name, size_t read_name_
         o.push_back('\n');
         prev_end = r.end;
     }
+}
+
+// Minimal fork-join over [0, n): `threads` host threads pull blocks of `grain` indices.
+template <class F>
+inline void parallel_for(int64_t n, int threads, int64_t grain, F&& body) {
+    if (n <= 0) return;
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && threads > hw) threads = hw;
+    if (threads <= 1 || n <= grain) {
+        for (int64_t i = 0; i < n; ++i) body(i);
+        return;
+    }
+    std::atomic<int64_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int64_t b = next.fetch_add(grain);
+            if (b >= n) break;
+            const int64_t e = b + grain < n ? b + grain : n;
+            for (int64_t i = b; i < e; ++i) body(i);
+        }
+    };
+    std::vector<std::thread> th;
+    const int64_t blocks = (n + grain - 1) / grain;
+    const int nt = (int)(blocks < threads ? blocks : threads);
+    for (int k = 1; k < nt; ++k) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+}
+
+// 2-bit packing of one chunk (16 bases per dword); returns true if the chunk contains N
+inline bool pack_chunk(const char* s, int32_t l, uint32_t* out) {
+    bool has_n = false;
+    const int32_t full = l & ~15;
+    for (int32_t i = 0; i < full; i += 16) {
+        uint32_t w = 0;
+        for (int k = 0; k < 16; ++k) {
+            const int code = base_code(s[i + k]);
+            has_n |= code == 4;
+            w |= (uint32_t)(code & 3) << (2 * k);
+        }
+        out[i >> 4] = w;
+    }
+    if (full < l) {
+        uint32_t w = 0;
+        for (int32_t i = full; i < l; ++i) {
+            const int code = base_code(s[i]);
+            has_n |= code == 4;
+            w |= (uint32_t)(code & 3) << (2 * (i & 15));
+        }
+        out[full >> 4] = w;
+    }
+    return has_n;
 }
 
 }  // namespace sd
