@@ -90,6 +90,9 @@ struct sd_engine {
     DevBuf<uint8_t> d_ftcodes;       // base code of template cell (j,k)
     DevBuf<uint32_t> d_fckpt;        // checkpoints
     DevBuf<int32_t> d_fckbase;       // per-checkpoint rebase values
+    DevBuf<int> d_queue;             // work-queue heads of the persistent kernels (fill, trace)
+    DevBuf<int> d_order;             // chunk indices, longest first
+    int n_cu = 256;
 
     // batch
     std::vector<sd::ChunkDesc> chunks;
@@ -256,6 +259,12 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
     try {
         SD_HIP(hipSetDevice(p->device));
         e->device = p->device;
+        {
+            hipDeviceProp_t prop;
+            SD_HIP(hipGetDeviceProperties(&prop, p->device));
+            e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            e->d_queue.alloc(2);
+        }
         // kernel family
         int family = p->kernel;
         std::string why;
@@ -369,6 +378,12 @@ int sd_engine_load_reads(sd_engine* e, const char* const* read_seqs, const int64
         SD_HIP(hipSetDevice(e->device));
         const int64_t nck = e->family == 2 ? sd::fast_ckpt_rows_total(e->fplan, e->chunks) : 0;
         e->d_chunks.upload(e->chunks);
+        {
+            std::vector<int> order(C);
+            for (size_t c = 0; c < C; ++c) order[c] = (int)c;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return e->chunks[(size_t)a].n > e->chunks[(size_t)b].n; });
+            e->d_order.upload(order);
+        }
         e->d_bases2.upload(bases2);
         e->d_nmask.upload(nmask);
         e->d_B.alloc((size_t)e->rows + C);
@@ -443,13 +458,14 @@ int sd_engine_run(sd_engine* e, void* hip_stream, char* errbuf, size_t errlen) {
                 SD_HIP(hipEventRecord(e->ev_fill[0], st));
                 sd::launch_fast_fill(e->fplan, st, e->d_chunks.p, C, e->d_bases2.p, e->d_nmask.p,
                                      e->d_ftable.p, e->d_flane.p, e->sc, e->d_B.p, e->d_argB.p,
-                                     e->d_fckpt.p, e->d_fckbase.p);
+                                     e->d_fckpt.p, e->d_fckbase.p, e->d_queue.p, e->d_order.p, e->n_cu);
                 SD_HIP(hipEventRecord(e->ev_fill[1], st));
                 SD_HIP(hipEventRecord(e->ev_trace[0], st));
                 sd::launch_fast_trace(e->fplan, st, e->d_chunks.p, C, e->d_bases2.p, e->d_nmask.p,
                                       e->d_fslot.p, e->d_ftcodes.p, e->d_flane.p, e->d_toff.p,
                                       e->d_tlen.p, e->sc, e->d_B.p, e->d_argB.p, e->d_fckpt.p,
-                                      e->d_fckbase.p, e->d_recs.p, e->d_cnt.p);
+                                      e->d_fckbase.p, e->d_recs.p, e->d_cnt.p, e->d_queue.p + 1, e->d_order.p,
+                                      e->n_cu);
                 SD_HIP(hipEventRecord(e->ev_trace[1], st));
                 e->fill_launches = 1;
             }

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, SD_FILL_NW / 2) void sd_fast_fill(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int H, int32_t* __restrict__ Bout,
-    int32_t* __restrict__ argV, uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase) {
+    int32_t* __restrict__ argV, uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase,
+    int* __restrict__ queue, const int* __restrict__ order) {
     constexpr int P4 = (P + 3) & ~3;
     extern __shared__ uint32_t lds[];  // [5][P4/4][64][4]
     constexpr int TBL = 5 * P4 * 64;
@@ -56,8 +57,10 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, SD_FILL_NW / 2) void sd_fast_fill(
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nw = (int)(blockDim.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * nw + wave;
-    if (c >= n_chunks) return;
+    (void)wave; (void)nw;
+    ChunkSched sched;
+    sched.init(queue, order, n_chunks);
+    for (int c = sched.next(); c >= 0; c = sched.next()) {
     const ChunkDesc cd = chunks[c];
     const int n = cd.n;
     ReadStream rs;
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, SD_FILL_NW / 2) void sd_fast_fill(
         ++tp;
         reduce_ends(Eend, i + 1);
     }
+    }  // chunk queue
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -202,13 +206,15 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
     const int32_t* __restrict__ toff, const int32_t* __restrict__ tlen, ScoreArgs sc, int P,
     const int32_t* __restrict__ B, const int32_t* __restrict__ argV,
     const uint32_t* __restrict__ ckpt, const int32_t* __restrict__ ckbase,
-    DevRec* __restrict__ recs, int32_t* __restrict__ rec_cnt) {
+    DevRec* __restrict__ recs, int32_t* __restrict__ rec_cnt, int* __restrict__ queue,
+    const int* __restrict__ order) {
     __shared__ uint8_t pt_all[4][FAST_R][64];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + wave;
-    if (c >= n_chunks) return;
     uint8_t(*pt)[64] = pt_all[wave];
+    ChunkSched sched;
+    sched.init(queue, order, n_chunks);
+    for (int c = sched.next(); c >= 0; c = sched.next()) {
     const ChunkDesc cd = chunks[c];
     const int n = cd.n;
     ReadCursor rc{bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr};
@@ -345,6 +351,7 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
         e = i - 1;
     }
     if (lane == 0) rec_cnt[c] = cnt;
+    }  // chunk queue
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -524,12 +531,13 @@ int64_t fast_ckpt_rows_total(const FastPlan& plan, std::vector<ChunkDesc>& chunk
 void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                       const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                       const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV,
-                      uint32_t* ckpt, int32_t* ckbase) {
+                      uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order, int n_cu) {
     const int NW = SD_FILL_NW;
-    const int grid = (n_chunks + NW - 1) / NW;
+    const int grid = std::min((n_chunks + NW - 1) / NW, 2 * n_cu);  // persistent: 2 workgroups per CU
+    (void)hipMemsetAsync(queue, 0, sizeof(int), st);
     if (plan.wide) {
         launch_fast_fill_wide(plan, st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt,
-                              ckbase);
+                              ckbase, queue, order, n_cu);
         return;
     }
     const size_t lds = (size_t)5 * plan.P4 * 64 * sizeof(uint32_t);
@@ -538,7 +546,8 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP>),                \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
         hipLaunchKernelGGL(sd_fast_fill<PP>, dim3(grid), dim3(NW * 64), lds, st, chunks, n_chunks, \
-                           bases2, nmask, table, lane_consts, sc, plan.H, B, argV, ckpt, ckbase);  \
+                           bases2, nmask, table, lane_consts, sc, plan.H, B, argV, ckpt, ckbase,   \
+                           queue, order);                                                         \
         break;
     switch (plan.P) {
         SD_FILL(4) SD_FILL(8) SD_FILL(12) SD_FILL(16) SD_FILL(20) SD_FILL(24) SD_FILL(28) SD_FILL(30)
@@ -555,12 +564,13 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
                        const uint8_t* tcodes, const uint32_t* lane_consts, const int32_t* toff,
                        const int32_t* tlen, ScoreArgs sc, const int32_t* B, const int32_t* argV,
                        const uint32_t* ckpt, const int32_t* ckbase, DevRec* recs,
-                       int32_t* rec_cnt) {
-    const int grid = (n_chunks + 3) / 4;
+                       int32_t* rec_cnt, int* queue, const int* order, int n_cu) {
+    const int grid = std::min((n_chunks + 3) / 4, 8 * n_cu);  // persistent: 8 workgroups of 4 waves per CU
+    (void)hipMemsetAsync(queue, 0, sizeof(int), st);
 #define SD_TRACE(QQ)                                                                              \
     hipLaunchKernelGGL(sd_fast_trace<QQ>, dim3(grid), dim3(256), 0, st, chunks, n_chunks, bases2, \
                        nmask, slot_of, tcodes, lane_consts, toff, tlen, sc, plan.P, B, argV, ckpt, \
-                       ckbase, recs, rec_cnt)
+                       ckbase, recs, rec_cnt, queue, order)
     switch (plan.Qk) {
         case 1: SD_TRACE(1); break;
         case 2: SD_TRACE(2); break;

@@ -66,19 +66,19 @@ int64_t fast_ckpt_rows_total(const FastPlan& plan, std::vector<ChunkDesc>& chunk
 void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                       const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                       const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV,
-                      uint32_t* ckpt, int32_t* ckbase);
+                      uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order, int n_cu);
 
 // wide variant (sd_fast_wide.hip), called by launch_fast_fill when plan.wide
 void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                            const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                            const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt,
-                           int32_t* ckbase);
+                           int32_t* ckbase, int* queue, const int* order, int n_cu);
 
 void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                        const uint32_t* bases2, const uint32_t* nmask, const uint16_t* slot_of,
                        const uint8_t* tcodes, const uint32_t* lane_consts, const int32_t* toff,
                        const int32_t* tlen, ScoreArgs sc, const int32_t* B, const int32_t* argV,
                        const uint32_t* ckpt, const int32_t* ckbase, DevRec* recs,
-                       int32_t* rec_cnt);
+                       int32_t* rec_cnt, int* queue, const int* order, int n_cu);
 
 }  // namespace sd

@@ -76,6 +76,26 @@ __device__ __forceinline__ int wave_prefix_max(int v) {
     return v;
 }
 
+// Persistent waves: every wave pulls the next chunk from an atomic queue when it is done with its
+// own, so the tail of a launch is balanced per SIMD instead of per workgroup (C2 fill 18.3 ->
+// 17.7 ms).  `order` lists the chunks longest first.  (A static strided assignment was measured
+// slower: 19.3 ms -- SIMDs do not run at identical speed.)
+struct ChunkSched {
+    int* queue;
+    const int* order;
+    int n_chunks;
+    __device__ __forceinline__ void init(int* q, const int* o, int n) {
+        queue = q; order = o; n_chunks = n;
+    }
+    // wave-uniform next chunk index, -1 when the queue is empty
+    __device__ __forceinline__ int next() {
+        int q = 0;
+        if ((threadIdx.x & 63) == 0) q = atomicAdd(queue, 1);
+        q = __builtin_amdgcn_readfirstlane(q);
+        return q < n_chunks ? order[q] : -1;
+    }
+};
+
 struct ReadCursor {
     const uint32_t* w;   // 2-bit words of the chunk
     const uint32_t* nm;  // N mask words or nullptr

@@ -13,6 +13,8 @@
 // Replaces reference stringdecomposer/src/main.cpp:171-216 like sd_fast_fill does.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "sd_fast.hpp"
 #include "sd_fast_dev.hpp"
 
@@ -39,7 +41,8 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int32_t* __restrict__ Bout,
-    uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase) {
+    uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase, int* __restrict__ queue,
+    const int* __restrict__ order) {
     static_assert(P % 16 == 0, "wide variant streams the table 16 slots at a time");
     constexpr int G = P / 16;
     extern __shared__ uint32_t lds[];  // [5][G][2 halves][64][4]
@@ -51,8 +54,10 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nw = (int)(blockDim.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * nw + wave;
-    if (c >= n_chunks) return;
+    (void)wave; (void)nw;
+    ChunkSched sched;
+    sched.init(queue, order, n_chunks);
+    for (int c = sched.next(); c >= 0; c = sched.next()) {
     const ChunkDesc cd = chunks[c];
     const int n = cd.n;
     ReadStream rs;
@@ -170,21 +175,23 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
         ++tp;
         reduce_ends(L[P - 1], i + 1);
     }
+    }  // chunk queue
 }
 
 void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                            const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                            const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt,
-                           int32_t* ckbase) {
+                           int32_t* ckbase, int* queue, const int* order, int n_cu) {
     const int NW = 8;
-    const int grid = (n_chunks + NW - 1) / NW;
+    const int grid = std::min((n_chunks + NW - 1) / NW, n_cu);  // persistent: one workgroup per CU (LDS)
     const size_t lds = (size_t)5 * (plan.P / 16) * 512 * sizeof(uint32_t);
 #define SD_FILLW(PP)                                                                                 \
     case PP:                                                                                         \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill_wide<PP>),             \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
         hipLaunchKernelGGL(sd_fast_fill_wide<PP>, dim3(grid), dim3(NW * 64), lds, st, chunks,        \
-                           n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt, ckbase);        \
+                           n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt, ckbase, queue,  \
+                           order);                                                                   \
         break;
     switch (plan.P) {
         SD_FILLW(80) SD_FILLW(96) SD_FILLW(112) SD_FILLW(128) SD_FILLW(144) SD_FILLW(160)
