@@ -119,7 +119,7 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, SD_FILL_NW / 2) void sd_fast_fill(
         const int v = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
         Brel = b + tp * sc.ins;
         const int slot = (row - 1) & 63;
-        accBV = lane == slot ? (int)(((uint32_t)(base + Brel) << 7) | (uint32_t)v) : accBV;
+        acc_put(accBV, (int)(((uint32_t)(base + Brel) << 7) | (uint32_t)v), slot);
         if (slot == 63 || row == n) {
             if (lane <= slot) Bc[row - slot + lane] = accBV;
         }
@@ -140,20 +140,22 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, SD_FILL_NW / 2) void sd_fast_fill(
 
     for (int i = 1; i < n; ++i) {
         if ((i & (FAST_R - 1)) == 0) {
-            // rebase on B_i, fold the row offset tp*ins back in, checkpoint the (true) row i-1
-            const uint32_t d2 = pack2(Brel - tp * sc.ins);
-            base += Brel;
-            Brel = 0;
-            tp = 0;
-            K = bfi(startMask, NEG2, pk_subs(K, d2));
-            Eend = pk_subs(Eend, d2);
+            if ((i & (FAST_REBASE - 1)) == 0) {
+                // rebase the int16 state on B_i and fold the row offset tp*ins back in
+                const uint32_t d2 = pack2(Brel - tp * sc.ins);
+                base += Brel;
+                Brel = 0;
+                tp = 0;
+                K = bfi(startMask, NEG2, pk_subs(K, d2));
+                Eend = pk_subs(Eend, d2);
+#pragma unroll
+                for (int s = 0; s < P; ++s) L[s] = pk_subs(L[s], d2);
+            }
+            // checkpoint the (true) row i-1 for the traceback: E = ckbase + stored value
             const int q = (i / FAST_R) - 1;
 #pragma unroll
-            for (int s = 0; s < P; ++s) {
-                L[s] = pk_subs(L[s], d2);
-                ck[(uint64_t)q * (P * 64) + s * 64] = pk_max(L[s], K);
-            }
-            if (lane == 0) ckb[q] = base;
+            for (int s = 0; s < P; ++s) ck[(uint64_t)q * (P * 64) + s * 64] = pk_max(L[s], K);
+            if (lane == 0) ckb[q] = base + tp * sc.ins;
         }
         const uint32_t KB = pk_max(K, pack2(Brel + sc.del - tp * sc.ins));
         const uint32_t pd0 = bfi(startMask, NEG2, lane_up(Eend, 1));
@@ -383,7 +385,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     if (T > 65535) { why = "too many templates"; return false; }
     auto ab = [](int v) { return v < 0 ? -v : v; };
     const int maxabs = std::max(std::max(ab(sc.ins), ab(sc.del)), std::max(ab(sc.mismatch), ab(sc.match)));
-    if ((int64_t)(3 * Lmax + FAST_R + 4) * maxabs > 8000) { why = "scores too large for int16 cells"; return false; }
+    if ((int64_t)(3 * Lmax + 2 * FAST_REBASE + 4) * maxabs > 8000) { why = "scores too large for int16 cells"; return false; }
     if (Lmax > 64 * 4) { why = "template longer than 256 bp"; return false; }
 
     int P = 0, split = 0;

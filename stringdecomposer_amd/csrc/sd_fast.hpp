@@ -19,7 +19,8 @@
 
 namespace sd {
 
-constexpr int FAST_R = 32;          // checkpoint / rebase interval (rows)
+constexpr int FAST_R = 32;          // checkpoint interval (rows)
+constexpr int FAST_REBASE = 128;    // int16 rebase interval (rows), a multiple of FAST_R
 constexpr int FAST_LANE_WORDS = 8;  // dwords of per-lane constants
 
 // per-lane constant block (dword index), every dword = packed {lo plane, hi plane} int16

@@ -76,6 +76,14 @@ __device__ __forceinline__ int wave_prefix_max(int v) {
     return v;
 }
 
+// acc[lane == slot] = value (wave-uniform value and slot): one v_mov + one v_cndmask with a
+// scalar one-hot mask instead of v_mov + v_cmp + v_cndmask
+__device__ __forceinline__ void acc_put(int& acc, int value, int slot) {
+    const unsigned long long m = 1ull << slot;
+    int v = value;
+    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(acc) : "v"(v), "s"(m));
+}
+
 // Persistent waves: every wave pulls the next chunk from an atomic queue when it is done with its
 // own, so the tail of a launch is balanced per SIMD instead of per workgroup (C2 fill 18.3 ->
 // 17.7 ms).  `order` lists the chunks longest first.  (A static strided assignment was measured

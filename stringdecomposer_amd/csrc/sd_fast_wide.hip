@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
         const int v = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
         Brel = b + tp * sc.ins;
         const int slot = (row - 1) & 63;
-        accBV = lane == slot ? (int)(((uint32_t)(base + Brel) << 7) | (uint32_t)v) : accBV;
+        acc_put(accBV, (int)(((uint32_t)(base + Brel) << 7) | (uint32_t)v), slot);
         if (slot == 63 || row == n) {
             if (lane <= slot) Bc[row - slot + lane] = accBV;
         }
@@ -127,17 +127,18 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
     for (int i = 1; i < n; ++i) {
         const int rcur = rnext;
         if ((i & (FAST_R - 1)) == 0) {
-            const uint32_t d2 = pack2(Brel - tp * sc.ins);
-            base += Brel;
-            Brel = 0;
-            tp = 0;
+            if ((i & (FAST_REBASE - 1)) == 0) {
+                const uint32_t d2 = pack2(Brel - tp * sc.ins);
+                base += Brel;
+                Brel = 0;
+                tp = 0;
+#pragma unroll
+                for (int s = 0; s < P; ++s) L[s] = pk_subs(L[s], d2);
+            }
             const int q = (i / FAST_R) - 1;
 #pragma unroll
-            for (int s = 0; s < P; ++s) {
-                L[s] = pk_subs(L[s], d2);
-                ck[(uint64_t)q * (P * 64) + s * 64] = L[s];
-            }
-            if (lane == 0) ckb[q] = base;
+            for (int s = 0; s < P; ++s) ck[(uint64_t)q * (P * 64) + s * 64] = L[s];
+            if (lane == 0) ckb[q] = base + tp * sc.ins;
         }
         uint32_t KB = pack2(Brel + sc.del - tp * sc.ins);  // kept in a VGPR: see the per-step pin below
         uint32_t u_[P], v_[P], c_[P];
