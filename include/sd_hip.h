@@ -43,7 +43,8 @@ typedef struct sd_params {
     int32_t threads;                   /* argv[3] (-t): host threads for parse / format            */
     int32_t device;                    /* HIP device ordinal                                      */
     int32_t kernel;                    /* 0 auto, 1 generic int32 workgroup kernel, 2 fast packed-int16 wave kernel */
-    int32_t reserved[6];
+    int32_t max_batch_rows;            /* 0 = size device batches from free HBM; >0 = cap on chunk rows per batch */
+    int32_t reserved[5];
 } sd_params;
 
 void sd_params_default(sd_params* p); /* -1,-1,-1,1 / 5000 / 500 / -1 / 1 / 0 / auto */

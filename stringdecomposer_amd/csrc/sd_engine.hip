@@ -309,38 +309,24 @@ void sd_engine_destroy(sd_engine* e) {
     delete e;
 }
 
-int sd_engine_load_reads(sd_engine* e, const char* const* read_seqs, const int64_t* read_lens,
-                         int32_t n_reads, int64_t* n_chunks, char* errbuf, size_t errlen) {
-    if (!e) return SD_ERR_PARAM;
+// Packs the given chunks (pointer + length each), uploads them and sizes the per-batch device
+// buffers.  e->chunks must be empty on entry; chunk c refers to cptr[c][0 .. clen[c]).
+static int load_chunks_impl(sd_engine* e, const std::vector<const char*>& cptr,
+                            const std::vector<int32_t>& clen, char* errbuf, size_t errlen) {
     e->ran = false;
     e->chunks.clear();
-    e->chunk_read.clear();
-    e->chunk_off.clear();
-    e->read_nchunks.assign((size_t)std::max(n_reads, 0), 0);
-    e->n_reads = n_reads;
-    // chunk table (main.cpp:70-81), then 2-bit packing of all chunks on the host threads
     std::vector<uint32_t> bases2, nmask;
     uint64_t row0 = 0;
     size_t words_total = 0;
-    for (int32_t r = 0; r < n_reads; ++r) {
-        const int64_t len = read_lens[r];
-        int cnt = sd::chunk_plan(len, e->p.part_size, e->p.overlap, [&](int64_t off, int32_t l) {
-            sd::ChunkDesc cd{};
-            cd.woff = (uint32_t)words_total;
-            cd.n = l;
-            cd.noff = -1;
-            cd.row0 = row0;
-            row0 += (uint64_t)l;
-            words_total += ((size_t)l + 15) / 16;
-            e->chunks.push_back(cd);
-            e->chunk_read.push_back(r);
-            e->chunk_off.push_back(off);
-        });
-        if (cnt == 0) {
-            set_err(errbuf, errlen, "ERROR: Sequence #" + std::to_string(r) + " is empty");
-            return SD_ERR_EMPTY;
-        }
-        e->read_nchunks[(size_t)r] = cnt;
+    for (size_t c = 0; c < cptr.size(); ++c) {
+        sd::ChunkDesc cd{};
+        cd.woff = (uint32_t)words_total;
+        cd.n = clen[c];
+        cd.noff = -1;
+        cd.row0 = row0;
+        row0 += (uint64_t)clen[c];
+        words_total += ((size_t)clen[c] + 15) / 16;
+        e->chunks.push_back(cd);
     }
     if (words_total >= (1ull << 31)) {
         set_err(errbuf, errlen, "batch too large: split the reads into smaller groups");
@@ -352,8 +338,7 @@ int sd_engine_load_reads(sd_engine* e, const char* const* read_seqs, const int64
         std::vector<uint8_t> hasn(C0, 0);
         sd::parallel_for((int64_t)C0, e->p.threads, 16, [&](int64_t c) {
             const sd::ChunkDesc& cd = e->chunks[(size_t)c];
-            const char* s = read_seqs[e->chunk_read[(size_t)c]] + e->chunk_off[(size_t)c];
-            hasn[(size_t)c] = sd::pack_chunk(s, cd.n, bases2.data() + cd.woff) ? 1 : 0;
+            hasn[(size_t)c] = sd::pack_chunk(cptr[(size_t)c], cd.n, bases2.data() + cd.woff) ? 1 : 0;
         });
         size_t nwords = 0;
         for (size_t c = 0; c < C0; ++c)
@@ -366,14 +351,13 @@ int sd_engine_load_reads(sd_engine* e, const char* const* read_seqs, const int64
             sd::parallel_for((int64_t)C0, e->p.threads, 16, [&](int64_t c) {
                 const sd::ChunkDesc& cd = e->chunks[(size_t)c];
                 if (cd.noff < 0) return;
-                const char* s = read_seqs[e->chunk_read[(size_t)c]] + e->chunk_off[(size_t)c];
+                const char* s = cptr[(size_t)c];
                 for (int32_t i = 0; i < cd.n; ++i)
                     if (s[i] == 'N') nmask[(size_t)cd.noff + (size_t)(i >> 5)] |= 1u << (i & 31);
             });
     }
     e->rows = (int64_t)row0;
     const size_t C = e->chunks.size();
-    if (n_chunks) *n_chunks = (int64_t)C;
     try {
         SD_HIP(hipSetDevice(e->device));
         const int64_t nck = e->family == 2 ? sd::fast_ckpt_rows_total(e->fplan, e->chunks) : 0;
@@ -426,6 +410,33 @@ int sd_engine_load_reads(sd_engine* e, const char* const* read_seqs, const int64
         return SD_ERR_HIP;
     }
     return SD_OK;
+}
+
+int sd_engine_load_reads(sd_engine* e, const char* const* read_seqs, const int64_t* read_lens,
+                         int32_t n_reads, int64_t* n_chunks, char* errbuf, size_t errlen) {
+    if (!e) return SD_ERR_PARAM;
+    e->chunk_read.clear();
+    e->chunk_off.clear();
+    e->read_nchunks.assign((size_t)std::max(n_reads, 0), 0);
+    e->n_reads = n_reads;
+    // chunk table (main.cpp:70-81)
+    std::vector<const char*> cptr;
+    std::vector<int32_t> clen;
+    for (int32_t r = 0; r < n_reads; ++r) {
+        int cnt = sd::chunk_plan(read_lens[r], e->p.part_size, e->p.overlap, [&](int64_t off, int32_t l) {
+            cptr.push_back(read_seqs[r] + off);
+            clen.push_back(l);
+            e->chunk_read.push_back(r);
+            e->chunk_off.push_back(off);
+        });
+        if (cnt == 0) {
+            set_err(errbuf, errlen, "ERROR: Sequence #" + std::to_string(r) + " is empty");
+            return SD_ERR_EMPTY;
+        }
+        e->read_nchunks[(size_t)r] = cnt;
+    }
+    if (n_chunks) *n_chunks = (int64_t)cptr.size();
+    return load_chunks_impl(e, cptr, clen, errbuf, errlen);
 }
 
 int sd_engine_run(sd_engine* e, void* hip_stream, char* errbuf, size_t errlen) {
@@ -601,38 +612,74 @@ static int decompose_impl(const std::vector<sd::Seq>& reads, const std::vector<s
     sd_engine* eng = nullptr;
     int rc = sd_engine_create(&eng, p, mseq.data(), mlen.data(), (int32_t)monos.size(), eb, sizeof eb);
     if (rc) { err = eb; return rc; }
-    // groups of reads bounded by rows so that device buffers stay moderate
-    const int64_t row_budget = (int64_t)768 << 20;
-    size_t r0 = 0;
-    while (r0 < reads.size() && rc == SD_OK) {
-        int64_t rows = 0;
-        size_t r1 = r0;
-        while (r1 < reads.size() && (r1 == r0 || rows + (int64_t)reads[r1].seq.size() * 11 / 10 <= row_budget)) {
-            rows += (int64_t)reads[r1].seq.size() * 11 / 10;
-            ++r1;
+    // Global chunk table (main.cpp:70-81); the device works through it in batches of consecutive
+    // chunks sized to the free HBM, so a single 200-Mb sequence and a million reads take the same path.
+    struct CRef { int32_t read; int64_t off; int32_t len; };
+    std::vector<CRef> table;
+    std::vector<int32_t> nch(reads.size(), 0);
+    for (size_t r = 0; r < reads.size(); ++r)
+        nch[r] = sd::chunk_plan((int64_t)reads[r].seq.size(), p->part_size, p->overlap,
+                                [&](int64_t off, int32_t l) { table.push_back(CRef{(int32_t)r, off, l}); });
+    int64_t row_budget = (int64_t)768 << 20;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            // per row: B + argB + records (24 B) + fast-family checkpoints (P*256 B every FAST_R rows)
+            const double per_row = 26.0 + (eng->family == 2 ? eng->fplan.P * 256.0 / sd::FAST_R : 0.0);
+            row_budget = std::min<int64_t>(row_budget, (int64_t)(0.55 * (double)free_b / per_row));
+            row_budget = std::max<int64_t>(row_budget, (int64_t)p->part_size + p->overlap);
         }
-        std::vector<const char*> rs;
-        std::vector<int64_t> rl;
-        for (size_t r = r0; r < r1; ++r) { rs.push_back(reads[r].seq.data()); rl.push_back((int64_t)reads[r].seq.size()); }
-        int64_t nch = 0;
-        rc = sd_engine_load_reads(eng, rs.data(), rl.data(), (int32_t)rs.size(), &nch, eb, sizeof eb);
+        if (p->max_batch_rows > 0) row_budget = p->max_batch_rows;  // explicit cap (tests, small GPUs)
+    }
+    std::vector<sd_rec> batch_rows;      // records of the read being assembled
+    size_t next_read = 0;                // first read not yet written
+    int32_t chunks_seen_of_read = 0;
+    size_t c0 = 0;
+    while (c0 < table.size() && rc == SD_OK) {
+        int64_t rows = 0;
+        size_t c1 = c0;
+        while (c1 < table.size() && (c1 == c0 || rows + table[c1].len <= row_budget)) rows += table[c1++].len;
+        std::vector<const char*> cptr;
+        std::vector<int32_t> clen;
+        for (size_t c = c0; c < c1; ++c) {
+            cptr.push_back(reads[(size_t)table[c].read].seq.data() + table[c].off);
+            clen.push_back(table[c].len);
+        }
+        rc = load_chunks_impl(eng, cptr, clen, eb, sizeof eb);
         if (rc == SD_OK) rc = sd_engine_run(eng, nullptr, eb, sizeof eb);
         sd_rec* recs = nullptr; int64_t* roff = nullptr;
         if (rc == SD_OK) rc = sd_engine_fetch(eng, &recs, &roff, eb, sizeof eb);
-        sd_rec* rows_o = nullptr; int64_t* row_off = nullptr;
-        if (rc == SD_OK) rc = sd_engine_assemble(eng, recs, roff, &rows_o, &row_off, eb, sizeof eb);
         if (rc == SD_OK) {
-            std::vector<std::string> parts(r1 - r0);
-            sd::parallel_for((int64_t)(r1 - r0), p->threads, 4, [&](int64_t q) {
-                const size_t r = r0 + (size_t)q;
-                const int64_t a = row_off[q], b = row_off[q + 1];
-                sd::format_rows(parts[(size_t)q], reads[r].name.data(), reads[r].name.size(), tnames,
-                                rows_o + a, (size_t)(b - a));
+            // per-read assembly (main.cpp:104-117); reads complete in input order
+            std::vector<std::vector<sd_rec>> done_rows;
+            std::vector<size_t> done_ids;
+            for (size_t c = c0; c < c1; ++c) {
+                const int32_t add = (int32_t)table[c].off;
+                for (int64_t x = roff[c - c0]; x < roff[c - c0 + 1]; ++x) {
+                    sd_rec t = recs[x];
+                    t.start += add;
+                    t.end += add;
+                    batch_rows.push_back(t);
+                }
+                if (++chunks_seen_of_read == nch[next_read]) {
+                    done_rows.emplace_back();
+                    done_rows.back().swap(batch_rows);
+                    done_ids.push_back(next_read);
+                    ++next_read;
+                    chunks_seen_of_read = 0;
+                }
+            }
+            std::vector<std::string> parts(done_ids.size());
+            sd::parallel_for((int64_t)done_ids.size(), p->threads, 4, [&](int64_t q) {
+                sd::seam_merge(done_rows[(size_t)q]);
+                const sd::Seq& rd = reads[done_ids[(size_t)q]];
+                sd::format_rows(parts[(size_t)q], rd.name.data(), rd.name.size(), tnames,
+                                done_rows[(size_t)q].data(), done_rows[(size_t)q].size());
             });
             for (const std::string& part : parts) tsv += part;
         }
-        std::free(recs); std::free(roff); std::free(rows_o); std::free(row_off);
-        r0 = r1;
+        std::free(recs); std::free(roff);
+        c0 = c1;
     }
     if (rc) err = eb;
     sd_engine_destroy(eng);

@@ -44,7 +44,7 @@ class Params(C.Structure):
     _fields_ = [("ins", C.c_int32), ("del_", C.c_int32), ("mismatch", C.c_int32),
                 ("match", C.c_int32), ("part_size", C.c_int32), ("overlap", C.c_int32),
                 ("ed_thr", C.c_int32), ("threads", C.c_int32), ("device", C.c_int32),
-                ("kernel", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("kernel", C.c_int32), ("max_batch_rows", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class Rec(C.Structure):
@@ -116,13 +116,14 @@ def _strs(seq):
 
 
 def make_params(scoring=(-1, -1, -1, 1), part_size=5000, overlap=500, ed_thr=-1, threads=1,
-                device=0, kernel=KERNEL_AUTO):
+                device=0, kernel=KERNEL_AUTO, max_batch_rows=0):
     L = load()
     p = Params()
     L.sd_params_default(C.byref(p))
     p.ins, p.del_, p.mismatch, p.match = [int(x) for x in scoring]
     p.part_size, p.overlap, p.ed_thr = int(part_size), int(overlap), int(ed_thr)
     p.threads, p.device, p.kernel = int(threads), int(device), int(kernel)
+    p.max_batch_rows = int(max_batch_rows)
     return p
 
 

@@ -189,6 +189,18 @@ def test_64_monomer_set_wide_layout(oracle):
     assert res["fast"] == res["generic"]
 
 
+def test_device_batching_is_invisible():
+    """Chunks are fed to the device in batches sized to the free HBM; forcing tiny batches (a
+    single read then spans many batches) must not change a byte."""
+    mn, ms = synth.make_monomers(12, seed=9)
+    rn, rs = synth.make_reads(ms, 5, read_len=50000, seed=9)
+    rs[1] = rs[1][:123]
+    rs[3] = rs[3][:27111]
+    ref = lib.decompose(rn, rs, mn, ms)
+    for cap in (5500, 17000, 60001):
+        assert lib.decompose(rn, rs, mn, ms, max_batch_rows=cap, threads=3) == ref
+
+
 def test_cli_end_to_end_reference_golden(tmp_path):
     """The reference's own integration test (reference Makefile:16-19): CLI with --second-best on
     test_data, grep the log line, diff final_decomposition.tsv against the golden file."""
