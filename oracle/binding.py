@@ -58,6 +58,17 @@ def lib():
                                     C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int, C.c_int,
                                     C.c_int, C.c_int, Scoring, C.POINTER(C.c_void_p),
                                     C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+        L.sdo_decompose_files_ex.restype = C.c_int
+        L.sdo_decompose_files_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, Scoring,
+                                             C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                             C.c_char_p, C.c_size_t]
+        L.sdo_decompose_ex.restype = C.c_int
+        L.sdo_decompose_ex.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int,
+                                       C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int, C.c_int,
+                                       C.c_int, C.c_int, Scoring, C.c_int, C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
+        L.sdo_hw_edit_distance.restype = C.c_int
+        L.sdo_hw_edit_distance.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int]
         L.sdo_nw_identity.restype = C.c_int
         L.sdo_nw_identity.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int),
                                       C.POINTER(C.c_int)]
@@ -124,14 +135,15 @@ def postprocess(recs):
     return [(arr[i].tmpl, arr[i].start, arr[i].end, arr[i].score) for i in range(m)]
 
 
-def decompose_files(reads_fa, monomers_fa, threads=1, part=5000, overlap=500, sc=(-1, -1, -1, 1)):
+def decompose_files(reads_fa, monomers_fa, threads=1, part=5000, overlap=500, sc=(-1, -1, -1, 1),
+                    ed_thr=-1):
     """Raw TSV bytes, as the reference `dp` prints on stdout."""
     L = lib()
     out = C.c_void_p()
     ln = C.c_size_t()
     err = C.create_string_buffer(2048)
-    rc = L.sdo_decompose_files(os.fsencode(reads_fa), os.fsencode(monomers_fa), threads, part,
-                               overlap, scoring(sc), C.byref(out), C.byref(ln), err, 2048)
+    rc = L.sdo_decompose_files_ex(os.fsencode(reads_fa), os.fsencode(monomers_fa), threads, part,
+                                  overlap, scoring(sc), ed_thr, C.byref(out), C.byref(ln), err, 2048)
     if rc != 0:
         raise OracleError(rc, err.value.decode(errors="replace"))
     data = C.string_at(out, ln.value)
@@ -140,14 +152,14 @@ def decompose_files(reads_fa, monomers_fa, threads=1, part=5000, overlap=500, sc
 
 
 def decompose(read_names, read_seqs, mono_names, mono_seqs, threads=1, part=5000, overlap=500,
-              sc=(-1, -1, -1, 1)):
+              sc=(-1, -1, -1, 1), ed_thr=-1):
     L = lib()
     out = C.c_void_p()
     ln = C.c_size_t()
     err = C.create_string_buffer(2048)
-    rc = L.sdo_decompose(_strs(read_names), _strs(read_seqs), len(read_names), _strs(mono_names),
-                         _strs(mono_seqs), len(mono_names), threads, part, overlap, scoring(sc),
-                         C.byref(out), C.byref(ln), err, 2048)
+    rc = L.sdo_decompose_ex(_strs(read_names), _strs(read_seqs), len(read_names), _strs(mono_names),
+                            _strs(mono_seqs), len(mono_names), threads, part, overlap, scoring(sc),
+                            ed_thr, C.byref(out), C.byref(ln), err, 2048)
     if rc != 0:
         raise OracleError(rc, err.value.decode(errors="replace"))
     data = C.string_at(out, ln.value)
@@ -164,6 +176,13 @@ def nw_identity(query, target):
     t = target.encode() if isinstance(target, str) else target
     ed = L.sdo_nw_identity(q, len(q), t, len(t), C.byref(m), C.byref(c))
     return ed, m.value, c.value
+
+
+def hw_edit_distance(tmpl, text):
+    L = lib()
+    a = tmpl.encode() if isinstance(tmpl, str) else tmpl
+    b = text.encode() if isinstance(text, str) else text
+    return L.sdo_hw_edit_distance(a, len(a), b, len(b))
 
 
 def reverse_complement(s):

@@ -359,10 +359,56 @@ static void sb_put(sbuf* s, const char* t, size_t n) {
     s->p[s->len] = 0;
 }
 
-int sdo_decompose(const char* const* read_names, const char* const* read_seqs, int n_reads,
-                  const char* const* mono_names, const char* const* mono_seqs, int n_mono,
-                  int threads, int part_size, int overlap, sdo_scoring sc, char** tsv,
-                  size_t* tsv_len, char* err, size_t errlen) {
+/* MonomerEditDistance (main.cpp:128-133): edlib HW ("infix") mode = unit-cost edit distance of the
+ * whole template against the best-matching substring of the chunk (free gaps before and after
+ * the match in the chunk).  Plain DP restatement of that definition. */
+int sdo_hw_edit_distance(const char* tmpl, int m, const char* text, int n) {
+    int* col = (int*)malloc(sizeof(int) * (size_t)(m + 1));
+    for (int i = 0; i <= m; ++i) col[i] = i;
+    int best = col[m];
+    for (int j = 1; j <= n; ++j) {
+        int diag = col[0]; /* D[0][j-1] = 0 */
+        col[0] = 0;
+        for (int i = 1; i <= m; ++i) {
+            int up = col[i - 1], left = col[i];
+            int v = diag + (tmpl[i - 1] == text[j - 1] ? 0 : 1);
+            if (up + 1 < v) v = up + 1;
+            if (left + 1 < v) v = left + 1;
+            diag = left;
+            col[i] = v;
+        }
+        if (col[m] < best) best = col[m];
+    }
+    free(col);
+    return best;
+}
+
+/* FilterMonomersForRead (main.cpp:135-149): order the templates by (distance, index), keep the
+ * first one and every other one with distance <= ed_thr, in that order.  Returns the count;
+ * keep[] receives the original template indices in filtered order. */
+int sdo_filter_templates(const char* chunk, int n, const char* const* tmpl, const int* tlen, int T,
+                         int ed_thr, int* keep) {
+    int* dist = (int*)malloc(sizeof(int) * (size_t)T);
+    int* ord = (int*)malloc(sizeof(int) * (size_t)T);
+    for (int j = 0; j < T; ++j) { dist[j] = sdo_hw_edit_distance(tmpl[j], tlen[j], chunk, n); ord[j] = j; }
+    for (int a = 1; a < T; ++a) { /* insertion sort by (dist, index); indices start ordered */
+        int x = ord[a], b = a - 1;
+        while (b >= 0 && dist[ord[b]] > dist[x]) { ord[b + 1] = ord[b]; --b; }
+        ord[b + 1] = x;
+    }
+    int cnt = 0;
+    keep[cnt++] = ord[0];
+    for (int a = 1; a < T; ++a)
+        if (dist[ord[a]] <= ed_thr) keep[cnt++] = ord[a];
+    free(dist);
+    free(ord);
+    return cnt;
+}
+
+int sdo_decompose_ex(const char* const* read_names, const char* const* read_seqs, int n_reads,
+                     const char* const* mono_names, const char* const* mono_seqs, int n_mono,
+                     int threads, int part_size, int overlap, sdo_scoring sc, int ed_thr, char** tsv,
+                     size_t* tsv_len, char* err, size_t errlen) {
     *tsv = NULL; *tsv_len = 0;
     if (part_size <= 0 || overlap < 0 || n_mono <= 0) {
         set_err(err, errlen, "bad parameters");
@@ -429,8 +475,22 @@ int sdo_decompose(const char* const* read_names, const char* const* read_seqs, i
         for (int64_t c = 0; c < total_chunks; ++c) {
             int n = c_len[c];
             sdo_rec* rr = (sdo_rec*)malloc(sizeof(sdo_rec) * (size_t)n);
-            int k = sdo_align_chunk(read_seqs[c_read[c]] + c_off[c], n, (const char* const*)ts, tl,
+            int k;
+            if (ed_thr > -1) { /* main.cpp:91-93 */
+                int* keep = (int*)malloc(sizeof(int) * (size_t)T);
+                int nk = sdo_filter_templates(read_seqs[c_read[c]] + c_off[c], n, (const char* const*)ts,
+                                              tl, T, ed_thr, keep);
+                const char** fs = (const char**)malloc(sizeof(char*) * (size_t)nk);
+                int* fl = (int*)malloc(sizeof(int) * (size_t)nk);
+                for (int a = 0; a < nk; ++a) { fs[a] = ts[keep[a]]; fl[a] = tl[keep[a]]; }
+                k = sdo_align_chunk(read_seqs[c_read[c]] + c_off[c], n, fs, fl, nk, sc, rr, n, NULL,
+                                    NULL, NULL);
+                for (int a = 0; a < k; ++a) rr[a].tmpl = keep[rr[a].tmpl];
+                free(keep); free(fs); free(fl);
+            } else {
+                k = sdo_align_chunk(read_seqs[c_read[c]] + c_off[c], n, (const char* const*)ts, tl,
                                     T, sc, rr, n, NULL, NULL, NULL);
+            }
             if (k < 0) {
 #ifdef _OPENMP
 #pragma omp atomic write
@@ -490,17 +550,32 @@ int sdo_decompose(const char* const* read_names, const char* const* read_seqs, i
     return 0;
 }
 
+int sdo_decompose(const char* const* read_names, const char* const* read_seqs, int n_reads,
+                  const char* const* mono_names, const char* const* mono_seqs, int n_mono,
+                  int threads, int part_size, int overlap, sdo_scoring sc, char** tsv,
+                  size_t* tsv_len, char* err, size_t errlen) {
+    return sdo_decompose_ex(read_names, read_seqs, n_reads, mono_names, mono_seqs, n_mono, threads,
+                            part_size, overlap, sc, -1, tsv, tsv_len, err, errlen);
+}
+
 int sdo_decompose_files(const char* reads_fa, const char* monomers_fa, int threads, int part_size,
                         int overlap, sdo_scoring sc, char** tsv, size_t* tsv_len, char* err,
                         size_t errlen) {
+    return sdo_decompose_files_ex(reads_fa, monomers_fa, threads, part_size, overlap, sc, -1, tsv,
+                                  tsv_len, err, errlen);
+}
+
+int sdo_decompose_files_ex(const char* reads_fa, const char* monomers_fa, int threads, int part_size,
+                           int overlap, sdo_scoring sc, int ed_thr, char** tsv, size_t* tsv_len,
+                           char* err, size_t errlen) {
     sdo_fasta R, M;
     int rc = sdo_load_fasta(reads_fa, &R, err, errlen);
     if (rc) return rc;
     rc = sdo_load_fasta(monomers_fa, &M, err, errlen);
     if (rc) { sdo_free_fasta(&R); return rc; }
-    rc = sdo_decompose((const char* const*)R.names, (const char* const*)R.seqs, R.n,
-                       (const char* const*)M.names, (const char* const*)M.seqs, M.n, threads,
-                       part_size, overlap, sc, tsv, tsv_len, err, errlen);
+    rc = sdo_decompose_ex((const char* const*)R.names, (const char* const*)R.seqs, R.n,
+                          (const char* const*)M.names, (const char* const*)M.seqs, M.n, threads,
+                          part_size, overlap, sc, ed_thr, tsv, tsv_len, err, errlen);
     sdo_free_fasta(&R);
     sdo_free_fasta(&M);
     return rc;

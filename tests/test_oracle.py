@@ -11,12 +11,14 @@ import pytest
 from conftest import GOLDEN, case_names, load_case
 
 
-@pytest.mark.parametrize("name", case_names())
+@pytest.mark.parametrize("name", case_names(include_edthr=True))
 def test_oracle_matches_reference_binary_output(oracle, name):
     c = load_case(name)
     sc = tuple(c["scoring"]) if c["scoring"] else (-1, -1, -1, 1)
-    got = oracle.decompose_files(c["reads"], c["monomers"], threads=4, part=c["part"],
-                                 overlap=c["overlap"], sc=sc)
+    # --ed_thr fixtures come from the 10-argument form, in which the reference ignores the scores
+    got = oracle.decompose_files(c["reads"], c["monomers"], threads=8, part=c["part"],
+                                 overlap=c["overlap"], sc=sc if c["ed_thr"] is None else (-1, -1, -1, 1),
+                                 ed_thr=-1 if c["ed_thr"] is None else c["ed_thr"])
     assert hashlib.sha256(got).hexdigest() == c["sha256"]
     assert got == c["raw"]
 
