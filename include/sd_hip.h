@@ -39,7 +39,7 @@ typedef struct sd_params {
     int32_t ins, del, mismatch, match; /* argv[6..9]; defaults -1,-1,-1,1 (main.cpp:380)          */
     int32_t part_size;                 /* argv[4] (-b/--batch-size, main.py:212): chunk step, bp   */
     int32_t overlap;                   /* argv[5] (-v/--overlap,   main.py:216)                    */
-    int32_t ed_thr;                    /* argv[10] (--ed_thr): -1 = off; >=0 not supported yet     */
+    int32_t ed_thr;                    /* argv[10] (--ed_thr): -1 = off; >=0 = per-chunk prefilter */
     int32_t threads;                   /* argv[3] (-t): host threads for parse / format            */
     int32_t device;                    /* HIP device ordinal                                      */
     int32_t kernel;                    /* 0 auto, 1 generic int32 workgroup kernel, 2 fast packed-int16 wave kernel */

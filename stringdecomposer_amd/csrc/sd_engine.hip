@@ -90,6 +90,10 @@ struct sd_engine {
     DevBuf<uint8_t> d_ftcodes;       // base code of template cell (j,k)
     DevBuf<uint32_t> d_fckpt;        // checkpoints
     DevBuf<int32_t> d_fckbase;       // per-checkpoint rebase values
+    // --ed_thr prefilter (fast family only)
+    DevBuf<unsigned long long> d_peq;
+    DevBuf<int32_t> d_endvl, d_endoff, d_dist;
+    DevBuf<uint32_t> d_cendoff, d_crank;
     DevBuf<int> d_queue;             // work-queue heads of the persistent kernels (fill, trace)
     DevBuf<int> d_order;             // chunk indices, longest first
     int n_cu = 256;
@@ -151,10 +155,6 @@ int validate_params(const sd_params* p, std::string& err) {
     if (!p) { err = "null params"; return SD_ERR_PARAM; }
     if (p->part_size <= 0) { err = "part_size must be > 0"; return SD_ERR_PARAM; }
     if (p->overlap < 0) { err = "overlap must be >= 0"; return SD_ERR_PARAM; }
-    if (p->ed_thr > -1) {
-        err = "--ed_thr >= 0 (per-chunk monomer prefilter, main.cpp:128-149) is not supported by the device path yet";
-        return SD_ERR_UNSUPPORTED;
-    }
     return SD_OK;
 }
 
@@ -275,6 +275,10 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
             return SD_ERR_UNSUPPORTED;
         }
         if (family != 1 && family != 2) { set_err(errbuf, errlen, "bad kernel family"); return SD_ERR_PARAM; }
+        if (p->ed_thr > -1 && family != 2) {
+            set_err(errbuf, errlen, "--ed_thr needs the fast kernel family, which is not applicable here: " + why);
+            return SD_ERR_UNSUPPORTED;
+        }
         e->family = family;
         e->d_toff.upload(e->toff);
         e->d_tlen.upload(e->tlen);
@@ -290,6 +294,13 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
             e->d_flane.upload(e->fplan.lane_consts);
             e->d_fslot.upload(e->fplan.slot_of);
             e->d_ftcodes.upload(e->fplan.tcodes);
+            if (p->ed_thr > -1) {
+                std::vector<unsigned long long> peq;
+                sd::build_peq(e->tseq, peq);
+                e->d_peq.upload(peq);
+                e->d_endvl.upload(e->fplan.end_vlane);
+                e->d_endoff.upload(e->fplan.end_off);
+            }
         }
         SD_HIP(hipEventCreate(&e->ev_run0));
         SD_HIP(hipEventCreate(&e->ev_run1));
@@ -400,6 +411,11 @@ static int load_chunks_impl(sd_engine* e, const std::vector<const char*>& cptr,
             ensure_events(e->ev_fill, e->subs.size());
             ensure_events(e->ev_trace, e->subs.size());
         } else {
+            if (e->p.ed_thr > -1) {
+                e->d_dist.alloc(C * (size_t)e->T);
+                e->d_cendoff.alloc(C * 64);
+                e->d_crank.alloc(C * 64);
+            }
             e->d_fckpt.alloc((size_t)nck * (size_t)e->fplan.P * 64);
             e->d_fckbase.alloc((size_t)nck + 1);
             ensure_events(e->ev_fill, 1);
@@ -466,10 +482,16 @@ int sd_engine_run(sd_engine* e, void* hip_stream, char* errbuf, size_t errlen) {
                     ++e->fill_launches;
                 }
             } else {
+                const bool ranked = e->p.ed_thr > -1;
+                if (ranked)  // main.cpp:91-93: per-chunk template prefilter
+                    sd::launch_edthr_filter(st, e->d_chunks.p, C, e->T, e->p.ed_thr, e->d_bases2.p,
+                                            e->d_nmask.p, e->d_peq.p, e->d_tlen.p, e->d_endvl.p,
+                                            e->d_endoff.p, e->d_dist.p, e->d_cendoff.p, e->d_crank.p);
                 SD_HIP(hipEventRecord(e->ev_fill[0], st));
                 sd::launch_fast_fill(e->fplan, st, e->d_chunks.p, C, e->d_bases2.p, e->d_nmask.p,
                                      e->d_ftable.p, e->d_flane.p, e->sc, e->d_B.p, e->d_argB.p,
-                                     e->d_fckpt.p, e->d_fckbase.p, e->d_queue.p, e->d_order.p, e->n_cu);
+                                     e->d_fckpt.p, e->d_fckbase.p, e->d_queue.p, e->d_order.p, e->n_cu,
+                                     ranked ? e->d_cendoff.p : nullptr, ranked ? e->d_crank.p : nullptr);
                 SD_HIP(hipEventRecord(e->ev_fill[1], st));
                 SD_HIP(hipEventRecord(e->ev_trace[0], st));
                 sd::launch_fast_trace(e->fplan, st, e->d_chunks.p, C, e->d_bases2.p, e->d_nmask.p,

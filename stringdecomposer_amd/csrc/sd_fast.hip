@@ -40,13 +40,14 @@ namespace sd {
 #ifndef SD_FILL_NW
 #define SD_FILL_NW 8   // waves (= chunks) per workgroup; two workgroups per CU
 #endif
-template <int P>
+template <int P, bool RANKED>
 __global__ __launch_bounds__(SD_FILL_NW * 64, SD_FILL_NW / 2) void sd_fast_fill(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int H, int32_t* __restrict__ Bout,
     int32_t* __restrict__ argV, uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase,
-    int* __restrict__ queue, const int* __restrict__ order) {
+    int* __restrict__ queue, const int* __restrict__ order, const uint32_t* __restrict__ cendoff,
+    const uint32_t* __restrict__ crank) {
     constexpr int P4 = (P + 3) & ~3;
     extern __shared__ uint32_t lds[];  // [5][P4/4][64][4]
     constexpr int TBL = 5 * P4 * 64;
@@ -70,7 +71,10 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, SD_FILL_NW / 2) void sd_fast_fill(
     const uint32_t startMask = lc[FLC_STARTMASK];
     const uint32_t contMask = lc[FLC_CONTMASK];
     const uint32_t cont2Mask = lc[FLC_CONT2];
-    const uint32_t endOff = lc[FLC_ENDOFF];
+    const uint32_t endOffPlan = lc[FLC_ENDOFF];
+    // --ed_thr: per-chunk end offsets (-inf for dropped templates) and tie-break ranks
+    const uint32_t endOff = RANKED ? cendoff[(size_t)c * 64 + lane] : endOffPlan;
+    const uint32_t rank2 = RANKED ? crank[(size_t)c * 64 + lane] : 0u;
     const uint32_t row0adj = lc[FLC_ROW0];
     const uint32_t ins2 = pack2(sc.ins);
 
@@ -114,8 +118,18 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, SD_FILL_NW / 2) void sd_fast_fill(
         const int lo = (int)(short)(val & 0xffffu);
         const int hi = (int)val >> 16;
         const int b = wave_max(max(lo, hi));
-        const unsigned long long mlo = __ballot(lo == b);
-        const unsigned long long mhi = __ballot(hi == b);
+        unsigned long long mlo, mhi;
+        if (RANKED) {
+            // ties go to the first template of the chunk's filtered order (main.cpp:141-147)
+            const int klo = lo == b ? (int)(rank2 & 0xffffu) : 0x7fff;
+            const int khi = hi == b ? (int)(rank2 >> 16) : 0x7fff;
+            const int kmin = -wave_max(-min(klo, khi));
+            mlo = __ballot(klo == kmin);
+            mhi = __ballot(khi == kmin);
+        } else {
+            mlo = __ballot(lo == b);
+            mhi = __ballot(hi == b);
+        }
         const int v = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
         Brel = b + tp * sc.ins;
         const int slot = (row - 1) & 63;
@@ -430,6 +444,13 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         }
     }
     plan.H = Vmax - 1;
+    plan.end_vlane.assign((size_t)T, 0);
+    plan.end_off.assign((size_t)T, 0);
+    for (int j = 0; j < T; ++j) {
+        const int L = (int)tseq[(size_t)j].size();
+        plan.end_vlane[(size_t)j] = plan.vlane0[(size_t)j] + (L + P - 1) / P - 1;
+        plan.end_off[(size_t)j] = (L - 1) * sc.del;
+    }
 
     // per virtual lane: owner template and index inside it
     std::vector<int> owner(128, -1), uidx(128, 0), nv(128, 0);
@@ -533,23 +554,29 @@ int64_t fast_ckpt_rows_total(const FastPlan& plan, std::vector<ChunkDesc>& chunk
 void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                       const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                       const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV,
-                      uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order, int n_cu) {
+                      uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order, int n_cu,
+                      const uint32_t* cendoff, const uint32_t* crank) {
     const int NW = SD_FILL_NW;
     const int grid = std::min((n_chunks + NW - 1) / NW, 2 * n_cu);  // persistent: 2 workgroups per CU
     (void)hipMemsetAsync(queue, 0, sizeof(int), st);
     if (plan.wide) {
         launch_fast_fill_wide(plan, st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt,
-                              ckbase, queue, order, n_cu);
+                              ckbase, queue, order, n_cu, cendoff, crank);
         return;
     }
     const size_t lds = (size_t)5 * plan.P4 * 64 * sizeof(uint32_t);
-#define SD_FILL(PP)                                                                                \
-    case PP:                                                                                       \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP>),                \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-        hipLaunchKernelGGL(sd_fast_fill<PP>, dim3(grid), dim3(NW * 64), lds, st, chunks, n_chunks, \
-                           bases2, nmask, table, lane_consts, sc, plan.H, B, argV, ckpt, ckbase,   \
-                           queue, order);                                                         \
+    const bool ranked = cendoff != nullptr;
+#define SD_FILL_K(PP, RK)                                                                            \
+    {                                                                                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK>),              \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+        hipLaunchKernelGGL((sd_fast_fill<PP, RK>), dim3(grid), dim3(NW * 64), lds, st, chunks,        \
+                           n_chunks, bases2, nmask, table, lane_consts, sc, plan.H, B, argV, ckpt,   \
+                           ckbase, queue, order, cendoff, crank);                                    \
+    }
+#define SD_FILL(PP)                                                                                  \
+    case PP:                                                                                         \
+        if (ranked) SD_FILL_K(PP, true) else SD_FILL_K(PP, false)                                    \
         break;
     switch (plan.P) {
         SD_FILL(4) SD_FILL(8) SD_FILL(12) SD_FILL(16) SD_FILL(20) SD_FILL(24) SD_FILL(28) SD_FILL(30)
@@ -559,6 +586,7 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
         default: break;
     }
 #undef SD_FILL
+#undef SD_FILL_K
 }
 
 void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,

@@ -49,6 +49,8 @@ struct FastPlan {
     std::vector<uint32_t> lane_consts;   // [64][FAST_LANE_WORDS]
     std::vector<uint16_t> slot_of;       // per template cell x=toff[j]+k: (slot << 7) | vlane
     std::vector<uint8_t> tcodes;         // per template cell: base code
+    std::vector<int32_t> end_vlane;      // virtual lane holding the end of template j
+    std::vector<int32_t> end_off;        // (L_j - 1) * del
 };
 
 // slots-per-virtual-lane values the fill kernels are instantiated for
@@ -61,19 +63,29 @@ static const int FAST_WIDE_P_LIST[] = {80, 96, 112, 128, 144, 160, 176, 192, 208
 bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max_rows,
                      FastPlan& plan, std::string& why);
 
+// --ed_thr prefilter on the device (sd_filter.hip): infix edit distances, kept set and ranks per
+// chunk -> per-chunk lane constants (cendoff, crank: [chunk][64] packed {lo,hi} int16)
+void build_peq(const std::vector<std::string>& tseq, std::vector<unsigned long long>& peq);
+void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, int T, int ed_thr,
+                         const uint32_t* bases2, const uint32_t* nmask, const unsigned long long* peq,
+                         const int32_t* tlen, const int32_t* end_vlane, const int32_t* end_off,
+                         int32_t* dist, uint32_t* cendoff, uint32_t* crank);
+
 // number of checkpoint rows of the batch; fills ChunkDesc::pad with each chunk's first checkpoint
 int64_t fast_ckpt_rows_total(const FastPlan& plan, std::vector<ChunkDesc>& chunks);
 
 void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                       const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                       const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV,
-                      uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order, int n_cu);
+                      uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order, int n_cu,
+                      const uint32_t* cendoff, const uint32_t* crank);
 
 // wide variant (sd_fast_wide.hip), called by launch_fast_fill when plan.wide
 void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                            const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                            const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt,
-                           int32_t* ckbase, int* queue, const int* order, int n_cu);
+                           int32_t* ckbase, int* queue, const int* order, int n_cu,
+                           const uint32_t* cendoff, const uint32_t* crank);
 
 void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                        const uint32_t* bases2, const uint32_t* nmask, const uint16_t* slot_of,

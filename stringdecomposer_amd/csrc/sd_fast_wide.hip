@@ -36,13 +36,14 @@ __device__ __forceinline__ uint32_t add_b8(uint32_t u, uint32_t tb, int pair) {
 
 }  // namespace
 
-template <int P>
+template <int P, bool RANKED>
 __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int32_t* __restrict__ Bout,
     uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase, int* __restrict__ queue,
-    const int* __restrict__ order) {
+    const int* __restrict__ order, const uint32_t* __restrict__ cendoff,
+    const uint32_t* __restrict__ crank) {
     static_assert(P % 16 == 0, "wide variant streams the table 16 slots at a time");
     constexpr int G = P / 16;
     extern __shared__ uint32_t lds[];  // [5][G][2 halves][64][4]
@@ -64,7 +65,10 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
     rs.init(bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr, n);
 
     const uint32_t* lc = lane_consts + lane * FAST_LANE_WORDS;
-    const uint32_t endOff = lc[FLC_ENDOFF];
+    const uint32_t endOffPlan = lc[FLC_ENDOFF];
+    // --ed_thr: per-chunk end offsets (-inf for dropped templates) and tie-break ranks
+    const uint32_t endOff = RANKED ? cendoff[(size_t)c * 64 + lane] : endOffPlan;
+    const uint32_t rank2 = RANKED ? crank[(size_t)c * 64 + lane] : 0u;
     const uint32_t row0adj = lc[FLC_ROW0];
     const uint32_t ins2 = pack2(sc.ins);
 
@@ -90,8 +94,18 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
         const int lo = (int)(short)(val & 0xffffu);
         const int hi = (int)val >> 16;
         const int b = wave_max(max(lo, hi));
-        const unsigned long long mlo = __ballot(lo == b);
-        const unsigned long long mhi = __ballot(hi == b);
+        unsigned long long mlo, mhi;
+        if (RANKED) {
+            // ties go to the first template of the chunk's filtered order (main.cpp:141-147)
+            const int klo = lo == b ? (int)(rank2 & 0xffffu) : 0x7fff;
+            const int khi = hi == b ? (int)(rank2 >> 16) : 0x7fff;
+            const int kmin = -wave_max(-min(klo, khi));
+            mlo = __ballot(klo == kmin);
+            mhi = __ballot(khi == kmin);
+        } else {
+            mlo = __ballot(lo == b);
+            mhi = __ballot(hi == b);
+        }
         const int v = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
         Brel = b + tp * sc.ins;
         const int slot = (row - 1) & 63;
@@ -182,17 +196,23 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
 void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                            const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                            const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt,
-                           int32_t* ckbase, int* queue, const int* order, int n_cu) {
+                           int32_t* ckbase, int* queue, const int* order, int n_cu,
+                           const uint32_t* cendoff, const uint32_t* crank) {
     const int NW = 8;
     const int grid = std::min((n_chunks + NW - 1) / NW, n_cu);  // persistent: one workgroup per CU (LDS)
     const size_t lds = (size_t)5 * (plan.P / 16) * 512 * sizeof(uint32_t);
+    const bool ranked = cendoff != nullptr;
+#define SD_FILLW_K(PP, RK)                                                                           \
+    {                                                                                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill_wide<PP, RK>),         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+        hipLaunchKernelGGL((sd_fast_fill_wide<PP, RK>), dim3(grid), dim3(NW * 64), lds, st, chunks,   \
+                           n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt, ckbase, queue,  \
+                           order, cendoff, crank);                                                   \
+    }
 #define SD_FILLW(PP)                                                                                 \
     case PP:                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill_wide<PP>),             \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-        hipLaunchKernelGGL(sd_fast_fill_wide<PP>, dim3(grid), dim3(NW * 64), lds, st, chunks,        \
-                           n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt, ckbase, queue,  \
-                           order);                                                                   \
+        if (ranked) SD_FILLW_K(PP, true) else SD_FILLW_K(PP, false)                                  \
         break;
     switch (plan.P) {
         SD_FILLW(80) SD_FILLW(96) SD_FILLW(112) SD_FILLW(128) SD_FILLW(144) SD_FILLW(160)
@@ -200,6 +220,7 @@ void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc
         default: break;
     }
 #undef SD_FILLW
+#undef SD_FILLW_K
 }
 
 }  // namespace sd

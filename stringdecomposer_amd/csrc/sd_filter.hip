@@ -1,0 +1,144 @@
+// sd_filter.hip -- the optional --ed_thr prefilter on the device.
+//
+// Reference: MonomersAligner::FilterMonomersForRead / MonomerEditDistance
+// (stringdecomposer/src/main.cpp:128-149): per chunk, the infix ("HW") edit distance of every
+// template against the chunk (there via vendored edlib), templates ordered by (distance, index),
+// the first one and every other one with distance <= ed_thr kept IN THAT ORDER -- the order
+// matters because AlignPartClassicDP breaks score ties towards the first template of its list.
+//
+//  sd_hw_dist    one thread per (chunk, template): Myers' bit-vector algorithm (J. ACM 46(3), 1999)
+//                in its block form (Hyyro 2003) for patterns of up to 256 symbols, search variant
+//                (free leading / trailing text), minimum of the bottom-row score over all columns.
+//  sd_rank_keep  one thread per (chunk, template): kept? + rank inside the filtered order; writes the
+//                per-chunk lane constants the ranked fill kernels use (end offsets of dropped
+//                templates become -inf, ties between template ends go to the smallest rank).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "sd_device.hpp"
+#include "sd_fast.hpp"
+
+namespace sd {
+
+__global__ __launch_bounds__(256) void sd_hw_dist(const ChunkDesc* __restrict__ chunks, int n_chunks,
+                                                  int T, const uint32_t* __restrict__ bases2,
+                                                  const uint32_t* __restrict__ nmask,
+                                                  const unsigned long long* __restrict__ peq,
+                                                  const int32_t* __restrict__ tlen,
+                                                  int32_t* __restrict__ dist) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)n_chunks * T) return;
+    const int c = (int)(g / T), j = (int)(g % T);
+    const ChunkDesc cd = chunks[c];
+    const int m = tlen[j];
+    const int W = (m + 63) >> 6;
+    const unsigned long long* pq = peq + (size_t)j * 20;  // [5 symbols][4 words]
+    const unsigned long long lastBit = 1ull << ((m - 1) & 63);
+    unsigned long long Pv[4], Mv[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { Pv[b] = ~0ull; Mv[b] = 0ull; }
+    int score = m, best = m;
+    const uint32_t* w = bases2 + cd.woff;
+    const uint32_t* nm = cd.noff >= 0 ? nmask + cd.noff : nullptr;
+    uint32_t wb = 0, nb = 0;
+    for (int i = 0; i < cd.n; ++i) {
+        if ((i & 15) == 0) wb = w[i >> 4];
+        int r = (wb >> (2 * (i & 15))) & 3;
+        if (nm) {
+            if ((i & 31) == 0) nb = nm[i >> 5];
+            if ((nb >> (i & 31)) & 1) r = 4;
+        }
+        int hin = 0;  // search variant: the row above the pattern costs nothing
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b < W) {
+                unsigned long long Eq = pq[r * 4 + b];
+                const unsigned long long pv = Pv[b], mv = Mv[b];
+                const unsigned long long Xv = Eq | mv;
+                if (hin < 0) Eq |= 1ull;
+                const unsigned long long Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+                unsigned long long Ph = mv | ~(Xh | pv);
+                unsigned long long Mh = pv & Xh;
+                const unsigned long long top = (b == W - 1) ? lastBit : (1ull << 63);
+                int hout = 0;
+                if (Ph & top) hout = 1;
+                if (Mh & top) hout = -1;
+                Ph <<= 1;
+                Mh <<= 1;
+                if (hin < 0) Mh |= 1ull;
+                if (hin > 0) Ph |= 1ull;
+                Pv[b] = Mh | ~(Xv | Ph);
+                Mv[b] = Ph & Xv;
+                hin = hout;
+            }
+        }
+        score += hin;  // vertical delta of the pattern's last row
+        best = min(best, score);
+    }
+    dist[(size_t)c * T + j] = best;
+}
+
+// endoff / rank arrays: [chunk][64 lanes] dwords, packed {lo plane, hi plane} int16
+__global__ void sd_rank_keep(int n_chunks, int T, int ed_thr, const int32_t* __restrict__ dist,
+                             const int32_t* __restrict__ end_vlane, const int32_t* __restrict__ end_off,
+                             uint16_t* __restrict__ cendoff, uint16_t* __restrict__ crank) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)n_chunks * T) return;
+    const int c = (int)(g / T), j = (int)(g % T);
+    const int32_t* d = dist + (size_t)c * T;
+    const int dj = d[j];
+    // first = smallest (distance, index); kept = first or distance <= ed_thr (main.cpp:141-147)
+    int first = 0;
+    for (int i = 1; i < T; ++i)
+        if (d[i] < d[first]) first = i;
+    const bool kept = j == first || dj <= ed_thr;
+    int rank = 0;
+    for (int i = 0; i < T; ++i) {
+        const bool ki = i == first || d[i] <= ed_thr;
+        if (ki && (d[i] < dj || (d[i] == dj && i < j))) ++rank;
+    }
+    const int v = end_vlane[j];  // virtual lane holding the template's end
+    const size_t at = ((size_t)c * 64 + (v & 63)) * 2 + (v >> 6);
+    cendoff[at] = (uint16_t)(kept ? end_off[j] : -32768);
+    crank[at] = (uint16_t)(kept ? rank : 0x7fff);
+}
+
+__global__ void sd_fill_u32(uint32_t* p, size_t n, uint32_t v) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+void build_peq(const std::vector<std::string>& tseq, std::vector<unsigned long long>& peq) {
+    peq.assign(tseq.size() * 20, 0ull);
+    for (size_t j = 0; j < tseq.size(); ++j)
+        for (size_t k = 0; k < tseq[j].size() && k < 256; ++k) {
+            int code;
+            switch (tseq[j][k]) {
+                case 'A': code = 0; break;
+                case 'C': code = 1; break;
+                case 'G': code = 2; break;
+                case 'T': code = 3; break;
+                default: code = 4; break;
+            }
+            peq[j * 20 + (size_t)code * 4 + (k >> 6)] |= 1ull << (k & 63);
+        }
+}
+
+void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, int T, int ed_thr,
+                         const uint32_t* bases2, const uint32_t* nmask, const unsigned long long* peq,
+                         const int32_t* tlen, const int32_t* end_vlane, const int32_t* end_off,
+                         int32_t* dist, uint32_t* cendoff, uint32_t* crank) {
+    const long long total = (long long)n_chunks * T;
+    const int grid = (int)((total + 255) / 256);
+    const size_t words = (size_t)n_chunks * 64;
+    hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, cendoff, words, 0x80008000u);
+    hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, crank, words, 0x7fff7fffu);
+    hipLaunchKernelGGL(sd_hw_dist, dim3(grid), dim3(256), 0, st, chunks, n_chunks, T, bases2, nmask, peq, tlen, dist);
+    hipLaunchKernelGGL(sd_rank_keep, dim3(grid), dim3(256), 0, st, n_chunks, T, ed_thr, dist, end_vlane, end_off,
+                       reinterpret_cast<uint16_t*>(cendoff), reinterpret_cast<uint16_t*>(crank));
+}
+
+}  // namespace sd

@@ -21,16 +21,21 @@ FAMILIES = [("generic", lib.KERNEL_GENERIC), ("fast", lib.KERNEL_FAST)]
 def _decompose_case(c, kernel, tmp_path):
     sc = tuple(c["scoring"]) if c["scoring"] else (-1, -1, -1, 1)
     out = str(tmp_path / "raw.tsv")
+    ed = -1 if c["ed_thr"] is None else c["ed_thr"]
+    if ed > -1:
+        sc = (-1, -1, -1, 1)  # the reference ignores the scores in its 10-argument (--ed_thr) form
     lib.decompose_files(c["reads"], c["monomers"], out, scoring=sc, part_size=c["part"],
-                        overlap=c["overlap"], kernel=kernel)
+                        overlap=c["overlap"], kernel=kernel, ed_thr=ed)
     with open(out, "rb") as f:
         return f.read()
 
 
 @pytest.mark.parametrize("fam", FAMILIES, ids=[f[0] for f in FAMILIES])
-@pytest.mark.parametrize("name", case_names())
+@pytest.mark.parametrize("name", case_names(include_edthr=True))
 def test_golden_fixture_raw_tsv(name, fam, tmp_path):
     c = load_case(name)
+    if c["ed_thr"] is not None and fam[0] == "generic":
+        pytest.skip("--ed_thr runs on the fast family only")
     try:
         got = _decompose_case(c, fam[1], tmp_path)
     except lib.SdError as e:
@@ -187,6 +192,23 @@ def test_64_monomer_set_wide_layout(oracle):
         res[name] = e.fetch()
         e.close()
     assert res["fast"] == res["generic"]
+
+
+@pytest.mark.parametrize("thr", [0, 8, 25, 60])
+def test_ed_thr_prefilter_vs_oracle(oracle, thr):
+    """--ed_thr (main.cpp:128-149): per-chunk infix edit distances, kept set and its order
+    (which decides score ties) against the oracle, on reads with N and a custom scoring."""
+    mn, ms = synth.make_monomers(12, seed=41)
+    rn, rs = synth.make_reads(ms, 3, read_len=11000, seed=42)
+    b = bytearray(rs[1])
+    for pos in synth.Stream(42, 7).below(300, len(b)):
+        b[int(pos)] = ord("N")
+    rs[1] = bytes(b)
+    rs[2] = rs[2][:777]
+    for sc in [(-1, -1, -1, 1), (-2, -3, -4, 2)]:
+        got = lib.decompose(rn, rs, mn, ms, scoring=sc, ed_thr=thr)
+        exp = oracle.decompose(rn, rs, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc, ed_thr=thr)
+        assert got == exp
 
 
 def test_device_batching_is_invisible():

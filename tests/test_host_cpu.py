@@ -43,9 +43,6 @@ def test_no_cpu_fallback_without_device():
 def test_param_validation_is_host_side():
     mn, ms = synth.make_monomers(2, seed=1)
     with pytest.raises(lib.SdError) as e:
-        lib.Engine(ms, ed_thr=10)
-    assert e.value.code == lib.SD_ERR_UNSUPPORTED
-    with pytest.raises(lib.SdError) as e:
         lib.Engine(ms, part_size=0)
     assert e.value.code == lib.SD_ERR_PARAM
     with pytest.raises(lib.SdError) as e:
