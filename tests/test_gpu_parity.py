@@ -7,6 +7,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 from conftest import GOLDEN, ROOT, case_names, load_case
@@ -209,6 +210,59 @@ def test_ed_thr_prefilter_vs_oracle(oracle, thr):
         got = lib.decompose(rn, rs, mn, ms, scoring=sc, ed_thr=thr)
         exp = oracle.decompose(rn, rs, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc, ed_thr=thr)
         assert got == exp
+
+
+def _random_monomers(st, n, lo, hi, with_n=False):
+    """n related monomers (a common ancestor, 15 % substitutions) with lengths in [lo, hi]."""
+    anc = st.below(hi + 16, 4)
+    out = []
+    for j in range(n):
+        L = lo + int(st.below(1, hi - lo + 1)[0])
+        codes = synth.mutate(anc, st, 0.15, 0.02, 0.02)
+        while len(codes) < L:
+            codes = np.concatenate([codes, st.below(L, 4)])
+        m = bytearray(synth._to_ascii(codes[:L]))
+        if with_n and j % 3 == 0 and L > 2:
+            m[L // 2] = ord("N")
+        out.append(bytes(m))
+    return out
+
+
+SHAPES = [  # (monomers, min len, max len, N in templates)
+    (1, 8, 12, False), (2, 30, 60, False), (3, 100, 130, True), (5, 160, 186, False),
+    (12, 165, 176, True), (20, 90, 110, False), (31, 60, 64, False), (40, 120, 176, False),
+    (64, 167, 176, False), (64, 200, 224, False), (7, 230, 250, False), (9, 2, 40, False),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=["%dx%d-%d%s" % (a, b, c, "N" if d else "") for a, b, c, d in SHAPES])
+def test_random_template_set_shapes_vs_oracle(oracle, shape):
+    """Layout corner cases of the kernel families (slots per lane, virtual lanes per template,
+    narrow / wide / generic, N in templates) on random template sets, every record against the
+    oracle.  Reads are random concatenations of mutated templates plus junk and N."""
+    nm, lo, hi, with_n = shape
+    st = synth.Stream(1234, nm * 1000 + lo)
+    ms = _random_monomers(st, nm, lo, hi, with_n)
+    mn = ["m%d" % j for j in range(nm)]
+    reads = []
+    for r in range(3):
+        parts = []
+        while sum(len(x) for x in parts) < 700 + 150 * r:
+            j = int(st.below(1, nm)[0])
+            codes = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8),
+                                    np.frombuffer(ms[j].replace(b"N", b"A"), dtype=np.uint8))
+            x = synth._to_ascii(synth.mutate(codes, st, 0.05, 0.03, 0.03))
+            parts.append(synth.revcomp_bytes(x) if st.below(1, 2)[0] else x)
+            if st.below(1, 4)[0] == 0:
+                parts.append(synth._to_ascii(st.below(int(st.below(1, 40)[0]) + 1, 4)))
+        b = bytearray(b"".join(parts))
+        b[len(b) // 3] = ord("N")
+        reads.append(bytes(b))
+    rn = ["r%d" % i for i in range(len(reads))]
+    for sc, part, ov in [((-1, -1, -1, 1), 5000, 500), ((-2, -3, -4, 2), 300, 50), ((-1, -2, -1, 3), 5000, 500)]:
+        got = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov)
+        exp = oracle.decompose(rn, reads, mn, ms, threads=8, sc=sc, part=part, overlap=ov)
+        assert got == exp, (shape, sc)
 
 
 def test_device_batching_is_invisible():
