@@ -225,9 +225,11 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
     DevRec* __restrict__ recs, int32_t* __restrict__ rec_cnt, int* __restrict__ queue,
     const int* __restrict__ order) {
     __shared__ uint8_t pt_all[4][FAST_R][64];
+    __shared__ int32_t mt_all[4][5][64][4];  // (mm - del) of the lane's cells for the 5 read symbols
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     uint8_t(*pt)[64] = pt_all[wave];
+    int32_t(*mt)[64][4] = mt_all[wave];
     ChunkSched sched;
     sched.init(queue, order, n_chunks);
     for (int c = sched.next(); c >= 0; c = sched.next()) {
@@ -259,6 +261,8 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
             const int k = lane * QK + q;
             code[q] = k < Lj ? (int)tcodes[x0 + k] : 7;
             slot[q] = k < Lj ? (int)slot_of[x0 + k] : 0;
+#pragma unroll
+            for (int b = 0; b < 5; ++b) mt[b][lane][q] = code[q] == b ? mD : xD;
         }
         int i = e, k = Lj - 1;
         bool stop_row0 = false;
@@ -315,9 +319,11 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
                 const int32_t pdEdge = lane_up_neg(E[QK - 1]);
                 int32_t loc[QK], w[QK], dg[QK];
                 int32_t run = NEG_INF32, pd = pdEdge;
+                const int4 mrow = *reinterpret_cast<const int4*>(mt[r][lane]);
+                const int32_t mm4[4] = {mrow.x, mrow.y, mrow.z, mrow.w};
 #pragma unroll
                 for (int q = 0; q < QK; ++q) {
-                    const int32_t mmd = code[q] == r ? mD : xD;
+                    const int32_t mmd = mm4[q];
                     const int32_t v = max(pd, Bd) + mmd;     // start / diag (lane 0: pd = -inf)
                     dg[q] = pd + mmd;
                     w[q] = E[q] + ins;
