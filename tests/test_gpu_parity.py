@@ -294,3 +294,33 @@ def test_cli_end_to_end_reference_golden(tmp_path):
         assert f.read() == g.read()
     with open(os.path.join(out, "final_decomposition_raw.tsv"), "rb") as f:
         assert f.read() == load_case("td_default")["raw"]
+
+
+def test_cli_scoring_ref_compat_and_ed_thr(tmp_path, oracle):
+    """CLI flags: -s is honoured (documented difference), --ref-compat reproduces the reference
+    CLI (scores ignored), --ed_thr is passed through; light mode writes an empty _alt.tsv."""
+    mn, ms = synth.make_monomers(12, seed=51)
+    rn, rs = synth.make_reads(ms, 2, read_len=6000, seed=52)
+    rf, mf = str(tmp_path / "r.fa"), str(tmp_path / "m.fa")
+    synth.write_fasta(rf, rn, rs, width=70)
+    synth.write_fasta(mf, mn, ms)
+
+    def run(extra, name):
+        out = str(tmp_path / name)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "stringdecomposer"), rf, mf, "-o", out,
+                            "-t", "4"] + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert p.returncode == 0, p.stdout.decode()
+        with open(os.path.join(out, "final_decomposition_raw.tsv"), "rb") as f:
+            raw = f.read()
+        assert os.path.getsize(os.path.join(out, "final_decomposition_alt.tsv")) == 0
+        with open(os.path.join(out, "final_decomposition.tsv")) as f:
+            final = f.read().splitlines()
+        assert len(final) == raw.count(b"\n") and all(len(l.split("\t")) == 12 for l in final)
+        return raw
+
+    sc = (-2, -3, -4, 2)
+    assert run(["--scoring=-2,-3,-4,2"], "a") == oracle.decompose(rn, rs, mn, ms, threads=8, sc=sc)
+    default = oracle.decompose(rn, rs, mn, ms, threads=8)
+    assert run(["--scoring=-2,-3,-4,2", "--ref-compat"], "b") == default
+    assert run(["--ed_thr", "12"], "c") == oracle.decompose(rn, rs, mn, ms, threads=8, ed_thr=12)
+    assert run(["-b", "700", "-v", "100"], "d") == oracle.decompose(rn, rs, mn, ms, threads=8, part=700, overlap=100)
