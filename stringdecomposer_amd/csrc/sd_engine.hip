@@ -45,18 +45,23 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         n = 0;
+        cap = 0;
     }
+    size_t cap = 0;  // allocated elements (grow-only: batches of similar size reuse the buffer)
     void alloc(size_t count) {
-        free_();
         if (count == 0) count = 1;
-        SD_HIP(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+        if (count > cap) {
+            free_();
+            SD_HIP(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+            cap = count;
+        }
         n = count;
     }
     void upload(const std::vector<T>& h) {
         alloc(h.size());
         if (!h.empty()) SD_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     }
-    size_t bytes() const { return n * sizeof(T); }
+    size_t bytes() const { return cap * sizeof(T); }
     ~DevBuf() { free_(); }
 };
 
@@ -616,11 +621,20 @@ int sd_engine_info(sd_engine* e, int64_t info[8]) {
 // -------------------------------------------------------------------------------------------
 // one-shot entry points
 // -------------------------------------------------------------------------------------------
-static int decompose_impl(const std::vector<sd::Seq>& reads, const std::vector<sd::Seq>& monos,
+namespace {
+struct ReadView {  // borrowed for the duration of the call
+    const char* name;
+    size_t name_len;
+    const char* seq;
+    int64_t len;
+};
+}  // namespace
+
+static int decompose_impl(const std::vector<ReadView>& reads, const std::vector<sd::Seq>& monos,
                           const sd_params* p, std::string& tsv, std::string& err) {
     if (monos.empty()) { err = "no monomers"; return SD_ERR_PARAM; }
-    for (const sd::Seq& r : reads)
-        if (r.seq.empty()) { err = "ERROR: Sequence " + r.name + " is empty"; return SD_ERR_EMPTY; }
+    for (const ReadView& r : reads)
+        if (r.len <= 0) { err = "ERROR: Sequence " + std::string(r.name, r.name_len) + " is empty"; return SD_ERR_EMPTY; }
     std::vector<const char*> mseq;
     std::vector<int32_t> mlen;
     std::vector<std::string> tnames;
@@ -640,9 +654,11 @@ static int decompose_impl(const std::vector<sd::Seq>& reads, const std::vector<s
     std::vector<CRef> table;
     std::vector<int32_t> nch(reads.size(), 0);
     for (size_t r = 0; r < reads.size(); ++r)
-        nch[r] = sd::chunk_plan((int64_t)reads[r].seq.size(), p->part_size, p->overlap,
+        nch[r] = sd::chunk_plan(reads[r].len, p->part_size, p->overlap,
                                 [&](int64_t off, int32_t l) { table.push_back(CRef{(int32_t)r, off, l}); });
-    int64_t row_budget = (int64_t)768 << 20;
+    // default: batches of <= 96 M rows (1.7 k reads of 50 kb): large enough to fill the GPU many times
+    // over, small enough that the next batch reuses the same buffers and little HBM is touched
+    int64_t row_budget = (int64_t)96 << 20;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -664,7 +680,7 @@ static int decompose_impl(const std::vector<sd::Seq>& reads, const std::vector<s
         std::vector<const char*> cptr;
         std::vector<int32_t> clen;
         for (size_t c = c0; c < c1; ++c) {
-            cptr.push_back(reads[(size_t)table[c].read].seq.data() + table[c].off);
+            cptr.push_back(reads[(size_t)table[c].read].seq + table[c].off);
             clen.push_back(table[c].len);
         }
         rc = load_chunks_impl(eng, cptr, clen, eb, sizeof eb);
@@ -694,8 +710,8 @@ static int decompose_impl(const std::vector<sd::Seq>& reads, const std::vector<s
             std::vector<std::string> parts(done_ids.size());
             sd::parallel_for((int64_t)done_ids.size(), p->threads, 4, [&](int64_t q) {
                 sd::seam_merge(done_rows[(size_t)q]);
-                const sd::Seq& rd = reads[done_ids[(size_t)q]];
-                sd::format_rows(parts[(size_t)q], rd.name.data(), rd.name.size(), tnames,
+                const ReadView& rd = reads[done_ids[(size_t)q]];
+                sd::format_rows(parts[(size_t)q], rd.name, rd.name_len, tnames,
                                 done_rows[(size_t)q].data(), done_rows[(size_t)q].size());
             });
             for (const std::string& part : parts) tsv += part;
@@ -716,12 +732,23 @@ int sd_decompose(const char* const* read_names, const char* const* read_seqs,
     *tsv = nullptr;
     *tsv_len = 0;
     std::string err;
-    std::vector<sd::Seq> reads((size_t)std::max(n_reads, 0)), monos((size_t)std::max(n_mono, 0));
-    for (int32_t r = 0; r < n_reads; ++r) {
-        reads[(size_t)r].name = read_names[r];
-        reads[(size_t)r].seq.assign(read_seqs[r], (size_t)read_lens[r]);
-        int rc = sd::check_alphabet(read_names[r], read_seqs[r], read_lens[r], err);
-        if (rc) { set_err(errbuf, errlen, err); return rc; }
+    std::vector<ReadView> reads((size_t)std::max(n_reads, 0));
+    std::vector<sd::Seq> monos((size_t)std::max(n_mono, 0));
+    {
+        // alphabet check of all reads on the host threads; the first offending read (in input
+        // order) is reported, as load_fasta does (main.cpp:329-341)
+        std::vector<int> bad((size_t)std::max(n_reads, 0), 0);
+        sd::parallel_for(n_reads, p ? p->threads : 1, 8, [&](int64_t r) {
+            reads[(size_t)r] = ReadView{read_names[r], std::strlen(read_names[r]), read_seqs[r], read_lens[r]};
+            std::string e2;
+            bad[(size_t)r] = sd::check_alphabet(read_names[r], read_seqs[r], read_lens[r], e2) != SD_OK;
+        });
+        for (int32_t r = 0; r < n_reads; ++r)
+            if (bad[(size_t)r]) {
+                int rc = sd::check_alphabet(read_names[r], read_seqs[r], read_lens[r], err);
+                set_err(errbuf, errlen, err);
+                return rc;
+            }
     }
     for (int32_t m = 0; m < n_mono; ++m) {
         monos[(size_t)m].name = mono_names[m];
@@ -752,7 +779,10 @@ int sd_decompose_files(const char* reads_fa, const char* monomers_fa, const sd_p
     rc = sd::load_fasta(monomers_fa, monos, hn, err);    // main.cpp:395
     if (rc) { set_err(errbuf, errlen, err); return rc; }
     std::string out;
-    rc = decompose_impl(reads, monos, p, out, err);
+    std::vector<ReadView> views;
+    views.reserve(reads.size());
+    for (const sd::Seq& r : reads) views.push_back(ReadView{r.name.data(), r.name.size(), r.seq.data(), (int64_t)r.seq.size()});
+    rc = decompose_impl(views, monos, p, out, err);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
     FILE* fp = std::fopen(raw_tsv_out, "wb");
     if (!fp) { set_err(errbuf, errlen, std::string("cannot write ") + raw_tsv_out); return SD_ERR_IO; }
