@@ -656,37 +656,58 @@ static int decompose_impl(const std::vector<ReadView>& reads, const std::vector<
     for (size_t r = 0; r < reads.size(); ++r)
         nch[r] = sd::chunk_plan(reads[r].len, p->part_size, p->overlap,
                                 [&](int64_t off, int32_t l) { table.push_back(CRef{(int32_t)r, off, l}); });
-    // default: batches of <= 96 M rows (1.7 k reads of 50 kb): large enough to fill the GPU many times
-    // over, small enough that the next batch reuses the same buffers and little HBM is touched
-    int64_t row_budget = (int64_t)96 << 20;
+    // default: batches of <= 48 M rows (~900 reads of 50 kb): large enough to fill the GPU twice over,
+    // small enough that the host/device pipeline below has stages to overlap and buffers are reused
+    int64_t row_budget = (int64_t)48 << 20;
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             // per row: B + argB + records (24 B) + fast-family checkpoints (P*256 B every FAST_R rows)
             const double per_row = 26.0 + (eng->family == 2 ? eng->fplan.P * 256.0 / sd::FAST_R : 0.0);
-            row_budget = std::min<int64_t>(row_budget, (int64_t)(0.55 * (double)free_b / per_row));
+            row_budget = std::min<int64_t>(row_budget, (int64_t)(0.27 * (double)free_b / per_row));
             row_budget = std::max<int64_t>(row_budget, (int64_t)p->part_size + p->overlap);
         }
         if (p->max_batch_rows > 0) row_budget = p->max_batch_rows;  // explicit cap (tests, small GPUs)
     }
-    std::vector<sd_rec> batch_rows;      // records of the read being assembled
-    size_t next_read = 0;                // first read not yet written
-    int32_t chunks_seen_of_read = 0;
-    size_t c0 = 0;
-    while (c0 < table.size() && rc == SD_OK) {
+    // Two engines on two non-blocking streams form a software pipeline: while the device works on
+    // batch b, the host packs + uploads batch b+1 and enqueues it, then fetches and formats batch b.
+    sd_engine* eng2 = nullptr;
+    hipStream_t streams[2] = {nullptr, nullptr};
+    std::vector<std::pair<size_t, size_t>> batches;
+    for (size_t c0 = 0; c0 < table.size();) {
         int64_t rows = 0;
         size_t c1 = c0;
         while (c1 < table.size() && (c1 == c0 || rows + table[c1].len <= row_budget)) rows += table[c1++].len;
+        batches.emplace_back(c0, c1);
+        c0 = c1;
+    }
+    if (batches.size() > 1) {
+        rc = sd_engine_create(&eng2, p, mseq.data(), mlen.data(), (int32_t)monos.size(), eb, sizeof eb);
+        if (rc) { err = eb; sd_engine_destroy(eng); return rc; }
+        for (hipStream_t& st : streams)
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+    }
+    sd_engine* engs[2] = {eng, eng2 ? eng2 : eng};
+    auto submit = [&](size_t b) -> int {
         std::vector<const char*> cptr;
         std::vector<int32_t> clen;
-        for (size_t c = c0; c < c1; ++c) {
+        for (size_t c = batches[b].first; c < batches[b].second; ++c) {
             cptr.push_back(reads[(size_t)table[c].read].seq + table[c].off);
             clen.push_back(table[c].len);
         }
-        rc = load_chunks_impl(eng, cptr, clen, eb, sizeof eb);
-        if (rc == SD_OK) rc = sd_engine_run(eng, nullptr, eb, sizeof eb);
+        int r2 = load_chunks_impl(engs[b & 1], cptr, clen, eb, sizeof eb);
+        if (r2 == SD_OK) r2 = sd_engine_run(engs[b & 1], streams[b & 1], eb, sizeof eb);
+        return r2;
+    };
+    std::vector<sd_rec> batch_rows;      // records of the read being assembled
+    size_t next_read = 0;                // first read not yet written
+    int32_t chunks_seen_of_read = 0;
+    if (!batches.empty()) rc = submit(0);
+    for (size_t b = 0; b < batches.size() && rc == SD_OK; ++b) {
+        if (b + 1 < batches.size()) rc = submit(b + 1);
+        const size_t c0 = batches[b].first, c1 = batches[b].second;
         sd_rec* recs = nullptr; int64_t* roff = nullptr;
-        if (rc == SD_OK) rc = sd_engine_fetch(eng, &recs, &roff, eb, sizeof eb);
+        if (rc == SD_OK) rc = sd_engine_fetch(engs[b & 1], &recs, &roff, eb, sizeof eb);
         if (rc == SD_OK) {
             // per-read assembly (main.cpp:104-117); reads complete in input order
             std::vector<std::vector<sd_rec>> done_rows;
@@ -717,8 +738,11 @@ static int decompose_impl(const std::vector<ReadView>& reads, const std::vector<
             for (const std::string& part : parts) tsv += part;
         }
         std::free(recs); std::free(roff);
-        c0 = c1;
     }
+    if (rc != SD_OK) (void)hipDeviceSynchronize();  // nothing may still be running on buffers we free
+    for (hipStream_t st : streams)
+        if (st) (void)hipStreamDestroy(st);
+    if (eng2) sd_engine_destroy(eng2);
     if (rc) err = eb;
     sd_engine_destroy(eng);
     return rc;
