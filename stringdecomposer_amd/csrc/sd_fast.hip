@@ -3,22 +3,22 @@
 // Replaces AlignPartClassicDP (reference stringdecomposer/src/main.cpp:151-270) for scorings and
 // template sets that fit the packed-int16 lane layout described in sd_fast.hpp.
 //
-//  sd_fast_fill   one wave per chunk.  Row-synchronous sweep (rows are strictly sequential because
-//                 B_i = max_j dp[i-1][j][L_j-1] feeds every cell of row i, main.cpp:184-193); all
-//                 template cells of a row are processed two per VALU lane-op with v_pk_*_i16, in
-//                 the shifted domain E = D - k*del where the in-row deletion chain is a prefix
-//                 maximum (see sd_generic.hip header).  Per cell pair: 5 packed ops
-//                     u = max(E'[x-1], max(K, B+del));  v = u + (mm-del);  w = E'[x] + ins;
-//                     cand = max(v, w);  run = max(run, cand)
-//                 The cross-lane carry K of the chain is applied lazily (true E = max(local, K)).
-//                 The (mm - del) table of all templates lives in LDS, indexed by the read base.
-//                 Written to HBM per row: B_i and the arg-max virtual lane (8 bytes); every
-//                 FAST_R rows a checkpoint of the row (values relative to a moving base).
+//  sd_fast_fill   persistent waves, one chunk per wave at a time (atomic chunk queue).  Row-synchronous
+//                 sweep (rows are strictly sequential because B_i = max_j dp[i-1][j][L_j-1] feeds
+//                 every cell of row i, main.cpp:184-193); all template cells of a row are processed
+//                 two per VALU lane-op with v_pk_*_i16, in the domain S = D - k*del - base - tp*ins
+//                 where the in-row deletion chain is a prefix maximum and the insertion move is
+//                 "keep" (see the comment above the kernel).  Per cell pair: 4 packed ops
+//                     u = max(S[x-1], KB);  v = u + tbl;  c = max(v, S[x]);  run = max(run, c)
+//                 The cross-lane carry K of the chain is applied lazily (true value = max(local, K)).
+//                 The (mm - del - ins) table of all templates lives in LDS, indexed by the read base.
+//                 Written to HBM per row: one word (B_i << 7 | arg-max virtual lane); every FAST_R
+//                 rows a checkpoint of the row (values relative to a moving base).
 //                 No per-cell back-pointers are stored: the traceback recomputes them.
-//  sd_fast_trace  one wave per chunk.  Walks the reference's traceback (main.cpp:217-269); for
-//                 every monomer instance it recomputes only that template's cells, block by block
-//                 from the checkpoints, derives the reference's priority-encoded moves
-//                 (DEL > INS > DIAG > START) into LDS and follows them.
+//  sd_fast_trace  persistent waves, one chunk per wave at a time.  Walks the reference's traceback
+//                 (main.cpp:217-269); for every monomer instance it recomputes only that
+//                 template's cells, block by block from the checkpoints, derives the reference's
+//                 priority-encoded moves (DEL > INS > DIAG > START) into LDS and follows them.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
