@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <type_traits>
 
 #include "sd_fast.hpp"
 #include "sd_fast_dev.hpp"
@@ -224,12 +225,14 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
     const uint32_t* __restrict__ ckpt, const int32_t* __restrict__ ckbase,
     DevRec* __restrict__ recs, int32_t* __restrict__ rec_cnt, int* __restrict__ queue,
     const int* __restrict__ order) {
-    __shared__ uint8_t pt_all[4][FAST_R][64];
-    __shared__ int32_t mt_all[4][5][64][4];  // (mm - del) of the lane's cells for the 5 read symbols
+    constexpr int QP = QK <= 4 ? 4 : 8;       // cells per lane rounded up to whole int4 loads
+    using pt_t = std::conditional_t<(QK <= 4), uint8_t, uint16_t>;
+    __shared__ pt_t pt_all[4][FAST_R][64];      // 2-bit moves of the lane's cells
+    __shared__ int32_t mt_all[4][5][64][QP];    // (mm - del) of the lane's cells for the 5 read symbols
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    uint8_t(*pt)[64] = pt_all[wave];
-    int32_t(*mt)[64][4] = mt_all[wave];
+    pt_t(*pt)[64] = pt_all[wave];
+    int32_t(*mt)[64][QP] = mt_all[wave];
     ChunkSched sched;
     sched.init(queue, order, n_chunks);
     for (int c = sched.next(); c >= 0; c = sched.next()) {
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
                     left = Ef;
                     E[q] = Ef;
                 }
-                pt[0][lane] = (uint8_t)bits;
+                pt[0][lane] = (pt_t)bits;
                 rstart = 1;
             } else {
                 const int q0 = a / FAST_R - 1;
@@ -319,8 +322,12 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
                 const int32_t pdEdge = lane_up_neg(E[QK - 1]);
                 int32_t loc[QK], w[QK], dg[QK];
                 int32_t run = NEG_INF32, pd = pdEdge;
-                const int4 mrow = *reinterpret_cast<const int4*>(mt[r][lane]);
-                const int32_t mm4[4] = {mrow.x, mrow.y, mrow.z, mrow.w};
+                int32_t mm4[QP];
+#pragma unroll
+                for (int h = 0; h < QP / 4; ++h) {
+                    const int4 mrow = *reinterpret_cast<const int4*>(&mt[r][lane][4 * h]);
+                    mm4[4 * h + 0] = mrow.x; mm4[4 * h + 1] = mrow.y; mm4[4 * h + 2] = mrow.z; mm4[4 * h + 3] = mrow.w;
+                }
 #pragma unroll
                 for (int q = 0; q < QK; ++q) {
                     const int32_t mmd = mm4[q];
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
                     left = Ef;
                     E[q] = Ef;
                 }
-                pt[r_i - a][lane] = (uint8_t)bits;
+                pt[r_i - a][lane] = (pt_t)bits;
             }
             // walk inside the block (wave-uniform)
             bool done = false;
@@ -406,7 +413,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     auto ab = [](int v) { return v < 0 ? -v : v; };
     const int maxabs = std::max(std::max(ab(sc.ins), ab(sc.del)), std::max(ab(sc.mismatch), ab(sc.match)));
     if ((int64_t)(3 * Lmax + 2 * FAST_REBASE + 4) * maxabs > 8000) { why = "scores too large for int16 cells"; return false; }
-    if (Lmax > 64 * 4) { why = "template longer than 256 bp"; return false; }
+    if (Lmax > 64 * 8) { why = "template longer than 512 bp"; return false; }
 
     int P = 0, split = 0;
     for (int p : FAST_P_LIST) {
@@ -437,6 +444,8 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     plan.split = split;
     plan.Lmax = Lmax;
     plan.Qk = (Lmax + 63) / 64;
+    if (plan.Qk == 5) plan.Qk = 6;
+    if (plan.Qk == 7) plan.Qk = 8;
     plan.vlane0.assign((size_t)T, 0);
     int Vmax = 1;
     {
@@ -611,7 +620,9 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
         case 1: SD_TRACE(1); break;
         case 2: SD_TRACE(2); break;
         case 3: SD_TRACE(3); break;
-        default: SD_TRACE(4); break;
+        case 4: SD_TRACE(4); break;
+        case 6: SD_TRACE(6); break;
+        default: SD_TRACE(8); break;
     }
 #undef SD_TRACE
 }

@@ -232,6 +232,7 @@ SHAPES = [  # (monomers, min len, max len, N in templates)
     (1, 8, 12, False), (2, 30, 60, False), (3, 100, 130, True), (5, 160, 186, False),
     (12, 165, 176, True), (20, 90, 110, False), (31, 60, 64, False), (40, 120, 176, False),
     (64, 167, 176, False), (64, 200, 224, False), (7, 230, 250, False), (9, 2, 40, False),
+    (6, 300, 400, False), (3, 480, 512, True), (2, 513, 600, False),
 ]
 
 
