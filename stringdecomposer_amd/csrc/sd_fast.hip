@@ -42,7 +42,7 @@ namespace sd {
 #define SD_FILL_NW 8   // waves (= chunks) per workgroup; two workgroups per CU
 #endif
 template <int P, bool RANKED>
-__global__ __launch_bounds__(SD_FILL_NW * 64, SD_FILL_NW / 2) void sd_fast_fill(
+__global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int H, int32_t* __restrict__ Bout,
@@ -572,7 +572,7 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
                       uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order, int n_cu,
                       const uint32_t* cendoff, const uint32_t* crank) {
     const int NW = SD_FILL_NW;
-    const int grid = std::min((n_chunks + NW - 1) / NW, 2 * n_cu);  // persistent: 2 workgroups per CU
+    const int grid = std::min((n_chunks + NW - 1) / NW, (16 / NW) * n_cu);  // persistent: 16 waves per CU
     (void)hipMemsetAsync(queue, 0, sizeof(int), st);
     if (plan.wide) {
         launch_fast_fill_wide(plan, st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt,
