@@ -7,7 +7,7 @@
 // matters because AlignPartClassicDP breaks score ties towards the first template of its list.
 //
 //  sd_hw_dist    one thread per (chunk, template): Myers' bit-vector algorithm (J. ACM 46(3), 1999)
-//                in its block form (Hyyro 2003) for patterns of up to 256 symbols, search variant
+//                in its block form (Hyyro 2003) for patterns of up to 512 symbols, search variant
 //                (free leading / trailing text), minimum of the bottom-row score over all columns.
 //  sd_rank_keep  one thread per (chunk, template): kept? + rank inside the filtered order; writes the
 //                per-chunk lane constants the ranked fill kernels use (end offsets of dropped
@@ -35,11 +35,11 @@ __global__ __launch_bounds__(256) void sd_hw_dist(const ChunkDesc* __restrict__ 
     const ChunkDesc cd = chunks[c];
     const int m = tlen[j];
     const int W = (m + 63) >> 6;
-    const unsigned long long* pq = peq + (size_t)j * 20;  // [5 symbols][4 words]
+    const unsigned long long* pq = peq + (size_t)j * 40;  // [5 symbols][8 words]
     const unsigned long long lastBit = 1ull << ((m - 1) & 63);
-    unsigned long long Pv[4], Mv[4];
+    unsigned long long Pv[8], Mv[8];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) { Pv[b] = ~0ull; Mv[b] = 0ull; }
+    for (int b = 0; b < 8; ++b) { Pv[b] = ~0ull; Mv[b] = 0ull; }
     int score = m, best = m;
     const uint32_t* w = bases2 + cd.woff;
     const uint32_t* nm = cd.noff >= 0 ? nmask + cd.noff : nullptr;
@@ -53,9 +53,9 @@ __global__ __launch_bounds__(256) void sd_hw_dist(const ChunkDesc* __restrict__ 
         }
         int hin = 0;  // search variant: the row above the pattern costs nothing
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < 8; ++b) {
             if (b < W) {
-                unsigned long long Eq = pq[r * 4 + b];
+                unsigned long long Eq = pq[r * 8 + b];
                 const unsigned long long pv = Pv[b], mv = Mv[b];
                 const unsigned long long Xv = Eq | mv;
                 if (hin < 0) Eq |= 1ull;
@@ -112,9 +112,9 @@ __global__ void sd_fill_u32(uint32_t* p, size_t n, uint32_t v) {
 }
 
 void build_peq(const std::vector<std::string>& tseq, std::vector<unsigned long long>& peq) {
-    peq.assign(tseq.size() * 20, 0ull);
+    peq.assign(tseq.size() * 40, 0ull);
     for (size_t j = 0; j < tseq.size(); ++j)
-        for (size_t k = 0; k < tseq[j].size() && k < 256; ++k) {
+        for (size_t k = 0; k < tseq[j].size() && k < 512; ++k) {
             int code;
             switch (tseq[j][k]) {
                 case 'A': code = 0; break;
@@ -123,7 +123,7 @@ void build_peq(const std::vector<std::string>& tseq, std::vector<unsigned long l
                 case 'T': code = 3; break;
                 default: code = 4; break;
             }
-            peq[j * 20 + (size_t)code * 4 + (k >> 6)] |= 1ull << (k & 63);
+            peq[j * 40 + (size_t)code * 8 + (k >> 6)] |= 1ull << (k & 63);
         }
 }
 

@@ -260,10 +260,15 @@ def test_random_template_set_shapes_vs_oracle(oracle, shape):
         b[len(b) // 3] = ord("N")
         reads.append(bytes(b))
     rn = ["r%d" % i for i in range(len(reads))]
-    for sc, part, ov in [((-1, -1, -1, 1), 5000, 500), ((-2, -3, -4, 2), 300, 50), ((-1, -2, -1, 3), 5000, 500)]:
-        got = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov)
-        exp = oracle.decompose(rn, reads, mn, ms, threads=8, sc=sc, part=part, overlap=ov)
-        assert got == exp, (shape, sc)
+    for sc, part, ov, ed in [((-1, -1, -1, 1), 5000, 500, -1), ((-2, -3, -4, 2), 300, 50, -1),
+                             ((-1, -2, -1, 3), 5000, 500, -1), ((-1, -1, -1, 1), 700, 100, 30)]:
+        try:
+            got = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed)
+        except lib.SdError as e:
+            assert ed > -1 and e.code == lib.SD_ERR_UNSUPPORTED  # --ed_thr outside the fast family
+            continue
+        exp = oracle.decompose(rn, reads, mn, ms, threads=8, sc=sc, part=part, overlap=ov, ed_thr=ed)
+        assert got == exp, (shape, sc, ed)
 
 
 def test_device_batching_is_invisible():

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign (developer tool, needs a GPU): random template sets, scorings,
+chunk sizes, N densities and --ed_thr values through libsd_hip vs the CPU oracle.
+usage: python tools/fuzz_gpu.py [cases] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from stringdecomposer_amd import lib, synth
+from oracle import binding as oracle
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+st = synth.Stream(seed, 99)
+ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def rnd(k):
+    return int(st.below(1, k)[0])
+
+
+def monomers(n, lo, hi, pn):
+    anc = st.below(hi + 16, 4)
+    out = []
+    for j in range(n):
+        L = lo + rnd(hi - lo + 1)
+        codes = synth.mutate(anc, st, 0.05 + 0.2 * st.uniform(1)[0], 0.02, 0.02)
+        while len(codes) < L:
+            codes = np.concatenate([codes, st.below(L, 4)])
+        m = bytearray(synth._to_ascii(codes[:L]))
+        if st.uniform(1)[0] < pn and L > 2:
+            m[rnd(L)] = ord("N")
+        out.append(bytes(m))
+    return out
+
+
+bad = 0
+t0 = time.time()
+fam = {"fast": 0, "generic": 0}
+for case in range(cases):
+    shape = [(1, 5, 40), (3, 20, 90), (6, 100, 200), (12, 160, 180), (25, 150, 190), (50, 100, 180),
+             (64, 165, 178), (4, 300, 500), (2, 1, 30), (10, 60, 64)][rnd(10)]
+    nm = max(1, shape[0] - rnd(2))
+    ms = monomers(nm, shape[1], shape[2], 0.15 if rnd(3) == 0 else 0.0)
+    mn = ["m%d" % j for j in range(nm)]
+    sc = [(-1, -1, -1, 1), (-2, -3, -4, 2), (-1, -2, -1, 1), (0, 0, 0, 1), (-3, -1, -2, 3), (-5, -1, -3, 4),
+          (-1, -1, -2, 2), (-2, -2, -1, 1), (-9, -7, -8, 9)][rnd(9)]
+    part, ov = [(5000, 500), (700, 100), (333, 77), (150, 20), (5000, 0)][rnd(5)]
+    reads = []
+    for r in range(1 + rnd(3)):
+        parts, tot, want = [], 0, 50 + rnd(1500)
+        while tot < want:
+            j = rnd(nm)
+            codes = np.searchsorted(ACGT, np.frombuffer(ms[j].replace(b"N", b"C"), dtype=np.uint8))
+            x = synth._to_ascii(synth.mutate(codes, st, 0.08 * st.uniform(1)[0], 0.04 * st.uniform(1)[0], 0.04 * st.uniform(1)[0])) or b"A"
+            if rnd(2):
+                x = synth.revcomp_bytes(x)
+            parts.append(x)
+            if rnd(5) == 0:
+                parts.append(synth._to_ascii(st.below(1 + rnd(60), 4)))
+            tot = sum(len(p) for p in parts)
+        b = bytearray(b"".join(parts))
+        if rnd(3) == 0:
+            for p in st.below(1 + rnd(20), len(b)):
+                b[int(p)] = ord("N")
+        reads.append(bytes(b))
+    rn = ["r%d" % i for i in range(len(reads))]
+    ed = -1 if rnd(3) else rnd(80)
+    try:
+        got = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed, threads=4)
+    except lib.SdError as e:
+        if e.code == lib.SD_ERR_UNSUPPORTED:
+            continue
+        raise
+    exp = oracle.decompose(rn, reads, mn, ms, threads=32, sc=sc, part=part, overlap=ov, ed_thr=ed)
+    if got != exp:
+        bad += 1
+        print("MISMATCH case", case, "shape", shape, nm, [len(m) for m in ms][:8], sc, part, ov, "ed", ed, flush=True)
+        d = os.path.join(ROOT, "gpurun_out", "fuzz_fail_%d_%d" % (seed, case))
+        os.makedirs(d, exist_ok=True)
+        synth.write_fasta(os.path.join(d, "r.fa"), rn, reads)
+        synth.write_fasta(os.path.join(d, "m.fa"), mn, ms)
+        open(os.path.join(d, "params.txt"), "w").write(repr((sc, part, ov, ed)))
+print("fuzz: %d cases, %d mismatches, %.1fs" % (cases, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
