@@ -44,11 +44,12 @@ for case in range(cases):
     ms = monomers(nm, shape[1], shape[2], 0.15 if rnd(3) == 0 else 0.0)
     mn = ["m%d" % j for j in range(nm)]
     sc = [(-1, -1, -1, 1), (-2, -3, -4, 2), (-1, -2, -1, 1), (0, 0, 0, 1), (-3, -1, -2, 3), (-5, -1, -3, 4),
-          (-1, -1, -2, 2), (-2, -2, -1, 1), (-9, -7, -8, 9)][rnd(9)]
+          (-1, -1, -2, 2), (-2, -2, -1, 1), (-9, -7, -8, 9), (-1, -1, 2, 1), (-1, 0, -1, 1), (0, -1, -1, 1),
+          (-1, -1, -1, -1), (-4, -4, 3, 3)][rnd(14)]
     part, ov = [(5000, 500), (700, 100), (333, 77), (150, 20), (5000, 0)][rnd(5)]
     reads = []
     for r in range(1 + rnd(3)):
-        parts, tot, want = [], 0, 50 + rnd(1500)
+        parts, tot, want = [], 0, [50 + rnd(1500), 1 + rnd(40), 3000 + rnd(4000)][rnd(3) if rnd(4) else 0]
         while tot < want:
             j = rnd(nm)
             codes = np.searchsorted(ACGT, np.frombuffer(ms[j].replace(b"N", b"C"), dtype=np.uint8))
@@ -67,7 +68,8 @@ for case in range(cases):
     rn = ["r%d" % i for i in range(len(reads))]
     ed = -1 if rnd(3) else rnd(80)
     try:
-        got = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed, threads=4)
+        got = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed,
+                            threads=1 + rnd(6), max_batch_rows=[0, 0, 200, 1500][rnd(4)])
     except lib.SdError as e:
         if e.code == lib.SD_ERR_UNSUPPORTED:
             continue
