@@ -29,7 +29,7 @@ EXPORTS = [
     "sd_decompose", "sd_engine_create", "sd_engine_destroy", "sd_engine_load_reads",
     "sd_engine_run", "sd_engine_fetch", "sd_engine_assemble", "sd_engine_timings",
     "sd_engine_info", "sd_chunk_plan", "sd_seam_merge", "sd_format_rows", "sd_fasta_load",
-    "sd_fasta_free", "sd_nw_identity_batch",
+    "sd_fasta_free", "sd_nw_identity_batch", "sd_identity_segments",
 ]
 
 
@@ -100,6 +100,9 @@ def load():
     L.sd_fasta_free.argtypes = [P(Fasta)]
     L.sd_nw_identity_batch.argtypes = [P(C.c_char_p), P(C.c_int32), P(C.c_char_p), P(C.c_int32),
                                        C.c_int64, C.c_int32, P(C.c_int32), P(C.c_int32), P(C.c_int32)]
+    L.sd_identity_segments.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                       P(C.c_char_p), P(C.c_int32), C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -323,3 +326,26 @@ def nw_identity_batch(queries, targets, threads=1):
     if rc != SD_OK:
         raise SdError(rc, "sd_nw_identity_batch")
     return [(d[i], m[i], c[i]) for i in range(n)]
+
+
+def identity_segments(seq, starts, ends, templates, homo=False, threads=1):
+    """(dist, matches, columns) int32 arrays of shape [n_segments, n_templates]: every segment
+    seq[starts[s] .. ends[s]] (inclusive) against every template (main.py:107-150 all-vs-all)."""
+    import numpy as np
+    L = load()
+    sb = _b(seq)
+    st = np.ascontiguousarray(starts, dtype=np.int64)
+    en = np.ascontiguousarray(ends, dtype=np.int64)
+    n = int(st.shape[0])
+    tb = [_b(t) for t in templates]
+    T = len(tb)
+    tl = (C.c_int32 * max(T, 1))(*[len(t) for t in tb])
+    d = np.zeros((n, T), dtype=np.int32)
+    m = np.zeros((n, T), dtype=np.int32)
+    c = np.zeros((n, T), dtype=np.int32)
+    rc = L.sd_identity_segments(sb, len(sb), st.ctypes.data, en.ctypes.data, n, _strs(tb), tl, T,
+                                1 if homo else 0, threads, d.ctypes.data, m.ctypes.data,
+                                c.ctypes.data)
+    if rc != SD_OK:
+        raise SdError(rc, "sd_identity_segments")
+    return d, m, c

@@ -138,23 +138,31 @@ def aai_batch(pairs, threads):
     return out
 
 
-def classify(reads_mapping, coef):
-    """main.py:95-104 (pandas DataFrame.dot == numpy dot over [1, score, score - second_best])."""
-    if not reads_mapping:
-        return reads_mapping
-    s = np.array([float(r["score"]) for r in reads_mapping], dtype=np.float64)
-    s2 = np.array([float(r["second_best_score"]) for r in reads_mapping], dtype=np.float64)
+def _identity_percent(dist, matches, cols):
+    """main.py:38-60 on arrays: 0 for an empty side (edist -1), else '=' columns / CIGAR columns * 100."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a = matches.astype(np.float64) / cols
+        a = a * 100
+    return np.where(dist == -1, 0.0, a)
+
+
+def classify(score, second_best_score, coef):
+    """main.py:95-104 (pandas DataFrame.dot == numpy dot over [1, score, score - second_best]):
+    True where the block keeps '+', False where it becomes '?'."""
+    s = np.asarray(score, dtype=np.float64)
+    s2 = np.asarray(second_best_score, dtype=np.float64)
+    if s.size == 0:
+        return np.zeros(0, dtype=bool)
     X = np.stack([np.ones_like(s), s, s - s2], axis=1)
-    y = X.dot(np.array(coef, dtype=np.float64)) > 0
-    for i, r in enumerate(reads_mapping):
-        if not y[i]:
-            r["q"] = "?"
-    return reads_mapping
+    return X.dot(np.array(coef, dtype=np.float64)) > 0
 
 
 def convert_read(decomposition, read, monomers, light, threads, coef):
-    """main.py:107-150."""
+    """main.py:107-150.  Returns the list of per-block dicts of the reference (scores as floats)."""
     res = []
+    n = len(decomposition)
+    if n == 0:
+        return res
     if light:
         by_name = {}
         for m in monomers:
@@ -168,53 +176,73 @@ def convert_read(decomposition, read, monomers, light, threads, coef):
                         "homo_second_best": "None", "homo_second_best_score": -1,
                         "alt": {}, "q": "+"})
     else:
-        homo_m = [convert_to_homo(m.seq) for m in monomers]
-        pairs = []
-        for d in decomposition:
-            seg = read.seq[d["start"]:d["end"] + 1]
-            hseg = convert_to_homo(seg)
-            for m in monomers:
-                pairs.append((seg, m.seq))
-            for hm in homo_m:
-                pairs.append((hseg, hm))
-        vals = aai_batch(pairs, threads)
-        T = len(monomers)
+        starts = np.array([d["start"] for d in decomposition], dtype=np.int64)
+        ends = np.array([d["end"] for d in decomposition], dtype=np.int64)
+        seqs = [m.seq for m in monomers]
+        names = [m.name for m in monomers]
+        vals = _identity_percent(*lib.identity_segments(read.seq, starts, ends, seqs, False, threads))
+        hvals = _identity_percent(*lib.identity_segments(read.seq, starts, ends, seqs, True, threads))
+        # scores is a dict keyed by monomer name in the reference: a repeated name keeps its first
+        # position and its last value
+        first, last = {}, {}
+        for x, nm in enumerate(names):
+            first.setdefault(nm, x)
+            last[nm] = x
+        keys = list(first)
+        kcol = np.array([last[k] for k in keys], dtype=np.int64)
+        kvals = vals[:, kcol]                                  # [n, len(keys)] in dict order
+        own = np.array([keys.index(d["m"]) if d["m"] in first else -1 for d in decomposition])
+        if (own < 0).any():
+            raise KeyError(decomposition[int(np.argmax(own < 0))]["m"])
+        rows = np.arange(n)
+        masked = kvals.copy()
+        masked[rows, own] = -np.inf
+        sb = np.argmax(masked, axis=1) if len(keys) > 1 else np.full(n, -1)   # first maximum
+        horder = np.argsort(-hvals, axis=1, kind="stable")
         for i, d in enumerate(decomposition):
-            base = i * 2 * T
-            scores = {}
-            for x, m in enumerate(monomers):
-                scores[m.name] = vals[base + x]
-            monomer = d["m"]
-            secondbest, secondbest_score = None, -1
-            for m in scores:
-                if m != monomer:
-                    if not secondbest or secondbest_score < scores[m]:
-                        secondbest, secondbest_score = m, scores[m]
-            homo_scores = [[m.name, vals[base + T + x]] for x, m in enumerate(monomers)]
-            homo_scores = sorted(homo_scores, key=lambda x: -x[1])
-            res.append({"m": monomer, "start": str(d["start"]), "end": str(d["end"]),
-                        "score": scores[monomer],
+            if len(keys) > 1 and keys[sb[i]] != "":
+                secondbest, secondbest_score = keys[sb[i]], float(masked[i, sb[i]])
+            else:  # `not secondbest` quirk of main.py:127 for an empty name / single key
+                secondbest, secondbest_score = None, -1
+                for kx, m in enumerate(keys):
+                    if kx != own[i]:
+                        if not secondbest or secondbest_score < kvals[i, kx]:
+                            secondbest, secondbest_score = m, float(kvals[i, kx])
+            h0, h1 = int(horder[i, 0]), int(horder[i, 1])
+            res.append({"m": d["m"], "start": str(d["start"]), "end": str(d["end"]),
+                        "score": float(kvals[i, own[i]]),
                         "second_best": str(secondbest), "second_best_score": secondbest_score,
-                        "homo_best": homo_scores[0][0], "homo_best_score": homo_scores[0][1],
-                        "homo_second_best": homo_scores[1][0], "homo_second_best_score": homo_scores[1][1],
-                        "alt": scores, "q": "+"})
-    return classify(res, coef)
+                        "homo_best": names[h0], "homo_best_score": float(hvals[i, h0]),
+                        "homo_second_best": names[h1], "homo_second_best_score": float(hvals[i, h1]),
+                        "alt": (keys, kvals[i]), "q": "+"})
+    keep = classify([r["score"] for r in res], [r["second_best_score"] for r in res], coef)
+    for r, k in zip(res, keep):
+        if not k:
+            r["q"] = "?"
+    return res
 
 
 def print_read(fout, fout_alt, dec, read, monomers, identity_th, light, threads, coef):
     """main.py:153-165."""
     dec = convert_read(dec, read, monomers, light, threads, coef)
+    f2 = "{:.2f}".format
+    out, out_alt = [], []
     for d in dec:
         if d["score"] >= identity_th:
-            fout.write("\t".join([read.name, d["m"], d["start"], d["end"], "{:.2f}".format(d["score"]),
-                                  d["second_best"], "{:.2f}".format(d["second_best_score"]),
-                                  d["homo_best"], "{:.2f}".format(d["homo_best_score"]),
-                                  d["homo_second_best"], "{:.2f}".format(d["homo_second_best_score"]),
+            out.append("\t".join([read.name, d["m"], d["start"], d["end"], f2(d["score"]),
+                                  d["second_best"], f2(d["second_best_score"]),
+                                  d["homo_best"], f2(d["homo_best_score"]),
+                                  d["homo_second_best"], f2(d["homo_second_best_score"]),
                                   d["q"]]) + "\n")
-            for a in d["alt"]:
-                star = "*" if a == d["m"] else "-"
-                fout_alt.write("\t".join([read.name, a, d["start"], d["end"],
-                                          "{:.2f}".format(d["alt"][a]), star]) + "\n")
+            if d["alt"]:
+                keys, row = d["alt"]
+                head = read.name + "\t"
+                tail = "\t" + d["start"] + "\t" + d["end"] + "\t"
+                own = d["m"]
+                for a, v in zip(keys, row.tolist()):
+                    out_alt.append(head + a + tail + f2(v) + ("\t*\n" if a == own else "\t-\n"))
+    fout.write("".join(out))
+    fout_alt.write("".join(out_alt))
 
 
 def convert_tsv(decomposition, reads, monomers, outfile, identity_th, light, threads=1):

@@ -132,6 +132,12 @@ def test_nw_identity_matches_oracle_and_edlib(oracle):
         ts.append(t)
     qs += [b"", b"ACGT", b"A" * 700, b"ACGT" * 40]
     ts += [b"ACGT", b"", b"A" * 170, b"TGCA" * 40]
+    # bit-vector word boundaries, N symbols, a symbol outside ACGTN (full-matrix path), long pairs
+    for L in (1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 1000):
+        a = synth._ACGT[st.below(L, 4)].tobytes()
+        b = synth._ACGT[st.below(L + 3, 4)].tobytes()
+        qs += [a, a, a[:-1] + b"N", a[: L // 2] + b"R" + a[L // 2:]]
+        ts += [b, a, a, a]
     got = lib.nw_identity_batch(qs, ts, threads=3)
     for q, t, g in zip(qs, ts, got):
         assert g == oracle.nw_identity(q, t), (q, t)
@@ -172,9 +178,65 @@ def test_final_tsv_postprocessing_reproduces_reference_golden(tmp_path):
     sdmain.convert_tsv(c["raw"].decode(), reads, mons, out, 0, False, threads=4)
     with open(out, "rb") as f, open(os.path.join(td, "final_decomposition_fc89af8.tsv"), "rb") as g:
         assert f.read() == g.read()
+    # the _alt file (main.py:161-165): one row per block x monomer, recomputed here with the oracle's NW
+    oracle_b = __import__("oracle.binding", fromlist=["x"])
+    with open(out[:-4] + "_alt.tsv") as f:
+        alt = [ln.rstrip("\n").split("\t") for ln in f]
+    with open(out) as f:
+        main_rows = [ln.rstrip("\n").split("\t") for ln in f]
+    assert len(alt) == len(main_rows) * len(mons)
+    rseq = next(iter(reads.values())).seq
+    for bi in (0, 1, len(main_rows) // 2, len(main_rows) - 1):
+        row = main_rows[bi]
+        for x, m in enumerate(mons):
+            a = alt[bi * len(mons) + x]
+            ed, mt, cols = oracle_b.nw_identity(rseq[int(row[2]):int(row[3]) + 1], m.seq)
+            assert a[:4] == [row[0], m.name, row[2], row[3]]
+            assert a[4] == "{:.2f}".format(mt / cols * 100)
+            assert a[5] == ("*" if m.name == row[1] else "-")
     # light mode: sha recorded from the unmodified reference CLI
     sdmain.convert_tsv(c["raw"].decode(), reads, mons, out, 0, True, threads=2)
     with open(out, "rb") as f:
         assert hashlib.sha256(f.read()).hexdigest() == \
             "de9d4cc554051d842022f0a75db18a7d4ce7b3aa97af9cadc6ef960c7ea8ee85"
     assert os.path.getsize(out[:-4] + "_alt.tsv") == 0
+
+
+def test_convert_read_dict_semantics_with_repeated_names(oracle):
+    """main.py:118-146 keeps per-name dicts: a repeated monomer name keeps its first position and
+    last value; second best = first maximum among the other names; homo list is a stable sort."""
+    st = synth.Stream(5, 77)
+    base = synth._ACGT[st.below(60, 4)].tobytes().decode()
+    def mut(sq, k):
+        b = list(sq)
+        for p in st.below(k, len(b)):
+            b[int(p)] = "ACGT"[int(st.below(1, 4)[0])]
+        return "".join(b)
+    mons = [sdmain.Record("a", mut(base, 3)), sdmain.Record("b", mut(base, 6)),
+            sdmain.Record("a", mut(base, 9)), sdmain.Record("c", mut(base, 6))]
+    mons = sdmain.add_rc_monomers(mons)
+    read = sdmain.Record("r", "".join(mut(base, 5) for _ in range(6)))
+    dec = [{"m": ["a", "b", "c", "a'", "b", "c"][i], "start": 60 * i, "end": 60 * i + 59} for i in range(6)]
+    got = sdmain.convert_read(dec, read, mons, False, 2, sdmain._lr_coef())
+
+    def ident(q, t):
+        ed, m, c = oracle.nw_identity(q, t)
+        return 0 if ed == -1 else m / c * 100
+
+    for d, g in zip(dec, got):
+        seg = read.seq[d["start"]:d["end"] + 1]
+        scores = {}
+        for m in mons:
+            scores[m.name] = ident(seg, m.seq)
+        sb, sbs = None, -1
+        for m in scores:
+            if m != d["m"]:
+                if not sb or sbs < scores[m]:
+                    sb, sbs = m, scores[m]
+        hs = sorted([[m.name, ident(sdmain.convert_to_homo(seg), sdmain.convert_to_homo(m.seq))]
+                     for m in mons], key=lambda x: -x[1])
+        assert g["score"] == scores[d["m"]] and g["second_best"] == str(sb) and g["second_best_score"] == sbs
+        assert [g["homo_best"], g["homo_best_score"]] == hs[0]
+        assert [g["homo_second_best"], g["homo_second_best_score"]] == hs[1]
+        keys, row = g["alt"]
+        assert list(keys) == list(scores) and row.tolist() == [scores[k] for k in keys]
