@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <type_traits>
 
 #include "sd_fast.hpp"
@@ -41,7 +42,77 @@ namespace sd {
 #ifndef SD_FILL_NW
 #define SD_FILL_NW 8   // waves (= chunks) per workgroup; two workgroups per CU
 #endif
-template <int P, bool RANKED>
+//
+// F16 variant: the same recurrence on packed fp16 (every value is an integer of magnitude < 2048,
+// hence exact; -inf is the padding / "no predecessor" value).  gfx950 has v_pk_maximum3_f16, which
+// folds the last two maxima:  u = max(S[x-1], KB);  v = u + tbl;  S_new[x] = max3(S_new[x-1], v, S[x])
+// -- 3 packed ops per cell pair instead of 4.  fast_plan_build() enables it when the score range
+// fits (FastPlan::f16); the checkpoints then hold fp16 pairs (the traceback converts them).
+template <bool F16>
+struct CellOps {
+    static constexpr uint32_t NEG = F16 ? 0xFC00FC00u : NEG2;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ uint32_t mx(uint32_t a, uint32_t b) {
+        if constexpr (F16) {
+            return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_bit_cast(h2, a),
+                                                                              __builtin_bit_cast(h2, b)));
+        } else {
+            return pk_max(a, b);
+        }
+    }
+    static __device__ __forceinline__ uint32_t mx3(uint32_t a, uint32_t b, uint32_t c) {
+        return __builtin_bit_cast(
+            uint32_t, __builtin_elementwise_maximum(
+                          __builtin_elementwise_maximum(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b)),
+                          __builtin_bit_cast(h2, c)));
+    }
+    static __device__ __forceinline__ uint32_t add(uint32_t a, uint32_t b) {
+        if constexpr (F16) {
+            return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, a) + __builtin_bit_cast(h2, b));
+        } else {
+            return pk_adds(a, b);
+        }
+    }
+    static __device__ __forceinline__ uint32_t sub(uint32_t a, uint32_t b) {
+        if constexpr (F16) return add(a, b ^ 0x80008000u);
+        else return pk_subs(a, b);
+    }
+    // {x, x}
+    static __device__ __forceinline__ uint32_t splat(int x) {
+        if constexpr (F16) {
+            const float f = (float)x;
+            return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(f, f));
+        } else {
+            return pack2(x);
+        }
+    }
+    // host-built packed int16 constant -> cell format (anything <= -30000 is "-inf")
+    static __device__ __forceinline__ uint32_t from_i16x2(uint32_t w) {
+        if constexpr (F16) {
+            const int lo = (int)(short)(w & 0xffffu), hi = (int)w >> 16;
+            const float fl = lo <= -30000 ? -__builtin_inff() : (float)lo;
+            const float fh = hi <= -30000 ? -__builtin_inff() : (float)hi;
+            return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(fl, fh));
+        } else {
+            return w;
+        }
+    }
+    // the two cells of a word as (saturated) integers
+    static __device__ __forceinline__ void to_int(uint32_t w, int& lo, int& hi) {
+        if constexpr (F16) {
+            uint32_t a, b;
+            asm("v_cvt_i16_f16_e32 %0, %1" : "=v"(a) : "v"(w));
+            asm("v_cvt_i16_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(b) : "v"(w));
+            lo = (int)(short)(a & 0xffffu);
+            hi = (int)(short)(b & 0xffffu);
+        } else {
+            lo = (int)(short)(w & 0xffffu);
+            hi = (int)w >> 16;
+        }
+    }
+};
+
+template <int P, bool RANKED, bool F16>
 __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
@@ -52,8 +123,16 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     constexpr int P4 = (P + 3) & ~3;
     extern __shared__ uint32_t lds[];  // [5][P4/4][64][4]
     constexpr int TBL = 5 * P4 * 64;
-    for (int idx = threadIdx.x * 4; idx < TBL; idx += blockDim.x * 4)
-        *reinterpret_cast<uint4*>(&lds[idx]) = *reinterpret_cast<const uint4*>(&table[idx]);
+    using CO = CellOps<F16>;
+    constexpr uint32_t NEGC = CO::NEG;
+    for (int idx = threadIdx.x * 4; idx < TBL; idx += blockDim.x * 4) {
+        uint4 q = *reinterpret_cast<const uint4*>(&table[idx]);
+        if constexpr (F16) {
+            q.x = CO::from_i16x2(q.x); q.y = CO::from_i16x2(q.y);
+            q.z = CO::from_i16x2(q.z); q.w = CO::from_i16x2(q.w);
+        }
+        *reinterpret_cast<uint4*>(&lds[idx]) = q;
+    }
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -74,10 +153,10 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     const uint32_t cont2Mask = lc[FLC_CONT2];
     const uint32_t endOffPlan = lc[FLC_ENDOFF];
     // --ed_thr: per-chunk end offsets (-inf for dropped templates) and tie-break ranks
-    const uint32_t endOff = RANKED ? cendoff[(size_t)c * 64 + lane] : endOffPlan;
+    const uint32_t endOff = CO::from_i16x2(RANKED ? cendoff[(size_t)c * 64 + lane] : endOffPlan);
     const uint32_t rank2 = RANKED ? crank[(size_t)c * 64 + lane] : 0u;
-    const uint32_t row0adj = lc[FLC_ROW0];
-    const uint32_t ins2 = pack2(sc.ins);
+    const uint32_t row0adj = CO::from_i16x2(lc[FLC_ROW0]);
+    const uint32_t ins2 = CO::splat(sc.ins);
 
     int32_t* Bc = Bout + cd.row0 + (uint64_t)c;
     uint32_t* ck = ckpt + (uint64_t)cd.pad * (uint64_t)(P * 64) + lane;
@@ -85,7 +164,7 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
 
     uint32_t L[P];
     uint32_t tb[P4];
-    uint32_t K = NEG2;
+    uint32_t K = NEGC;
     int base = 0, Brel = 0, tp = 0;
     int accBV = 0;  // (B << 7 | arg-max virtual lane) of the last <=64 rows, one row per lane
 
@@ -106,18 +185,18 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     auto excl_scan = [&](uint32_t a) {
         uint32_t inc = a;
         if (H == 3 || H == 4) {  // doubling: window of 4 previous lanes (masks keep it inside the template)
-            inc = pk_max(inc, bfi(contMask, lane_up(inc, 1), NEG2));
-            inc = pk_max(inc, bfi(cont2Mask, lane_up(lane_up(inc, 1), 1), NEG2));
+            inc = CO::mx(inc, bfi(contMask, lane_up(inc, 1), NEGC));
+            inc = CO::mx(inc, bfi(cont2Mask, lane_up(lane_up(inc, 1), 1), NEGC));
         } else {
-            for (int h = 1; h < H; ++h) inc = pk_max(a, bfi(contMask, lane_up(inc, 1), NEG2));
+            for (int h = 1; h < H; ++h) inc = CO::mx(a, bfi(contMask, lane_up(inc, 1), NEGC));
         }
-        return H > 0 ? bfi(contMask, lane_up(inc, 1), NEG2) : NEG2;
+        return H > 0 ? bfi(contMask, lane_up(inc, 1), NEGC) : NEGC;
     };
     // B_{row} (relative to base) = max over template ends; arg = smallest virtual lane attaining it
     auto reduce_ends = [&](uint32_t Eend, int row) {
-        const uint32_t val = pk_adds(Eend, endOff);
-        const int lo = (int)(short)(val & 0xffffu);
-        const int hi = (int)val >> 16;
+        const uint32_t val = CO::add(Eend, endOff);
+        int lo, hi;
+        CO::to_int(val, lo, hi);
         const int b = wave_max(max(lo, hi));
         unsigned long long mlo, mhi;
         if (RANKED) {
@@ -144,41 +223,67 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     uint32_t pin = 0;
     load_table(rs.code(0), pin);
     rs.advance(0);
-    L[0] = pk_adds(tb[0], row0adj);
+    L[0] = CO::add(tb[0], row0adj);
 #pragma unroll
-    for (int q = 1; q < P; ++q) L[q] = pk_max(L[q - 1], pk_adds(tb[q], ins2));
+    for (int q = 1; q < P; ++q) L[q] = CO::mx(L[q - 1], CO::add(tb[q], ins2));
     load_table(rs.code(1), L[P - 1]);
     rs.advance(1);
     K = excl_scan(L[P - 1]);
-    uint32_t Eend = pk_max(L[P - 1], K);
+    uint32_t Eend = CO::mx(L[P - 1], K);
     reduce_ends(Eend, 1);
 
     for (int i = 1; i < n; ++i) {
         if ((i & (FAST_R - 1)) == 0) {
             if ((i & (FAST_REBASE - 1)) == 0) {
                 // rebase the int16 state on B_i and fold the row offset tp*ins back in
-                const uint32_t d2 = pack2(Brel - tp * sc.ins);
+                const uint32_t d2 = CO::splat(F16 ? -(Brel - tp * sc.ins) : Brel - tp * sc.ins);
                 base += Brel;
                 Brel = 0;
                 tp = 0;
+                if constexpr (F16) {
+                    K = bfi(startMask, NEGC, CO::add(K, d2));
+                    Eend = CO::add(Eend, d2);
+#pragma unroll
+                    for (int s = 0; s < P; ++s) L[s] = CO::add(L[s], d2);
+                } else {
                 K = bfi(startMask, NEG2, pk_subs(K, d2));
                 Eend = pk_subs(Eend, d2);
 #pragma unroll
                 for (int s = 0; s < P; ++s) L[s] = pk_subs(L[s], d2);
+                }
             }
             // checkpoint the (true) row i-1 for the traceback: E = ckbase + stored value
             const int q = (i / FAST_R) - 1;
 #pragma unroll
-            for (int s = 0; s < P; ++s) ck[(uint64_t)q * (P * 64) + s * 64] = pk_max(L[s], K);
+            for (int s = 0; s < P; ++s) ck[(uint64_t)q * (P * 64) + s * 64] = CO::mx(L[s], K);
             if (lane == 0) ckb[q] = base + tp * sc.ins;
         }
-        const uint32_t KB = pk_max(K, pack2(Brel + sc.del - tp * sc.ins));
-        const uint32_t pd0 = bfi(startMask, NEG2, lane_up(Eend, 1));
-        const uint32_t w0 = bfi(startMask, NEG2, L[0]);
+        const uint32_t KB = CO::mx(K, CO::splat(Brel + sc.del - tp * sc.ins));
+        const uint32_t pd0 = bfi(startMask, NEGC, lane_up(Eend, 1));
+        const uint32_t w0 = bfi(startMask, NEGC, L[0]);
         uint32_t u_[P], v_[P], c_[P];
         uint32_t run = 0;
         // software-pipelined over the slots so that no packed op consumes the result of the
         // instruction right before it (gfx950 needs a wait state there)
+        if constexpr (F16) {
+#pragma unroll
+            for (int s = 0; s < P + 4; ++s) {
+                if (s >= 4) {
+                    const int q = s - 4;
+                    L[q] = q == 0 ? CO::mx(v_[0], w0) : CO::mx3(L[q - 1], v_[q], L[q]);
+                }
+                if (s >= 2 && s - 2 < P) {
+                    const int q = s - 2;
+                    v_[q] = CO::add(u_[q], tb[q]);
+                }
+                if (s < P) {
+                    const int q = s;
+                    u_[q] = CO::mx(q == 0 ? pd0 : L[q - 1], KB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            (void)c_; (void)run;
+        } else {
 #pragma unroll
         for (int s = 0; s < P + 3; ++s) {
             if (s >= 3) {
@@ -200,12 +305,13 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
         load_table(rs.code(i + 1), L[P - 1]);  // unconditional (clamped): keeps tb[] out of phi copies
         rs.advance(i + 1);
-        const uint32_t a = pk_max(L[P - 1], K);
+        const uint32_t a = CO::mx(L[P - 1], K);
         const uint32_t X = excl_scan(a);
-        K = pk_max(K, X);
-        Eend = pk_max(a, X);
+        K = CO::mx(K, X);
+        Eend = CO::mx(a, X);
         ++tp;
         reduce_ends(Eend, i + 1);
     }
@@ -224,7 +330,7 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
     const int32_t* __restrict__ B, const int32_t* __restrict__ argV,
     const uint32_t* __restrict__ ckpt, const int32_t* __restrict__ ckbase,
     DevRec* __restrict__ recs, int32_t* __restrict__ rec_cnt, int* __restrict__ queue,
-    const int* __restrict__ order) {
+    const int* __restrict__ order, int ckf16) {
     constexpr int QP = QK <= 4 ? 4 : 8;       // cells per lane rounded up to whole int4 loads
     using pt_t = std::conditional_t<(QK <= 4), uint8_t, uint16_t>;
     __shared__ pt_t pt_all[4][FAST_R][64];      // 2-bit moves of the lane's cells
@@ -307,7 +413,9 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
                 for (int q = 0; q < QK; ++q) {
                     const int v = slot[q] & 127, s = slot[q] >> 7;
                     const uint32_t wv = ckq[s * 64 + (v & 63)];
-                    E[q] = cb + ((v >> 6) ? ((int)wv >> 16) : (int)(short)(wv & 0xffffu));
+                    const uint32_t hw = (v >> 6) ? (wv >> 16) : (wv & 0xffffu);
+                    E[q] = cb + (ckf16 ? (int)(float)__builtin_bit_cast(_Float16, (unsigned short)hw)
+                                       : (int)(short)hw);
                 }
                 rstart = a;
             }
@@ -438,6 +546,21 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     }
 
     plan.wide = wide;
+    {
+        // fp16 cells are exact while every value stays an integer below 2048 in magnitude.  Between two
+        // rebases (FAST_REBASE rows) a cell, relative to the row maximum at the rebase, is bounded by
+        //   max(REBASE + 1, Lmax) * mpos   (at most one positive score per consumed read base)
+        // + Lmax * (|ins| + |del|)         (E = D - k*del, and insertions already paid inside an instance)
+        // + REBASE * |ins|                 (the per-row insertion credit of the stored form)
+        // plus a few single scores for the intermediate sums.
+        const int mpos = std::max(std::max(sc.match, sc.mismatch), 0);
+        const int64_t ub = (int64_t)std::max(FAST_REBASE + 1, Lmax) * mpos +
+                           (int64_t)Lmax * (ab(sc.ins) + ab(sc.del)) + (int64_t)FAST_REBASE * ab(sc.ins) +
+                           8 * (int64_t)maxabs + 8;
+        const char* force = getenv("SD_FILL_CELLS");  // "i16" / "f16": developer A/B switch
+        plan.f16 = !wide && ub <= 2040;
+        if (force && force[0] == 'i') plan.f16 = false;
+    }
     plan.P = P;
     plan.P4 = (P + 3) & ~3;
     plan.T = T;
@@ -581,17 +704,21 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
     }
     const size_t lds = (size_t)5 * plan.P4 * 64 * sizeof(uint32_t);
     const bool ranked = cendoff != nullptr;
-#define SD_FILL_K(PP, RK)                                                                            \
+#define SD_FILL_K(PP, RK, HF)                                                                        \
     {                                                                                                \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK>),              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, HF>),          \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-        hipLaunchKernelGGL((sd_fast_fill<PP, RK>), dim3(grid), dim3(NW * 64), lds, st, chunks,        \
+        hipLaunchKernelGGL((sd_fast_fill<PP, RK, HF>), dim3(grid), dim3(NW * 64), lds, st, chunks,    \
                            n_chunks, bases2, nmask, table, lane_consts, sc, plan.H, B, argV, ckpt,   \
                            ckbase, queue, order, cendoff, crank);                                    \
     }
 #define SD_FILL(PP)                                                                                  \
     case PP:                                                                                         \
-        if (ranked) SD_FILL_K(PP, true) else SD_FILL_K(PP, false)                                    \
+        if (plan.f16) {                                                                              \
+            if (ranked) SD_FILL_K(PP, true, true) else SD_FILL_K(PP, false, true)                    \
+        } else {                                                                                     \
+            if (ranked) SD_FILL_K(PP, true, false) else SD_FILL_K(PP, false, false)                  \
+        }                                                                                            \
         break;
     switch (plan.P) {
         SD_FILL(4) SD_FILL(8) SD_FILL(12) SD_FILL(16) SD_FILL(20) SD_FILL(24) SD_FILL(28) SD_FILL(30)
@@ -615,7 +742,7 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
 #define SD_TRACE(QQ)                                                                              \
     hipLaunchKernelGGL(sd_fast_trace<QQ>, dim3(grid), dim3(256), 0, st, chunks, n_chunks, bases2, \
                        nmask, slot_of, tcodes, lane_consts, toff, tlen, sc, plan.P, B, argV, ckpt, \
-                       ckbase, recs, rec_cnt, queue, order)
+                       ckbase, recs, rec_cnt, queue, order, plan.f16 ? 1 : 0)
     switch (plan.Qk) {
         case 1: SD_TRACE(1); break;
         case 2: SD_TRACE(2); break;

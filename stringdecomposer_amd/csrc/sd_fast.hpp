@@ -36,6 +36,7 @@ enum FastLaneConst {
 struct FastPlan {
     bool ok = false;
     bool wide = false;    // one template per virtual lane, int8 table streamed from LDS (P > 64)
+    bool f16 = false;     // narrow layout with packed-fp16 cells (3 ops per cell pair, v_pk_maximum3_f16)
     int P = 0;            // slots per virtual lane
     int P4 = 0;           // P rounded up to a multiple of 4 (LDS table row)
     int H = 0;            // carry hops of the cross-lane chain: Vmax-1

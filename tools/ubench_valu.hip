@@ -12,6 +12,24 @@ __device__ __forceinline__ unsigned pk_adds(unsigned a, unsigned b) {
     return __builtin_bit_cast(unsigned, __builtin_elementwise_add_sat(__builtin_bit_cast(s2, a), __builtin_bit_cast(s2, b)));
 }
 
+__device__ __forceinline__ unsigned pk_max3h(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_maxh(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ unsigned pk_addh(unsigned a, unsigned b) {
+    unsigned r;
+    asm("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// MODE 7: 8 independent v_pk_maximum3_f16; 8: one dependent v_pk_maximum3_f16 chain;
+// 9: 8 independent chains of pk_max_f16 / pk_add_f16 / pk_maximum3_f16 (the 3-op cell update)
 // MODE 0: 8 independent pk_max chains; 1: 8 independent i32 max chains; 2: one dependent pk_max chain
 // 3: 8 independent chains alternating pk_max / pk_add(clamp); 4: one dependent i32 chain
 // 5: 8 independent DPP row_shr max (i32); 6: ds_bpermute chain
@@ -42,6 +60,19 @@ __global__ void k(unsigned* out, int iters, unsigned seed) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
                     a[i] = (unsigned)max((int)a[i], __builtin_amdgcn_update_dpp(0, (int)a[i], 0x111, 0xf, 0xf, false));
+            } else if (MODE == 7) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = pk_max3h(a[i], b, a[(i + 1) & 7]);
+            } else if (MODE == 8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[0] = pk_max3h(a[0], b, a[1 + (i & 3)]);
+            } else if (MODE == 9) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned u = pk_maxh(a[i], b);
+                    const unsigned v = pk_addh(u, a[(i + 3) & 7]);
+                    a[i] = pk_max3h(a[(i + 1) & 7], v, a[i]);
+                }
             } else if (MODE == 6) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) a[0] = (unsigned)__shfl_up((int)a[0], 1) + i;
@@ -85,6 +116,9 @@ int main() {
         run<4>("max_i32 dependent", w);
         run<5>("max_i32 dpp row_shr indep", w);
         run<6>("ds_bpermute dependent", w);
+        run<7>("pk_maximum3_f16 indep x8", w);
+        run<8>("pk_maximum3_f16 dependent", w);
+        run<9>("f16 max/add/max3 (x3 ops)", w);
     }
     return 0;
 }
