@@ -520,7 +520,18 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     if (T > 65535) { why = "too many templates"; return false; }
     auto ab = [](int v) { return v < 0 ? -v : v; };
     const int maxabs = std::max(std::max(ab(sc.ins), ab(sc.del)), std::max(ab(sc.mismatch), ab(sc.match)));
-    if ((int64_t)(3 * Lmax + 2 * FAST_REBASE + 4) * maxabs > 8000) { why = "scores too large for int16 cells"; return false; }
+    // Range of a stored cell between two rebases (FAST_REBASE rows), relative to the row maximum at
+    // the rebase:
+    //   max(REBASE + 1, Lmax) * mpos   (at most one positive score per consumed read base)
+    // + Lmax * (|ins| + |del|)         (E = D - k*del, and insertions already paid inside an instance)
+    // + REBASE * |ins|                 (the per-row insertion credit of the stored form)
+    // plus a few single scores for the intermediate sums.  Real cells are never below
+    // -(Lmax + 2) * maxabs, so with ub <= 12000 the int16 "-inf" (-32768 + anything added) stays below them.
+    const int mpos = std::max(std::max(sc.match, sc.mismatch), 0);
+    const int64_t ub = (int64_t)std::max(FAST_REBASE + 1, Lmax) * mpos +
+                       (int64_t)Lmax * (ab(sc.ins) + ab(sc.del)) + (int64_t)FAST_REBASE * ab(sc.ins) +
+                       8 * (int64_t)maxabs + 8;
+    if (ub > 12000) { why = "scores too large for int16 cells"; return false; }
     if (Lmax > 64 * 8) { why = "template longer than 512 bp"; return false; }
 
     int P = 0, split = 0;
@@ -538,6 +549,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     if (P == 0) {
         // wide layout: one template per virtual lane
         if (T > 128) { why = "more than 128 templates"; return false; }
+        if ((int64_t)(3 * Lmax + 2 * FAST_REBASE + 4) * maxabs > 8000) { why = "scores too large for the wide layout"; return false; }
         for (int p : FAST_WIDE_P_LIST)
             if (p >= Lmax) { P = p; break; }
         if (P == 0) { why = "template longer than the widest layout"; return false; }
@@ -547,16 +559,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
 
     plan.wide = wide;
     {
-        // fp16 cells are exact while every value stays an integer below 2048 in magnitude.  Between two
-        // rebases (FAST_REBASE rows) a cell, relative to the row maximum at the rebase, is bounded by
-        //   max(REBASE + 1, Lmax) * mpos   (at most one positive score per consumed read base)
-        // + Lmax * (|ins| + |del|)         (E = D - k*del, and insertions already paid inside an instance)
-        // + REBASE * |ins|                 (the per-row insertion credit of the stored form)
-        // plus a few single scores for the intermediate sums.
-        const int mpos = std::max(std::max(sc.match, sc.mismatch), 0);
-        const int64_t ub = (int64_t)std::max(FAST_REBASE + 1, Lmax) * mpos +
-                           (int64_t)Lmax * (ab(sc.ins) + ab(sc.del)) + (int64_t)FAST_REBASE * ab(sc.ins) +
-                           8 * (int64_t)maxabs + 8;
+        // fp16 cells are exact while every value stays an integer below 2048 in magnitude
         const char* force = getenv("SD_FILL_CELLS");  // "i16" / "f16": developer A/B switch
         plan.f16 = !wide && ub <= 2040;
         if (force && force[0] == 'i') plan.f16 = false;

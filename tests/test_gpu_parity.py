@@ -155,6 +155,24 @@ def test_full_c2_size_families_agree():
     assert dig["fast"] == dig["generic"]
 
 
+@pytest.mark.parametrize("sc,cells", [((-2, -1, -3, 6), "f16"), ((-2, -2, -3, 7), "int16"),
+                                      ((-1, -1, -1, 1), "f16"), ((0, 0, -1, 11), "f16"), ((0, 0, -1, 12), "int16")])
+def test_fill_cell_format_switch_at_the_fp16_range_limit(oracle, sc, cells):
+    """The fill uses packed fp16 cells while the score range keeps every value an exact integer
+    (fast_plan_build), packed int16 beyond.  Scorings on both sides of the switch, on reads that
+    maximise score growth (exact repeats), insertions (unrelated sequence) and ordinary noise."""
+    mn, ms = synth.make_monomers(12, seed=3)
+    st = synth.Stream(3, 5)
+    rn, rs = synth.make_reads(ms, 2, read_len=12000, seed=4)
+    rs = list(rs) + [(ms[0] * 40)[:6100], synth._ACGT[st.below(5600, 4)].tobytes(), ms[5] * 3 + b"A" * 700 + ms[2] * 20]
+    rn = ["r%d" % i for i in range(len(rs))]
+    e = lib.Engine(ms, scoring=sc, kernel=lib.KERNEL_FAST)
+    assert e.info()["cells"] == cells
+    e.close()
+    got = lib.decompose(rn, rs, mn, ms, scoring=sc, kernel=lib.KERNEL_FAST)
+    assert got == oracle.decompose(rn, rs, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc)
+
+
 def test_single_long_sequence_custom_scoring_vs_oracle(oracle):
     """BASELINE config 5 in miniature: one long sequence (1.2 Mb -> 240 chunks), custom -s scoring
     (honoured, as by the reference binary in its 9-argument form), against the oracle."""

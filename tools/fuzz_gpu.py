@@ -46,6 +46,8 @@ for case in range(cases):
     sc = [(-1, -1, -1, 1), (-2, -3, -4, 2), (-1, -2, -1, 1), (0, 0, 0, 1), (-3, -1, -2, 3), (-5, -1, -3, 4),
           (-1, -1, -2, 2), (-2, -2, -1, 1), (-9, -7, -8, 9), (-1, -1, 2, 1), (-1, 0, -1, 1), (0, -1, -1, 1),
           (-1, -1, -1, -1), (-4, -4, 3, 3)][rnd(14)]
+    if rnd(3) == 0:   # random scorings: exercises both cell formats (fp16 / int16) around the range switch
+        sc = (-rnd(9), -rnd(9), rnd(13) - 8, rnd(13) - 2)
     part, ov = [(5000, 500), (700, 100), (333, 77), (150, 20), (5000, 0)][rnd(5)]
     reads = []
     for r in range(1 + rnd(3)):
@@ -60,6 +62,13 @@ for case in range(cases):
             if rnd(5) == 0:
                 parts.append(synth._to_ascii(st.below(1 + rnd(60), 4)))
             tot = sum(len(p) for p in parts)
+        kind = rnd(8)
+        if kind == 0:      # exact repeats: fastest score growth
+            parts = [ms[rnd(nm)].replace(b"N", b"A")] * (1 + want // max(1, len(ms[0])))
+        elif kind == 1:    # unrelated sequence: insertion / mismatch dominated
+            parts = [synth._to_ascii(st.below(want, 4))]
+        elif kind == 2:    # homopolymer runs
+            parts = [bytes([b"ACGT"[rnd(4)]]) * (1 + rnd(300)) for _ in range(1 + want // 150)]
         b = bytearray(b"".join(parts))
         if rnd(3) == 0:
             for p in st.below(1 + rnd(20), len(b)):
