@@ -132,6 +132,7 @@ def main():
     alg_per_launch = alg_bytes / max(info["fill_launches"], 1)
     achieved = alg_per_launch / fill_s / 1e9 if fill_s > 0 else 0.0
     traffic = None
+    valu = None
     tf = os.path.join(ROOT, "profiles", "fill_traffic.json")
     if os.path.isfile(tf):
         try:
@@ -139,6 +140,14 @@ def main():
                 tj = json.load(f)
             if tj.get("workload_rows") == rows and tj.get("kernel_family") == info["family"]:
                 traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("SQ_INSTS_VALU_per_launch") and tj.get("cells", info["cells"]) == info["cells"]:
+                    # what actually binds the fill (SURVEY 8(d) caveat): VALU issue slots, one wave64
+                    # instruction per 4 cycles per SIMD, 4 SIMDs x 256 CUs; clock from GRBM_GUI_ACTIVE
+                    cyc = tj["GRBM_GUI_ACTIVE_per_launch"] / 8.0
+                    valu = {"wave_insts_per_launch": tj["SQ_INSTS_VALU_per_launch"],
+                            "insts_per_row": tj["SQ_INSTS_VALU_per_launch"] / rows,
+                            "issue_frac_profiled": tj["SQ_INSTS_VALU_per_launch"] * 4.0 / (1024.0 * cyc),
+                            "source": "profiles/fill_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE)"}
         except Exception:
             traffic = None
 
@@ -146,19 +155,20 @@ def main():
         "metric": "decomposed read-bp/sec (whole node) at 12 monomers x 50kb reads",
         "value": bp_total * K / dt, "unit": "bp/s", "n_gpus": ws, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "int16" if info["family"] == "fast" else "int32",
+        "scaling": "weak", "vs_baseline": None, "dtype": info["cells"].split("/")[0],
         "data": "synthetic",
         "config": {"workload": "C2: synthetic %d reads x %d bp per GPU, %d monomers (~171 bp) + reverse complements, "
                                "default scoring -1,-1,-1,1, part 5000 / overlap 500" % (args.reads, args.read_len, args.monomers),
                    "reads_per_gpu": args.reads, "read_len": args.read_len, "n_templates": info["n_templates"],
                    "sum_template_len": sumL, "chunks_per_gpu": n_chunks, "rows_per_gpu": rows,
                    "kernel_family": info["family"], "cells_per_lane": info["cells_per_lane"],
+                   "cell_arithmetic": info["cells"] + (" (packed pairs holding exact integers)" if info["cells"] == "f16" else ""),
                    "seed": args.seed, "sharding": "reads dealt to ranks in contiguous blocks, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "sd_fast_fill" if info["family"] == "fast" else "sd_generic_fill",
                      "algorithmic_bytes_per_launch": alg_per_launch,
-                     "avg_launch_ms": fill_s * 1e3,
+                     "avg_launch_ms": fill_s * 1e3, "valu_issue": valu,
                      "cells_per_s": rows * sumL / max(info["fill_launches"], 1) / fill_s if fill_s > 0 else 0.0},
         "kernel_ms_per_step": {"fill": fill_ms / K, "traceback": trace_ms / K, "compact": compact_ms / K},
         "rows_out_per_gpu": rows_out, "hbm_workspace_bytes": info["workspace_bytes"],

@@ -740,7 +740,9 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
                        const int32_t* tlen, ScoreArgs sc, const int32_t* B, const int32_t* argV,
                        const uint32_t* ckpt, const int32_t* ckbase, DevRec* recs,
                        int32_t* rec_cnt, int* queue, const int* order, int n_cu) {
-    const int grid = std::min((n_chunks + 3) / 4, 8 * n_cu);  // persistent: 8 workgroups of 4 waves per CU
+    int bpc = 8;
+    if (const char* ev = getenv("SD_TRACE_BPC")) bpc = std::max(1, atoi(ev));  // developer knob
+    const int grid = std::min((n_chunks + 3) / 4, bpc * n_cu);  // persistent: 8 workgroups of 4 waves per CU
     (void)hipMemsetAsync(queue, 0, sizeof(int), st);
 #define SD_TRACE(QQ)                                                                              \
     hipLaunchKernelGGL(sd_fast_trace<QQ>, dim3(grid), dim3(256), 0, st, chunks, n_chunks, bases2, \

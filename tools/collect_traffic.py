@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/fill_traffic.json.
 
-usage: collect_traffic.py <dir with pmc_FETCH_SIZE/ and pmc_WRITE_SIZE/ rocprof outputs> <bench json>
+usage: collect_traffic.py <dir with pmc_FETCH_SIZE/, pmc_WRITE_SIZE/ [, pmc_SQ_INSTS_VALU/] rocprof outputs> <bench json>
+(the optional third pass, --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE, adds the VALU issue-slot figures)
 HBM bytes per launch of the fill kernel, following MI355X_MICROARCH.md (HBM section):
   * counters are collected in separate --pmc passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2);
   * both are in KiB;
@@ -35,6 +36,12 @@ def main():
     kern = bench["roofline"]["kernel"]
     fetch, nf = per_launch(os.path.join(root, "pmc_FETCH_SIZE"), "FETCH_SIZE", kern)
     write, nw = per_launch(os.path.join(root, "pmc_WRITE_SIZE"), "WRITE_SIZE", kern)
+    extra = {}
+    if os.path.isdir(os.path.join(root, "pmc_SQ_INSTS_VALU")):
+        v, _ = per_launch(os.path.join(root, "pmc_SQ_INSTS_VALU"), "SQ_INSTS_VALU", kern)
+        g, _ = per_launch(os.path.join(root, "pmc_SQ_INSTS_VALU"), "GRBM_GUI_ACTIVE", kern)
+        extra = {"SQ_INSTS_VALU_per_launch": v, "GRBM_GUI_ACTIVE_per_launch": g,
+                 "cells": bench["config"].get("cell_arithmetic", "").split(" ")[0]}
     out = {
         "kernel": kern,
         "kernel_family": bench["config"]["kernel_family"],
@@ -47,6 +54,7 @@ def main():
         "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace; "
                   "KiB -> bytes; FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section)",
     }
+    out.update(extra)
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "fill_traffic.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
