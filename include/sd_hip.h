@@ -78,6 +78,28 @@ int sd_decompose(const char* const* read_names, const char* const* read_seqs,
                  const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono,
                  const sd_params* p, char** tsv, size_t* tsv_len, char* errbuf, size_t errlen);
 
+/* ---- chunk-range form: one job sharded over several GPUs, one process per GPU ---------------
+ * The chunks of a read set (main.cpp:70-81, all reads, input order) form one global table; a chunk's
+ * DP depends on nothing but its own bases and the template set (main.cpp:88-96), so rank g runs the
+ * contiguous range [lo_g, hi_g) of the table -- a single 200-Mb sequence splits like a million reads --
+ * and one rank turns the concatenated records into the raw TSV.  No collective on the data path. */
+int64_t sd_chunk_table_size(const int64_t* read_lens, int32_t n_reads, int32_t part_size, int32_t overlap);
+
+/* Records (chunk-local coordinates, as sd_engine_fetch) of chunks [chunk_lo, chunk_hi); batched and
+ * pipelined on the device like sd_decompose.  *recs / *rec_off (chunk_hi - chunk_lo + 1 entries) are
+ * malloc'ed (sd_free). */
+int sd_decompose_chunk_range(const char* const* read_seqs, const int64_t* read_lens, int32_t n_reads,
+                             const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono,
+                             const sd_params* p, int64_t chunk_lo, int64_t chunk_hi, sd_rec** recs,
+                             int64_t** rec_off, char* errbuf, size_t errlen);
+
+/* Host only: records of ALL chunks in table order -> raw TSV (chunk offsets main.cpp:109-111, seam
+ * merge :287-302, SaveBatch :272-285).  The bytes equal sd_decompose's. */
+int sd_assemble_tsv(const char* const* read_names, const int64_t* read_lens, int32_t n_reads,
+                    const char* const* mono_names, int32_t n_mono, const sd_params* p,
+                    const sd_rec* recs, const int64_t* rec_off, int64_t n_chunks, char** tsv,
+                    size_t* tsv_len, char* errbuf, size_t errlen);
+
 /* ---- engine: device-resident batches (what bench.py and the parity tests drive) ------------ */
 typedef struct sd_engine sd_engine;
 

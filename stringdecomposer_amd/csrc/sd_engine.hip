@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -630,32 +631,46 @@ struct ReadView {  // borrowed for the duration of the call
 };
 }  // namespace
 
-static int decompose_impl(const std::vector<ReadView>& reads, const std::vector<sd::Seq>& monos,
-                          const sd_params* p, std::string& tsv, std::string& err) {
-    if (monos.empty()) { err = "no monomers"; return SD_ERR_PARAM; }
-    for (const ReadView& r : reads)
-        if (r.len <= 0) { err = "ERROR: Sequence " + std::string(r.name, r.name_len) + " is empty"; return SD_ERR_EMPTY; }
-    std::vector<const char*> mseq;
-    std::vector<int32_t> mlen;
-    std::vector<std::string> tnames;
-    for (const sd::Seq& m : monos) {
-        mseq.push_back(m.seq.data());
-        mlen.push_back((int32_t)m.seq.size());
-        tnames.push_back(m.name);
-    }
-    for (const sd::Seq& m : monos) tnames.push_back(m.name + "'");  // main.cpp:367
-    char eb[1024] = {0};
-    sd_engine* eng = nullptr;
-    int rc = sd_engine_create(&eng, p, mseq.data(), mlen.data(), (int32_t)monos.size(), eb, sizeof eb);
-    if (rc) { err = eb; return rc; }
-    // Global chunk table (main.cpp:70-81); the device works through it in batches of consecutive
-    // chunks sized to the free HBM, so a single 200-Mb sequence and a million reads take the same path.
-    struct CRef { int32_t read; int64_t off; int32_t len; };
-    std::vector<CRef> table;
-    std::vector<int32_t> nch(reads.size(), 0);
+namespace {
+struct CRef { int32_t read; int64_t off; int32_t len; };
+
+// Global chunk table (main.cpp:70-81) of a read set; nch[r] = chunks of read r.
+void build_chunk_table(const std::vector<ReadView>& reads, const sd_params* p, std::vector<CRef>& table,
+                       std::vector<int32_t>& nch) {
+    nch.assign(reads.size(), 0);
     for (size_t r = 0; r < reads.size(); ++r)
         nch[r] = sd::chunk_plan(reads[r].len, p->part_size, p->overlap,
                                 [&](int64_t off, int32_t l) { table.push_back(CRef{(int32_t)r, off, l}); });
+}
+
+struct TemplateSet {
+    std::vector<const char*> mseq;
+    std::vector<int32_t> mlen;
+    std::vector<std::string> tnames;
+    explicit TemplateSet(const std::vector<sd::Seq>& monos) {
+        for (const sd::Seq& m : monos) {
+            mseq.push_back(m.seq.data());
+            mlen.push_back((int32_t)m.seq.size());
+            tnames.push_back(m.name);
+        }
+        for (const sd::Seq& m : monos) tnames.push_back(m.name + "'");  // main.cpp:367
+    }
+};
+}  // namespace
+
+// Runs the chunks [c_lo, c_hi) of `table` through the device in batches of consecutive chunks sized to
+// the free HBM, so a single 200-Mb sequence and a million reads take the same path.  Two engines on two
+// non-blocking streams form a software pipeline: while the device works on batch b, the host packs +
+// uploads batch b+1 and enqueues it, then hands the records of batch b to `sink(c0, c1, recs, rec_off)`
+// (chunk-local coordinates, rec_off relative to the batch).
+using BatchSink = std::function<void(size_t, size_t, const sd_rec*, const int64_t*)>;
+static int run_chunk_batches(const std::vector<ReadView>& reads, const std::vector<CRef>& table, size_t c_lo,
+                             size_t c_hi, const TemplateSet& ts, const sd_params* p, std::string& err,
+                             const BatchSink& sink) {
+    char eb[1024] = {0};
+    sd_engine* eng = nullptr;
+    int rc = sd_engine_create(&eng, p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size(), eb, sizeof eb);
+    if (rc) { err = eb; return rc; }
     // default: batches of <= 48 M rows (~900 reads of 50 kb): large enough to fill the GPU twice over,
     // small enough that the host/device pipeline below has stages to overlap and buffers are reused
     int64_t row_budget = (int64_t)48 << 20;
@@ -669,20 +684,18 @@ static int decompose_impl(const std::vector<ReadView>& reads, const std::vector<
         }
         if (p->max_batch_rows > 0) row_budget = p->max_batch_rows;  // explicit cap (tests, small GPUs)
     }
-    // Two engines on two non-blocking streams form a software pipeline: while the device works on
-    // batch b, the host packs + uploads batch b+1 and enqueues it, then fetches and formats batch b.
     sd_engine* eng2 = nullptr;
     hipStream_t streams[2] = {nullptr, nullptr};
     std::vector<std::pair<size_t, size_t>> batches;
-    for (size_t c0 = 0; c0 < table.size();) {
+    for (size_t c0 = c_lo; c0 < c_hi;) {
         int64_t rows = 0;
         size_t c1 = c0;
-        while (c1 < table.size() && (c1 == c0 || rows + table[c1].len <= row_budget)) rows += table[c1++].len;
+        while (c1 < c_hi && (c1 == c0 || rows + table[c1].len <= row_budget)) rows += table[c1++].len;
         batches.emplace_back(c0, c1);
         c0 = c1;
     }
     if (batches.size() > 1) {
-        rc = sd_engine_create(&eng2, p, mseq.data(), mlen.data(), (int32_t)monos.size(), eb, sizeof eb);
+        rc = sd_engine_create(&eng2, p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size(), eb, sizeof eb);
         if (rc) { err = eb; sd_engine_destroy(eng); return rc; }
         for (hipStream_t& st : streams)
             if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
@@ -699,44 +712,12 @@ static int decompose_impl(const std::vector<ReadView>& reads, const std::vector<
         if (r2 == SD_OK) r2 = sd_engine_run(engs[b & 1], streams[b & 1], eb, sizeof eb);
         return r2;
     };
-    std::vector<sd_rec> batch_rows;      // records of the read being assembled
-    size_t next_read = 0;                // first read not yet written
-    int32_t chunks_seen_of_read = 0;
     if (!batches.empty()) rc = submit(0);
     for (size_t b = 0; b < batches.size() && rc == SD_OK; ++b) {
         if (b + 1 < batches.size()) rc = submit(b + 1);
-        const size_t c0 = batches[b].first, c1 = batches[b].second;
         sd_rec* recs = nullptr; int64_t* roff = nullptr;
         if (rc == SD_OK) rc = sd_engine_fetch(engs[b & 1], &recs, &roff, eb, sizeof eb);
-        if (rc == SD_OK) {
-            // per-read assembly (main.cpp:104-117); reads complete in input order
-            std::vector<std::vector<sd_rec>> done_rows;
-            std::vector<size_t> done_ids;
-            for (size_t c = c0; c < c1; ++c) {
-                const int32_t add = (int32_t)table[c].off;
-                for (int64_t x = roff[c - c0]; x < roff[c - c0 + 1]; ++x) {
-                    sd_rec t = recs[x];
-                    t.start += add;
-                    t.end += add;
-                    batch_rows.push_back(t);
-                }
-                if (++chunks_seen_of_read == nch[next_read]) {
-                    done_rows.emplace_back();
-                    done_rows.back().swap(batch_rows);
-                    done_ids.push_back(next_read);
-                    ++next_read;
-                    chunks_seen_of_read = 0;
-                }
-            }
-            std::vector<std::string> parts(done_ids.size());
-            sd::parallel_for((int64_t)done_ids.size(), p->threads, 4, [&](int64_t q) {
-                sd::seam_merge(done_rows[(size_t)q]);
-                const ReadView& rd = reads[done_ids[(size_t)q]];
-                sd::format_rows(parts[(size_t)q], rd.name, rd.name_len, tnames,
-                                done_rows[(size_t)q].data(), done_rows[(size_t)q].size());
-            });
-            for (const std::string& part : parts) tsv += part;
-        }
+        if (rc == SD_OK) sink(batches[b].first, batches[b].second, recs, roff);
         std::free(recs); std::free(roff);
     }
     if (rc != SD_OK) (void)hipDeviceSynchronize();  // nothing may still be running on buffers we free
@@ -746,6 +727,69 @@ static int decompose_impl(const std::vector<ReadView>& reads, const std::vector<
     if (rc) err = eb;
     sd_engine_destroy(eng);
     return rc;
+}
+
+// Per-read assembly (main.cpp:104-117) of per-chunk records arriving in chunk order: chunk offsets,
+// seam merge, raw TSV text.  Reads complete in input order.
+namespace {
+struct ReadAssembler {
+    const std::vector<ReadView>& reads;
+    const std::vector<CRef>& table;
+    const std::vector<int32_t>& nch;
+    const std::vector<std::string>& tnames;
+    int threads;
+    std::string& tsv;
+    std::vector<sd_rec> cur;      // records of the read being assembled
+    size_t next_read = 0;         // first read not yet written
+    int32_t chunks_seen = 0;
+    ReadAssembler(const std::vector<ReadView>& r, const std::vector<CRef>& t, const std::vector<int32_t>& n,
+                  const std::vector<std::string>& tn, int th, std::string& out)
+        : reads(r), table(t), nch(n), tnames(tn), threads(th), tsv(out) {}
+    void add(size_t c0, size_t c1, const sd_rec* recs, const int64_t* roff) {
+        std::vector<std::vector<sd_rec>> done_rows;
+        std::vector<size_t> done_ids;
+        for (size_t c = c0; c < c1; ++c) {
+            const int32_t add = (int32_t)table[c].off;  // main.cpp:109-111
+            for (int64_t x = roff[c - c0]; x < roff[c - c0 + 1]; ++x) {
+                sd_rec t = recs[x];
+                t.start += add;
+                t.end += add;
+                cur.push_back(t);
+            }
+            if (++chunks_seen == nch[next_read]) {
+                done_rows.emplace_back();
+                done_rows.back().swap(cur);
+                done_ids.push_back(next_read);
+                ++next_read;
+                chunks_seen = 0;
+            }
+        }
+        std::vector<std::string> parts(done_ids.size());
+        sd::parallel_for((int64_t)done_ids.size(), threads, 4, [&](int64_t q) {
+            sd::seam_merge(done_rows[(size_t)q]);
+            const ReadView& rd = reads[done_ids[(size_t)q]];
+            sd::format_rows(parts[(size_t)q], rd.name, rd.name_len, tnames, done_rows[(size_t)q].data(),
+                            done_rows[(size_t)q].size());
+        });
+        for (const std::string& part : parts) tsv += part;
+    }
+};
+}  // namespace
+
+static int decompose_impl(const std::vector<ReadView>& reads, const std::vector<sd::Seq>& monos,
+                          const sd_params* p, std::string& tsv, std::string& err) {
+    if (monos.empty()) { err = "no monomers"; return SD_ERR_PARAM; }
+    for (const ReadView& r : reads)
+        if (r.len <= 0) { err = "ERROR: Sequence " + std::string(r.name, r.name_len) + " is empty"; return SD_ERR_EMPTY; }
+    TemplateSet ts(monos);
+    std::vector<CRef> table;
+    std::vector<int32_t> nch;
+    build_chunk_table(reads, p, table, nch);
+    ReadAssembler as(reads, table, nch, ts.tnames, p->threads, tsv);
+    return run_chunk_batches(reads, table, 0, table.size(), ts, p, err,
+                             [&](size_t c0, size_t c1, const sd_rec* recs, const int64_t* roff) {
+                                 as.add(c0, c1, recs, roff);
+                             });
 }
 
 int sd_decompose(const char* const* read_names, const char* const* read_seqs,
@@ -815,6 +859,129 @@ int sd_decompose_files(const char* reads_fa, const char* monomers_fa, const sd_p
         set_err(errbuf, errlen, std::string("short write to ") + raw_tsv_out);
         return SD_ERR_IO;
     }
+    return SD_OK;
+}
+
+// -------------------------------------------------------------------------------------------
+// chunk-range form: multi-GPU sharding of one job, one process per GPU
+// -------------------------------------------------------------------------------------------
+int64_t sd_chunk_table_size(const int64_t* read_lens, int32_t n_reads, int32_t part_size, int32_t overlap) {
+    if (!read_lens || n_reads < 0 || part_size <= 0 || overlap < 0) return -1;
+    int64_t n = 0;
+    for (int32_t r = 0; r < n_reads; ++r) n += sd::chunk_plan(read_lens[r], part_size, overlap, [](int64_t, int32_t) {});
+    return n;
+}
+
+int sd_decompose_chunk_range(const char* const* read_seqs, const int64_t* read_lens, int32_t n_reads,
+                             const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono,
+                             const sd_params* p, int64_t chunk_lo, int64_t chunk_hi, sd_rec** recs,
+                             int64_t** rec_off, char* errbuf, size_t errlen) {
+    if (!recs || !rec_off || !read_seqs || !read_lens || !mono_seqs || !mono_lens) return SD_ERR_PARAM;
+    *recs = nullptr;
+    *rec_off = nullptr;
+    std::string err;
+    int rc = validate_params(p, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    if (n_mono <= 0) { set_err(errbuf, errlen, "no monomers"); return SD_ERR_PARAM; }
+    std::vector<ReadView> reads((size_t)std::max(n_reads, 0));
+    for (int32_t r = 0; r < n_reads; ++r) {
+        if (read_lens[r] <= 0) { set_err(errbuf, errlen, "ERROR: Sequence #" + std::to_string(r) + " is empty"); return SD_ERR_EMPTY; }
+        reads[(size_t)r] = ReadView{"", 0, read_seqs[r], read_lens[r]};
+    }
+    std::vector<sd::Seq> monos((size_t)n_mono);
+    for (int32_t m = 0; m < n_mono; ++m) {
+        monos[(size_t)m].name = "m" + std::to_string(m);
+        monos[(size_t)m].seq.assign(mono_seqs[m], (size_t)mono_lens[m]);
+        rc = sd::check_alphabet(monos[(size_t)m].name.c_str(), mono_seqs[m], mono_lens[m], err);
+        if (rc) { set_err(errbuf, errlen, err); return rc; }
+    }
+    TemplateSet ts(monos);
+    std::vector<CRef> table;
+    std::vector<int32_t> nch;
+    build_chunk_table(reads, p, table, nch);
+    if (chunk_lo < 0 || chunk_hi < chunk_lo || (size_t)chunk_hi > table.size()) {
+        set_err(errbuf, errlen, "chunk range outside the chunk table");
+        return SD_ERR_PARAM;
+    }
+    // only the bases this range touches are validated here (every rank validates its own share)
+    {
+        std::vector<int> bad((size_t)(chunk_hi - chunk_lo), 0);
+        sd::parallel_for(chunk_hi - chunk_lo, p->threads, 64, [&](int64_t i) {
+            const CRef& c = table[(size_t)(chunk_lo + i)];
+            std::string e2;
+            bad[(size_t)i] = sd::check_alphabet("", reads[(size_t)c.read].seq + c.off, c.len, e2) != SD_OK;
+        });
+        for (size_t i = 0; i < bad.size(); ++i)
+            if (bad[i]) {
+                const CRef& c = table[(size_t)chunk_lo + i];
+                const std::string nm = "#" + std::to_string(c.read);
+                rc = sd::check_alphabet(nm.c_str(), reads[(size_t)c.read].seq + c.off, c.len, err);
+                set_err(errbuf, errlen, err);
+                return rc;
+            }
+    }
+    std::vector<sd_rec> all;
+    std::vector<int64_t> offs(1, 0);
+    rc = run_chunk_batches(reads, table, (size_t)chunk_lo, (size_t)chunk_hi, ts, p, err,
+                           [&](size_t c0, size_t c1, const sd_rec* r, const int64_t* ro) {
+                               const int64_t base = (int64_t)all.size();
+                               all.insert(all.end(), r, r + ro[c1 - c0]);
+                               for (size_t c = 1; c <= c1 - c0; ++c) offs.push_back(base + ro[c]);
+                           });
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    sd_rec* o = static_cast<sd_rec*>(std::malloc(sizeof(sd_rec) * std::max<size_t>(all.size(), 1)));
+    if (!all.empty()) std::memcpy(o, all.data(), sizeof(sd_rec) * all.size());
+    int64_t* ro = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * offs.size()));
+    std::memcpy(ro, offs.data(), sizeof(int64_t) * offs.size());
+    *recs = o;
+    *rec_off = ro;
+    return SD_OK;
+}
+
+int sd_assemble_tsv(const char* const* read_names, const int64_t* read_lens, int32_t n_reads,
+                    const char* const* mono_names, int32_t n_mono, const sd_params* p,
+                    const sd_rec* recs, const int64_t* rec_off, int64_t n_chunks, char** tsv,
+                    size_t* tsv_len, char* errbuf, size_t errlen) {
+    if (!tsv || !tsv_len || !read_names || !read_lens || !mono_names || !rec_off || (!recs && rec_off[n_chunks] > 0))
+        return SD_ERR_PARAM;
+    *tsv = nullptr;
+    *tsv_len = 0;
+    std::string err;
+    int rc = validate_params(p, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    std::vector<ReadView> reads((size_t)std::max(n_reads, 0));
+    for (int32_t r = 0; r < n_reads; ++r)
+        reads[(size_t)r] = ReadView{read_names[r], std::strlen(read_names[r]), nullptr, read_lens[r]};
+    std::vector<std::string> tnames;
+    for (int32_t m = 0; m < n_mono; ++m) tnames.emplace_back(mono_names[m]);
+    for (int32_t m = 0; m < n_mono; ++m) tnames.push_back(std::string(mono_names[m]) + "'");
+    std::vector<CRef> table;
+    std::vector<int32_t> nch;
+    build_chunk_table(reads, p, table, nch);
+    if ((int64_t)table.size() != n_chunks) {
+        set_err(errbuf, errlen, "record offsets do not match the chunk table of these reads");
+        return SD_ERR_PARAM;
+    }
+    for (int64_t x = 0; x < rec_off[n_chunks]; ++x)
+        if (recs[x].tmpl < 0 || recs[x].tmpl >= 2 * n_mono) {
+            set_err(errbuf, errlen, "record with a template index outside the monomer set");
+            return SD_ERR_PARAM;
+        }
+    std::string out;
+    ReadAssembler as(reads, table, nch, tnames, p->threads, out);
+    // in slices, so that the formatting threads always have a few hundred reads to share
+    const size_t step = 4096;
+    for (size_t c0 = 0; c0 < table.size(); c0 += step) {
+        const size_t c1 = std::min(table.size(), c0 + step);
+        std::vector<int64_t> ro(c1 - c0 + 1);
+        for (size_t c = c0; c <= c1; ++c) ro[c - c0] = rec_off[c] - rec_off[c0];
+        as.add(c0, c1, recs + rec_off[c0], ro.data());
+    }
+    char* o = static_cast<char*>(std::malloc(out.size() + 1));
+    std::memcpy(o, out.data(), out.size());
+    o[out.size()] = 0;
+    *tsv = o;
+    *tsv_len = out.size();
     return SD_OK;
 }
 

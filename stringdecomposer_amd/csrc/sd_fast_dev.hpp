@@ -33,10 +33,11 @@ __device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 __device__ __forceinline__ uint32_t pack2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
 
-// value of lane (l - d), own value for l < d (callers mask those lanes)
+// value of lane (l - d); lanes l < d get 0 (DPP, bound_ctrl) or their own value (shuffle form): callers
+// mask those lanes.  bound_ctrl spares the copy a tied `old` operand would need.
 __device__ __forceinline__ uint32_t lane_up(uint32_t x, int d) {
 #if SD_USE_DPP
-    if (d == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+    if (d == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
 #endif
     return (uint32_t)__shfl_up((int)x, d);
 }

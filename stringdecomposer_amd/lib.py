@@ -29,7 +29,8 @@ EXPORTS = [
     "sd_decompose", "sd_engine_create", "sd_engine_destroy", "sd_engine_load_reads",
     "sd_engine_run", "sd_engine_fetch", "sd_engine_assemble", "sd_engine_timings",
     "sd_engine_info", "sd_chunk_plan", "sd_seam_merge", "sd_format_rows", "sd_fasta_load",
-    "sd_fasta_free", "sd_nw_identity_batch", "sd_identity_segments",
+    "sd_fasta_free", "sd_nw_identity_batch", "sd_identity_segments", "sd_chunk_table_size",
+    "sd_decompose_chunk_range", "sd_assemble_tsv",
 ]
 
 
@@ -103,6 +104,14 @@ def load():
     L.sd_identity_segments.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                        P(C.c_char_p), P(C.c_int32), C.c_int32, C.c_int32, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sd_chunk_table_size.restype = C.c_int64
+    L.sd_chunk_table_size.argtypes = [P(C.c_int64), C.c_int32, C.c_int32, C.c_int32]
+    L.sd_decompose_chunk_range.argtypes = [P(C.c_char_p), P(C.c_int64), C.c_int32, P(C.c_char_p), P(C.c_int32),
+                                           C.c_int32, P(Params), C.c_int64, C.c_int64, P(P(Rec)),
+                                           P(P(C.c_int64)), C.c_char_p, C.c_size_t]
+    L.sd_assemble_tsv.argtypes = [P(C.c_char_p), P(C.c_int64), C.c_int32, P(C.c_char_p), C.c_int32, P(Params),
+                                  C.c_void_p, C.c_void_p, C.c_int64, P(C.c_void_p), P(C.c_size_t),
+                                  C.c_char_p, C.c_size_t]
     _lib = L
     return L
 
@@ -351,3 +360,67 @@ def identity_segments(seq, starts, ends, templates, homo=False, threads=1):
     if rc != SD_OK:
         raise SdError(rc, "sd_identity_segments")
     return d, m, c
+
+
+# ---- chunk-range form (one job over several GPUs, one process per GPU; see shard.py) ---------------
+def _rec_dtype():
+    import numpy as np
+    return np.dtype([("tmpl", np.int32), ("start", np.int32), ("end", np.int32), ("score", np.int32)])
+
+
+def chunk_table_size(read_lens, part_size=5000, overlap=500):
+    L = load()
+    arr = (C.c_int64 * max(len(read_lens), 1))(*[int(x) for x in read_lens])
+    return L.sd_chunk_table_size(arr, len(read_lens), part_size, overlap)
+
+
+def decompose_chunk_range(read_seqs, mono_seqs, chunk_lo, chunk_hi, **kw):
+    """Records of the chunks [chunk_lo, chunk_hi) of the global chunk table of `read_seqs`:
+    (recs structured array [tmpl, start, end, score], rec_off int64[chunk_hi - chunk_lo + 1])."""
+    import numpy as np
+    L = load()
+    p = make_params(**kw)
+    rs = [_b(s) for s in read_seqs]
+    ms = [_b(s) for s in mono_seqs]
+    rl = (C.c_int64 * max(len(rs), 1))(*[len(s) for s in rs])
+    ml = (C.c_int32 * max(len(ms), 1))(*[len(s) for s in ms])
+    recs = C.POINTER(Rec)()
+    off = C.POINTER(C.c_int64)()
+    err = C.create_string_buffer(4096)
+    rc = L.sd_decompose_chunk_range(_strs(rs), rl, len(rs), _strs(ms), ml, len(ms), C.byref(p), chunk_lo,
+                                    chunk_hi, C.byref(recs), C.byref(off), err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+    n = chunk_hi - chunk_lo
+    o = np.ctypeslib.as_array(off, shape=(n + 1,)).copy()
+    nrec = int(o[n])
+    if nrec:
+        raw = C.string_at(recs, nrec * C.sizeof(Rec))
+        r = np.frombuffer(raw, dtype=_rec_dtype()).copy()
+    else:
+        r = np.zeros(0, dtype=_rec_dtype())
+    L.sd_free(recs)
+    L.sd_free(off)
+    return r, o
+
+
+def assemble_tsv(read_names, read_lens, mono_names, recs, rec_off, **kw):
+    """Raw TSV bytes from the records of all chunks in table order (host only)."""
+    import numpy as np
+    L = load()
+    p = make_params(**kw)
+    rn = [_b(s) for s in read_names]
+    mn = [_b(s) for s in mono_names]
+    rl = (C.c_int64 * max(len(rn), 1))(*[int(x) for x in read_lens])
+    r = np.ascontiguousarray(recs, dtype=_rec_dtype())
+    o = np.ascontiguousarray(rec_off, dtype=np.int64)
+    out = C.c_void_p()
+    ln = C.c_size_t()
+    err = C.create_string_buffer(4096)
+    rc = L.sd_assemble_tsv(_strs(rn), rl, len(rn), _strs(mn), len(mn), C.byref(p), r.ctypes.data,
+                           o.ctypes.data, len(o) - 1, C.byref(out), C.byref(ln), err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+    data = C.string_at(out, ln.value)
+    L.sd_free(out)
+    return data

@@ -21,6 +21,7 @@ import sys
 import numpy as np
 
 from . import lib
+from . import shard
 
 CUR_DIR = os.path.dirname(os.path.abspath(__file__))
 LOGREG_FILE = os.path.join(CUR_DIR, "models", "ont_logreg_model.txt")
@@ -278,6 +279,25 @@ def run(sequences, monomers, num_threads, scoring, batch_size, raw_file, ed_thr,
         sys.exit(1)
     logger.info(" ".join(["Run", lib.LIB_PATH, "with parameters", sequences, monomers, str(num_threads),
                           str(batch_size), str(overlap), scoring]))
+    rank, local_rank, ws = shard.world()
+    if ws > 1:
+        # launched with `python -m torch.distributed.run --nproc-per-node G bin/stringdecomposer ...`:
+        # one process per GPU, each takes a contiguous range of the global chunk table (shard.py);
+        # the records meet on rank 0 through a host-side (gloo) gather -- no device collective.
+        dist = shard.init_process_group("gloo")
+        names, seqs, _ = lib.fasta_load(sequences)
+        mnames, mseqs, _ = lib.fasta_load(monomers)
+        raw = shard.decompose_sharded(names, seqs, mnames, mseqs, dist=dist, scoring=(ins, dels, mm, match),
+                                      part_size=int(batch_size), overlap=int(overlap), ed_thr=int(ed_thr),
+                                      threads=int(num_threads), kernel=kernel,
+                                      device=local_rank % max(lib.device_count(), 1))
+        shard.barrier(dist)
+        dist.destroy_process_group()
+        if rank != 0:
+            return None
+        with open(raw_file, "wb") as f:
+            f.write(raw)
+        return raw.decode()
     lib.decompose_files(sequences, monomers, raw_file, scoring=(ins, dels, mm, match),
                         part_size=int(batch_size), overlap=int(overlap), ed_thr=int(ed_thr),
                         threads=int(num_threads), device=device, kernel=kernel)
@@ -319,7 +339,12 @@ def main(argv=None):
     pathlib.Path(args.out_dir).mkdir(parents=True, exist_ok=True)
 
     logfn = os.path.join(args.out_dir, "stringdecomposer.log")
-    logger = get_logger(logfn, logger_name="StringDecomposer")
+    if shard.world()[0] == 0:
+        logger = get_logger(logfn, logger_name="StringDecomposer")
+    else:  # ranks > 0 of a multi-GPU launch compute their share and stay silent
+        logger = logging.getLogger("StringDecomposer.rank%d" % shard.world()[0])
+        logger.addHandler(logging.NullHandler())
+        logger.propagate = False
     logger.info(f"cmd: {sys.argv}")
 
     raw_decomp_fn = os.path.join(args.out_dir, args.out_file + "_raw.tsv")
@@ -333,6 +358,8 @@ def main(argv=None):
         sys.stderr.write(e.msg + "\n")
         logger.info("String Decomposer failed: " + e.msg)
         sys.exit(e.code if 0 < e.code < 256 else 1)
+    if raw_decomposition is None:
+        return  # not rank 0
     logger.info("Saved raw decomposition to " + raw_decomp_fn)
 
     reads = load_fasta(args.sequences, "map")

@@ -1,9 +1,16 @@
 """Multi-GPU sharding of the hot path: independent chunks, no data-path collective.
 
 A chunk's DP depends only on its <= part+overlap bases and the (replicated) template set
-(reference main.cpp:88-96), so reads are dealt to ranks in contiguous blocks and every rank runs
-the same single-GPU engine on its block.  torch.distributed (RCCL on GPUs, gloo in the CPU tests)
-is used only for the barrier / max-over-ranks timing and for gathering small row counts.
+(reference main.cpp:88-96).  Two granularities:
+  * bench.py (weak scaling): reads are dealt to ranks in contiguous blocks, every rank runs the
+    single-GPU engine on its block;
+  * decompose_sharded (one job, strong scaling): the chunks of ALL reads form one global table and
+    rank g takes the contiguous chunk range block_range(n_chunks, g, G) -- a single 200-Mb sequence
+    (BASELINE config 5) spreads over the GPUs exactly like a million reads.  The compact
+    records (24 B per ~171 bp) are gathered on rank 0, which applies the chunk offsets, the seam merge
+    and the TSV formatting (host only).
+torch.distributed (RCCL on GPUs, gloo in the CPU tests) is used only for the barrier / max-over-ranks
+timing and for that gather; there is no collective on the data path.
 """
 import os
 
@@ -69,3 +76,44 @@ def sum_over_ranks(dist, value, device="cpu"):
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+def decompose_sharded(read_names, read_seqs, mono_names, mono_seqs, dist=None, range_fn=None, **params):
+    """Raw TSV (bytes) of the whole job on rank 0, None on the other ranks.
+
+    Every rank holds the full read set (it parsed the same FASTA), computes the records of its own
+    contiguous range of the global chunk table on its GPU and sends them to rank 0.
+    `range_fn(read_seqs, mono_seqs, lo, hi, **params) -> (recs, rec_off)` defaults to the HIP path
+    (lib.decompose_chunk_range); the CPU tests inject a checker-based one."""
+    import numpy as np
+    from . import lib
+    rank, local_rank, ws = world() if dist is not None else (0, 0, 1)
+    part = int(params.get("part_size", 5000))
+    overlap = int(params.get("overlap", 500))
+    read_lens = [len(s) for s in read_seqs]
+    n_chunks = lib.chunk_table_size(read_lens, part, overlap)
+    lo, hi = block_range(n_chunks, rank, ws)
+    if range_fn is None:
+        params = dict(params, device=params.get("device", local_rank))
+        range_fn = lib.decompose_chunk_range
+    recs, off = range_fn(read_seqs, mono_seqs, lo, hi, **params)
+    recs = np.ascontiguousarray(recs)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    if dist is None or ws == 1:
+        parts = [(lo, recs, off)]
+    else:
+        box = [None] * ws if rank == 0 else None
+        dist.gather_object((lo, recs, off), box, dst=0)
+        if rank != 0:
+            return None
+        parts = sorted(box, key=lambda t: t[0])
+    all_recs = np.concatenate([p[1] for p in parts]) if parts else recs
+    offs = [np.zeros(1, dtype=np.int64)]
+    base = 0
+    for _, r, o in parts:
+        offs.append(o[1:] + base)
+        base += len(r)
+    all_off = np.concatenate(offs)
+    assert len(all_off) == n_chunks + 1
+    keep = {k: v for k, v in params.items() if k in ("scoring", "part_size", "overlap", "threads")}
+    return lib.assemble_tsv(read_names, read_lens, mono_names, all_recs, all_off, **keep)

@@ -12,7 +12,7 @@ import pytest
 
 from conftest import GOLDEN, ROOT, case_names, load_case
 
-from stringdecomposer_amd import lib, synth
+from stringdecomposer_amd import lib, shard, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -348,3 +348,49 @@ def test_cli_scoring_ref_compat_and_ed_thr(tmp_path, oracle):
     assert run(["--scoring=-2,-3,-4,2", "--ref-compat"], "b") == default
     assert run(["--ed_thr", "12"], "c") == oracle.decompose(rn, rs, mn, ms, threads=8, ed_thr=12)
     assert run(["-b", "700", "-v", "100"], "d") == oracle.decompose(rn, rs, mn, ms, threads=8, part=700, overlap=100)
+
+
+def test_chunk_range_form_equals_one_shot(oracle):
+    """the global chunk table cut into contiguous ranges (what each GPU of a multi-GPU job
+    runs), records concatenated and assembled on the host == the one-shot call == the oracle.  One long
+    sequence (so a single read spans several ranges) + ordinary reads; small device batches inside a range."""
+    mn, ms = synth.make_monomers(12, seed=9)
+    rn, rs = synth.make_reads(ms, 5, read_len=23000, seed=9)
+    n1, s1 = synth.make_reads(ms, 1, read_len=260000, seed=10)
+    rn, rs = ["chrX"] + list(rn), list(s1) + list(rs)
+    sc = (-1, -2, -1, 1)
+    one = lib.decompose(rn, rs, mn, ms, scoring=sc)
+    n = lib.chunk_table_size([len(s) for s in rs])
+    assert n == sum(len(lib.chunk_plan(len(s))) for s in rs)
+    parts = []
+    for g in range(3):
+        lo, hi = shard.block_range(n, g, 3)
+        parts.append(lib.decompose_chunk_range(rs, ms, lo, hi, scoring=sc, max_batch_rows=[0, 30000, 9000][g]))
+    recs = np.concatenate([p[0] for p in parts])
+    off = np.concatenate([[0]] + [p[1][1:] + sum(len(q[0]) for q in parts[:i]) for i, p in enumerate(parts)])
+    got = lib.assemble_tsv(rn, [len(s) for s in rs], mn, recs, off, scoring=sc, threads=3)
+    assert got == one
+    assert got == oracle.decompose(rn, rs, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc)
+    assert shard.decompose_sharded(rn, rs, mn, ms, scoring=sc) == one
+    with pytest.raises(lib.SdError):
+        lib.decompose_chunk_range(rs, ms, 0, n + 1)
+
+
+def test_cli_two_processes_on_one_gpu(tmp_path):
+    """The multi-GPU launch form of the CLI (one process per GPU under torch.distributed.run); here both
+    ranks share GPU 0.  Output files equal the single-process run."""
+    td = os.path.join(GOLDEN, "test_data")
+    outs = []
+    for nproc in (1, 2):
+        out = str(tmp_path / ("o%d" % nproc))
+        cmd = [sys.executable, os.path.join(ROOT, "bin", "stringdecomposer"), os.path.join(td, "read.fa"),
+               os.path.join(td, "DXZ1_star_monomers.fa"), "-o", out, "-t", "4", "--second-best"]
+        if nproc > 1:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                   "--master-addr", "127.0.0.1", "--master-port", "29631"] + cmd[1:]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode()[-2000:]
+        outs.append(out)
+    for fn in ("final_decomposition_raw.tsv", "final_decomposition.tsv", "final_decomposition_alt.tsv"):
+        with open(os.path.join(outs[0], fn), "rb") as a, open(os.path.join(outs[1], fn), "rb") as b:
+            assert a.read() == b.read(), fn

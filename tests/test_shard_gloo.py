@@ -68,3 +68,66 @@ def test_block_range_partitions(n, ws):
         assert 0 <= hi - lo <= n // ws + 1
         got += list(range(lo, hi))
     assert got == list(range(n))
+
+
+# ---- one job sharded by chunk range ----------------------------------------------------
+def _checker_range_fn(read_seqs, mono_seqs, lo, hi, scoring=(-1, -1, -1, 1), part_size=5000, overlap=500, **_):
+    """Records of chunks [lo, hi) computed by the CPU oracle (test infrastructure): stands in for the
+    HIP path so that the sharding / gather / assembly logic runs on a machine without a GPU."""
+    import numpy as np
+    from oracle import binding as oracle
+    from stringdecomposer_amd import lib
+    tmpl = [m if isinstance(m, str) else m.decode() for m in mono_seqs]
+    tmpl = tmpl + [oracle.reverse_complement(m) for m in tmpl]
+    table = []
+    for s in read_seqs:
+        table += [(s, off, ln) for off, ln in lib.chunk_plan(len(s), part_size, overlap)]
+    recs, off = [], [0]
+    for s, o, ln in table[lo:hi]:
+        chunk = s[o:o + ln]
+        recs += [(t, a, b, int(sc)) for t, a, b, sc in
+                 oracle.align_chunk(chunk if isinstance(chunk, str) else chunk.decode(), tmpl, scoring)]
+        off.append(len(recs))
+    return np.array(recs, dtype=lib._rec_dtype()), np.array(off, dtype=np.int64)
+
+
+def _shard_worker(rank, ws, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ws),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist = shard.init_process_group("gloo")
+    mn, ms = synth.make_monomers(3, seed=2)
+    ms = [m[:60] for m in ms]
+    # one long sequence (5 chunks) + short reads: the long one must split across the two ranks
+    names, seqs = synth.make_reads(ms, 3, read_len=700, seed=2)
+    n2, s2 = synth.make_reads(ms, 1, read_len=2450, seed=3)
+    names, seqs = ["long"] + names, list(s2) + list(seqs)
+    out = shard.decompose_sharded(names, seqs, mn, ms, dist=dist, range_fn=_checker_range_fn,
+                                  scoring=(-1, -2, -1, 1), part_size=500, overlap=100, threads=2)
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_one_job_sharded_by_chunk_range_world_size_2():
+    from oracle import binding as oracle
+    ws, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_shard_worker, args=(r, ws, port, q)) for r in range(ws)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(ws))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[1] is None
+    mn, ms = synth.make_monomers(3, seed=2)
+    ms = [m[:60] for m in ms]
+    names, seqs = synth.make_reads(ms, 3, read_len=700, seed=2)
+    n2, s2 = synth.make_reads(ms, 1, read_len=2450, seed=3)
+    names, seqs = ["long"] + names, list(s2) + list(seqs)
+    exp = oracle.decompose(names, seqs, mn, ms, sc=(-1, -2, -1, 1), part=500, overlap=100)
+    assert res[0] == exp
+    # and the single-process form of the same driver
+    one = shard.decompose_sharded(names, seqs, mn, ms, range_fn=_checker_range_fn,
+                                  scoring=(-1, -2, -1, 1), part_size=500, overlap=100)
+    assert one == exp
