@@ -321,6 +321,9 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
 // ---------------------------------------------------------------------------------------------
 // traceback with per-template recomputation
 // ---------------------------------------------------------------------------------------------
+#ifndef SD_TRACE_ADAPT
+#define SD_TRACE_ADAPT 1
+#endif
 template <int QK>
 __global__ __launch_bounds__(256) void sd_fast_trace(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
@@ -363,30 +366,49 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
     while (true) {
         const int Lj = tlen[j];
         const int x0 = toff[j];
-        int code[QK];
-        int slot[QK];
-#pragma unroll
-        for (int q = 0; q < QK; ++q) {
-            const int k = lane * QK + q;
-            code[q] = k < Lj ? (int)tcodes[x0 + k] : 7;
-            slot[q] = k < Lj ? (int)slot_of[x0 + k] : 0;
-#pragma unroll
-            for (int b = 0; b < 5; ++b) mt[b][lane][q] = code[q] == b ? mD : xD;
-        }
+        struct Cells { int code[QK]; int slot[QK]; };   // of the lane's cells, passed by value: the
+        struct Pos { int i, k; bool done; };             // lambdas must not capture mutable state
+        Cells cells;
         int i = e, k = Lj - 1;
         bool stop_row0 = false;
-        while (true) {
+        // The path only ever moves towards smaller k, so a block entered at cell k needs the cells
+        // 0..k and nothing beyond: the lanes are re-dealt with fewer cells each (QQ = QK, ~QK/2, ~QK/4)
+        // as the walk approaches the start of the template -- the recurrence of a cell never looks at
+        // larger k, so this is exact.  Lane l owns the cells [l*QQ, l*QQ + QQ).
+        auto setup = [&](auto qq_c) -> Cells {
+            constexpr int QQ = decltype(qq_c)::value;
+            Cells cl;
+#pragma unroll
+            for (int q = 0; q < QK; ++q) { cl.code[q] = 7; cl.slot[q] = 0; }
+#pragma unroll
+            for (int q = 0; q < QQ; ++q) {
+                const int kk = lane * QQ + q;
+                cl.code[q] = kk < Lj ? (int)tcodes[x0 + kk] : 7;
+                cl.slot[q] = kk < Lj ? (int)slot_of[x0 + kk] : 0;
+#pragma unroll
+                for (int b = 0; b < 5; ++b) mt[b][lane][q] = cl.code[q] == b ? mD : xD;
+            }
+            return cl;
+        };
+        // one block of rows [a, i]: recompute, derive the moves, walk; returns true when the instance
+        // start (START move) was reached
+        auto block = [&](auto qq_c, const Cells cl, const int i_in, const int k_in) -> Pos {
+            constexpr int QQ = decltype(qq_c)::value;
+            constexpr int QQP = QQ <= 4 ? 4 : 8;
+            int i = i_in, k = k_in;
+            const int* code = cl.code;
+            const int* slot = cl.slot;
             const int a = i & ~(FAST_R - 1);  // first row of the block
-            int32_t E[QK];
+            int32_t E[QQ];
             int rstart;
             if (a == 0) {
                 // row 0, main.cpp:171-182
                 const int r = rc.code(0);
                 int32_t run = NEG_INF32;
-                int32_t loc[QK];
+                int32_t loc[QQ];
 #pragma unroll
-                for (int q = 0; q < QK; ++q) {
-                    const int kk = lane * QK + q;
+                for (int q = 0; q < QQ; ++q) {
+                    const int kk = lane * QQ + q;
                     const int32_t mmd = code[q] == r ? mD : xD;
                     const int32_t cand = kk == 0 ? mmd + del : mmd;
                     run = kk == 0 ? cand : max(run, cand);
@@ -396,7 +418,7 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
                 int32_t left = X;
                 uint32_t bits = 0;
 #pragma unroll
-                for (int q = 0; q < QK; ++q) {
+                for (int q = 0; q < QQ; ++q) {
                     const int32_t Ef = max(loc[q], X);
                     const int pc = Ef == left ? 0 : 3;  // k == 0: left = -inf
                     bits |= (uint32_t)pc << (2 * q);
@@ -410,7 +432,7 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
                 const int32_t cb = ckbase[cd.pad + q0];
                 const uint32_t* ckq = ckpt + ((uint64_t)cd.pad + q0) * (uint64_t)(P * 64);
 #pragma unroll
-                for (int q = 0; q < QK; ++q) {
+                for (int q = 0; q < QQ; ++q) {
                     const int v = slot[q] & 127, s = slot[q] >> 7;
                     const uint32_t wv = ckq[s * 64 + (v & 63)];
                     const uint32_t hw = (v >> 6) ? (wv >> 16) : (wv & 0xffffu);
@@ -427,17 +449,17 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
             for (int r_i = rstart; r_i <= i; ++r_i) {
                 const int r = __builtin_amdgcn_readlane(vR, r_i - a);
                 const int32_t Bd = __builtin_amdgcn_readlane(vBd, r_i - a);
-                const int32_t pdEdge = lane_up_neg(E[QK - 1]);
-                int32_t loc[QK], w[QK], dg[QK];
+                const int32_t pdEdge = lane_up_neg(E[QQ - 1]);
+                int32_t loc[QQ], w[QQ], dg[QQ];
                 int32_t run = NEG_INF32, pd = pdEdge;
-                int32_t mm4[QP];
+                int32_t mm4[QQP];
 #pragma unroll
-                for (int h = 0; h < QP / 4; ++h) {
+                for (int h = 0; h < QQP / 4; ++h) {
                     const int4 mrow = *reinterpret_cast<const int4*>(&mt[r][lane][4 * h]);
                     mm4[4 * h + 0] = mrow.x; mm4[4 * h + 1] = mrow.y; mm4[4 * h + 2] = mrow.z; mm4[4 * h + 3] = mrow.w;
                 }
 #pragma unroll
-                for (int q = 0; q < QK; ++q) {
+                for (int q = 0; q < QQ; ++q) {
                     const int32_t mmd = mm4[q];
                     const int32_t v = max(pd, Bd) + mmd;     // start / diag (lane 0: pd = -inf)
                     dg[q] = pd + mmd;
@@ -452,7 +474,7 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
                 int32_t left = X;
                 uint32_t bits = 0;
 #pragma unroll
-                for (int q = 0; q < QK; ++q) {
+                for (int q = 0; q < QQ; ++q) {
                     const int32_t Ef = max(loc[q], X);
                     int pc = Ef == dg[q] ? 2 : 3;   // DIAG  main.cpp:249 / START main.cpp:253
                     pc = Ef == w[q] ? 1 : pc;       // INS   main.cpp:245 (tested at k == 0 too)
@@ -464,15 +486,34 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
                 pt[r_i - a][lane] = (pt_t)bits;
             }
             // walk inside the block (wave-uniform)
-            bool done = false;
             while (i >= a) {
-                const int pc = __builtin_amdgcn_readfirstlane((pt[i - a][k / QK] >> (2 * (k % QK))) & 3);
+                const int pc = __builtin_amdgcn_readfirstlane((pt[i - a][k / QQ] >> (2 * (k % QQ))) & 3);
                 if (pc == 0) { --k; }
                 else if (pc == 1) { --i; }
                 else if (pc == 2) { --i; --k; }
-                else { done = true; break; }
+                else { return Pos{i, k, true}; }
             }
-            if (done) { stop_row0 = (i == 0); break; }
+            return Pos{i, k, false};
+        };
+        constexpr int Q1 = (QK + 1) / 2, Q2 = (QK + 3) / 4;
+        int cur = 0;
+        while (true) {
+            const int need = (k >> 6) + 1;
+            const int lvl = (SD_TRACE_ADAPT && need <= Q2) ? Q2 : (SD_TRACE_ADAPT && need <= Q1) ? Q1 : QK;
+            Pos ps;
+            if (lvl == QK) {
+                if (cur != QK) { cells = setup(std::integral_constant<int, QK>()); cur = QK; }
+                ps = block(std::integral_constant<int, QK>(), cells, i, k);
+            } else if (lvl == Q1) {
+                if (cur != Q1) { cells = setup(std::integral_constant<int, Q1>()); cur = Q1; }
+                ps = block(std::integral_constant<int, Q1>(), cells, i, k);
+            } else {
+                if (cur != Q2) { cells = setup(std::integral_constant<int, Q2>()); cur = Q2; }
+                ps = block(std::integral_constant<int, Q2>(), cells, i, k);
+            }
+            i = ps.i;
+            k = ps.k;
+            if (ps.done) { stop_row0 = (i == 0); break; }
         }
         if (lane == 0) {
             DevRec rec;
