@@ -174,14 +174,16 @@ int sd_nw_identity_batch(const char* const* queries, const int32_t* qlens,
                          const char* const* targets, const int32_t* tlens, int64_t n_pairs,
                          int32_t threads, int32_t* dist, int32_t* matches, int32_t* columns);
 
-/* The all-vs-all form convert_read needs (main.py:107-150): segment s = seq[starts[s] .. ends[s]]
- * (inclusive, as in the raw TSV) is the query, template t the target; result index s * T + t.
+/* The forms convert_read needs (main.py:107-150): segment s = seq[starts[s] .. ends[s]] (inclusive,
+ * as in the raw TSV) is the query, a template the target.
+ *   pair_tmpl == NULL: all-vs-all (--second-best), result index s * T + t;
+ *   pair_tmpl != NULL: segment s against template pair_tmpl[s] only (light mode), result index s.
  * homo != 0 compresses homopolymer runs on both sides first (convert_to_homo, main.py:87-92).
  * Multi-threaded over segments. */
 int sd_identity_segments(const char* seq, int64_t seqlen, const int64_t* starts, const int64_t* ends,
                          int64_t n_seg, const char* const* tmpl, const int32_t* tlen, int32_t T,
-                         int32_t homo, int32_t threads, int32_t* dist, int32_t* matches,
-                         int32_t* columns);
+                         const int32_t* pair_tmpl, int32_t homo, int32_t threads, int32_t* dist,
+                         int32_t* matches, int32_t* columns);
 
 #ifdef __cplusplus
 }

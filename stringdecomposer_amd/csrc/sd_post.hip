@@ -190,8 +190,9 @@ static void homo_compress(const char* s, int64_t n, std::string& out) {
 
 extern "C" int sd_identity_segments(const char* seq, int64_t seqlen, const int64_t* starts,
                                     const int64_t* ends, int64_t n_seg, const char* const* tmpl,
-                                    const int32_t* tlen, int32_t T, int32_t homo, int32_t threads,
-                                    int32_t* dist, int32_t* matches, int32_t* columns) {
+                                    const int32_t* tlen, int32_t T, const int32_t* pair_tmpl,
+                                    int32_t homo, int32_t threads, int32_t* dist, int32_t* matches,
+                                    int32_t* columns) {
     if (n_seg < 0 || T < 0 || !seq || (n_seg && (!starts || !ends)) || (T && (!tmpl || !tlen)) ||
         !matches || !columns)
         return SD_ERR_PARAM;
@@ -200,6 +201,9 @@ extern "C" int sd_identity_segments(const char* seq, int64_t seqlen, const int64
     }
     for (int t = 0; t < T; ++t)
         if (tlen[t] > 65000) return SD_ERR_UNSUPPORTED;
+    if (pair_tmpl)
+        for (int64_t s = 0; s < n_seg; ++s)
+            if (pair_tmpl[s] < 0 || pair_tmpl[s] >= T) return SD_ERR_PARAM;
     std::vector<std::string> hm;
     if (homo) {
         hm.resize(T);
@@ -220,11 +224,12 @@ extern "C" int sd_identity_segments(const char* seq, int64_t seqlen, const int64
                 q = hs.data();
                 qlen = (int)hs.size();
             }
-            for (int t = 0; t < T; ++t) {
+            const int t0 = pair_tmpl ? pair_tmpl[s] : 0, t1 = pair_tmpl ? pair_tmpl[s] + 1 : T;
+            for (int t = t0; t < t1; ++t) {
                 int32_t d, m, c;
                 if (homo) nw.run(q, qlen, hm[t].data(), (int)hm[t].size(), d, m, c);
                 else nw.run(q, qlen, tmpl[t], tlen[t], d, m, c);
-                const int64_t o = s * T + t;
+                const int64_t o = pair_tmpl ? s : s * T + t;
                 if (dist) dist[o] = d;
                 matches[o] = m;
                 columns[o] = c;

@@ -102,8 +102,8 @@ def load():
     L.sd_nw_identity_batch.argtypes = [P(C.c_char_p), P(C.c_int32), P(C.c_char_p), P(C.c_int32),
                                        C.c_int64, C.c_int32, P(C.c_int32), P(C.c_int32), P(C.c_int32)]
     L.sd_identity_segments.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
-                                       P(C.c_char_p), P(C.c_int32), C.c_int32, C.c_int32, C.c_int32,
-                                       C.c_void_p, C.c_void_p, C.c_void_p]
+                                       P(C.c_char_p), P(C.c_int32), C.c_int32, C.c_void_p, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.sd_chunk_table_size.restype = C.c_int64
     L.sd_chunk_table_size.argtypes = [P(C.c_int64), C.c_int32, C.c_int32, C.c_int32]
     L.sd_decompose_chunk_range.argtypes = [P(C.c_char_p), P(C.c_int64), C.c_int32, P(C.c_char_p), P(C.c_int32),
@@ -339,9 +339,10 @@ def nw_identity_batch(queries, targets, threads=1):
     return [(d[i], m[i], c[i]) for i in range(n)]
 
 
-def identity_segments(seq, starts, ends, templates, homo=False, threads=1):
+def identity_segments(seq, starts, ends, templates, homo=False, threads=1, pair_tmpl=None):
     """(dist, matches, columns) int32 arrays of shape [n_segments, n_templates]: every segment
-    seq[starts[s] .. ends[s]] (inclusive) against every template (main.py:107-150 all-vs-all)."""
+    seq[starts[s] .. ends[s]] (inclusive) against every template (main.py:107-150 all-vs-all);
+    with pair_tmpl (template index per segment) arrays of shape [n_segments]: that pair only."""
     import numpy as np
     L = load()
     sb = _b(seq)
@@ -351,12 +352,14 @@ def identity_segments(seq, starts, ends, templates, homo=False, threads=1):
     tb = [_b(t) for t in templates]
     T = len(tb)
     tl = (C.c_int32 * max(T, 1))(*[len(t) for t in tb])
-    d = np.zeros((n, T), dtype=np.int32)
-    m = np.zeros((n, T), dtype=np.int32)
-    c = np.zeros((n, T), dtype=np.int32)
+    pt = None if pair_tmpl is None else np.ascontiguousarray(pair_tmpl, dtype=np.int32)
+    shape = (n, T) if pt is None else (n,)
+    d = np.zeros(shape, dtype=np.int32)
+    m = np.zeros(shape, dtype=np.int32)
+    c = np.zeros(shape, dtype=np.int32)
     rc = L.sd_identity_segments(sb, len(sb), st.ctypes.data, en.ctypes.data, n, _strs(tb), tl, T,
-                                1 if homo else 0, threads, d.ctypes.data, m.ctypes.data,
-                                c.ctypes.data)
+                                None if pt is None else pt.ctypes.data, 1 if homo else 0, threads,
+                                d.ctypes.data, m.ctypes.data, c.ctypes.data)
     if rc != SD_OK:
         raise SdError(rc, "sd_identity_segments")
     return d, m, c

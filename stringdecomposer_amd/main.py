@@ -166,10 +166,13 @@ def convert_read(decomposition, read, monomers, light, threads, coef):
         return res
     if light:
         by_name = {}
-        for m in monomers:
-            by_name[m.name] = m  # the reference keeps the last monomer of a given name
-        pairs = [(read.seq[d["start"]:d["end"] + 1], by_name[d["m"]].seq) for d in decomposition]
-        scores = aai_batch(pairs, threads)
+        for x, m in enumerate(monomers):
+            by_name[m.name] = x  # the reference keeps the last monomer of a given name
+        starts = np.array([d["start"] for d in decomposition], dtype=np.int64)
+        ends = np.array([d["end"] for d in decomposition], dtype=np.int64)
+        pair = np.array([by_name[d["m"]] for d in decomposition], dtype=np.int32)
+        scores = _identity_percent(*lib.identity_segments(read.seq, starts, ends, [m.seq for m in monomers],
+                                                          False, threads, pair_tmpl=pair)).tolist()
         for d, sc in zip(decomposition, scores):
             res.append({"m": d["m"], "start": str(d["start"]), "end": str(d["end"]), "score": sc,
                         "second_best": "None", "second_best_score": -1,
