@@ -612,7 +612,7 @@ int sd_engine_info(sd_engine* e, int64_t info[8]) {
     info[1] = e->sumL;
     info[2] = (int64_t)e->chunks.size();
     info[3] = e->rows;
-    info[4] = e->family | ((e->family == 1 ? 0 : e->fplan.wide ? 3 : e->fplan.f16 ? 2 : 1) << 8);
+    info[4] = e->family | ((e->family == 1 ? 0 : e->fplan.wide ? (e->fplan.f16 ? 4 : 3) : e->fplan.f16 ? 2 : 1) << 8);
     info[5] = e->family == 1 ? e->Q : e->fplan.P;
     info[6] = (int64_t)e->workspace_bytes();
     info[7] = e->family == 1 ? (int64_t)e->subs.size() : 1;

@@ -48,70 +48,6 @@ namespace sd {
 // folds the last two maxima:  u = max(S[x-1], KB);  v = u + tbl;  S_new[x] = max3(S_new[x-1], v, S[x])
 // -- 3 packed ops per cell pair instead of 4.  fast_plan_build() enables it when the score range
 // fits (FastPlan::f16); the checkpoints then hold fp16 pairs (the traceback converts them).
-template <bool F16>
-struct CellOps {
-    static constexpr uint32_t NEG = F16 ? 0xFC00FC00u : NEG2;
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ uint32_t mx(uint32_t a, uint32_t b) {
-        if constexpr (F16) {
-            return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_bit_cast(h2, a),
-                                                                              __builtin_bit_cast(h2, b)));
-        } else {
-            return pk_max(a, b);
-        }
-    }
-    static __device__ __forceinline__ uint32_t mx3(uint32_t a, uint32_t b, uint32_t c) {
-        return __builtin_bit_cast(
-            uint32_t, __builtin_elementwise_maximum(
-                          __builtin_elementwise_maximum(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b)),
-                          __builtin_bit_cast(h2, c)));
-    }
-    static __device__ __forceinline__ uint32_t add(uint32_t a, uint32_t b) {
-        if constexpr (F16) {
-            return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, a) + __builtin_bit_cast(h2, b));
-        } else {
-            return pk_adds(a, b);
-        }
-    }
-    static __device__ __forceinline__ uint32_t sub(uint32_t a, uint32_t b) {
-        if constexpr (F16) return add(a, b ^ 0x80008000u);
-        else return pk_subs(a, b);
-    }
-    // {x, x}
-    static __device__ __forceinline__ uint32_t splat(int x) {
-        if constexpr (F16) {
-            const float f = (float)x;
-            return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(f, f));
-        } else {
-            return pack2(x);
-        }
-    }
-    // host-built packed int16 constant -> cell format (anything <= -30000 is "-inf")
-    static __device__ __forceinline__ uint32_t from_i16x2(uint32_t w) {
-        if constexpr (F16) {
-            const int lo = (int)(short)(w & 0xffffu), hi = (int)w >> 16;
-            const float fl = lo <= -30000 ? -__builtin_inff() : (float)lo;
-            const float fh = hi <= -30000 ? -__builtin_inff() : (float)hi;
-            return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(fl, fh));
-        } else {
-            return w;
-        }
-    }
-    // the two cells of a word as (saturated) integers
-    static __device__ __forceinline__ void to_int(uint32_t w, int& lo, int& hi) {
-        if constexpr (F16) {
-            uint32_t a, b;
-            asm("v_cvt_i16_f16_e32 %0, %1" : "=v"(a) : "v"(w));
-            asm("v_cvt_i16_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(b) : "v"(w));
-            lo = (int)(short)(a & 0xffffu);
-            hi = (int)(short)(b & 0xffffu);
-        } else {
-            lo = (int)(short)(w & 0xffffu);
-            hi = (int)w >> 16;
-        }
-    }
-};
-
 template <int P, bool RANKED, bool F16>
 __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
@@ -668,8 +604,27 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         const int G = P / 16;
         const int xd = sc.mismatch - sc.del - sc.ins, md = sc.match - sc.del - sc.ins;
         if (xd < -127 || xd > 127 || md < -127 || md > 127) { why = "scores too large for the int8 table"; return false; }
-        plan.table.assign((size_t)5 * G * 512, 0x80808080u);
+        // fp16 cells (4 ops per slot instead of 5): the table bytes are bf8 (E5M2: sign, 5 exponent and
+        // 2 mantissa bits), which one gfx950 instruction expands to a packed fp16 pair; usable when both
+        // table values are exactly representable (|v| = 1.mm * 2^e) and the score range fits fp16
+        auto bf8_of = [](int v, bool& ok) -> int {
+            if (v == 0) return 0;
+            const int a = v < 0 ? -v : v;
+            int e = 0;
+            while ((a >> (e + 1)) != 0) ++e;
+            const int m4 = (a << 2) >> e;   // 4 * a / 2^e, in [4, 8)
+            if (((m4 << e) >> 2) != a || (e > 2 && (a & ((1 << (e - 2)) - 1)) != 0)) ok = false;
+            return (v < 0 ? 0x80 : 0) | ((e + 15) << 2) | (m4 & 3);
+        };
+        bool bf_ok = true;
+        const int xb = bf8_of(xd, bf_ok), mb = bf8_of(md, bf_ok);
+        {
+            const char* force = getenv("SD_FILL_CELLS");
+            plan.f16 = bf_ok && ub <= 2040 && !(force && force[0] == 'i');
+        }
+        plan.table.assign((size_t)5 * G * 512, plan.f16 ? 0xFCFCFCFCu : 0x80808080u);
         auto putb = [&](int grp, int v, int slot16, int val) {
+            if (plan.f16) val = val == md ? mb : xb;
             const int plane = v >> 6, lane = v & 63, h = slot16 >> 3, d = (slot16 & 7) >> 1, odd = slot16 & 1;
             uint32_t& w = plan.table[(((size_t)grp * 2 + h) * 64 + lane) * 4 + d];
             const int sh = 16 * odd + 8 * plane;

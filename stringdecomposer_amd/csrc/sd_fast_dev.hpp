@@ -77,6 +77,73 @@ __device__ __forceinline__ int wave_prefix_max(int v) {
     return v;
 }
 
+// Cell arithmetic of the fill kernels: packed int16 (saturating) or packed fp16 holding exact integers.
+// gfx950 has a packed three-input maximum only for fp16 (v_pk_maximum3_f16), which folds the last two
+// maxima of the cell update:  u = max(S[x-1], KB);  v = u + tbl;  S_new[x] = max3(S_new[x-1], v, S[x]).
+template <bool F16>
+struct CellOps {
+    static constexpr uint32_t NEG = F16 ? 0xFC00FC00u : NEG2;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ uint32_t mx(uint32_t a, uint32_t b) {
+        if constexpr (F16) {
+            return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_bit_cast(h2, a),
+                                                                              __builtin_bit_cast(h2, b)));
+        } else {
+            return pk_max(a, b);
+        }
+    }
+    static __device__ __forceinline__ uint32_t mx3(uint32_t a, uint32_t b, uint32_t c) {
+        return __builtin_bit_cast(
+            uint32_t, __builtin_elementwise_maximum(
+                          __builtin_elementwise_maximum(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b)),
+                          __builtin_bit_cast(h2, c)));
+    }
+    static __device__ __forceinline__ uint32_t add(uint32_t a, uint32_t b) {
+        if constexpr (F16) {
+            return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, a) + __builtin_bit_cast(h2, b));
+        } else {
+            return pk_adds(a, b);
+        }
+    }
+    static __device__ __forceinline__ uint32_t sub(uint32_t a, uint32_t b) {
+        if constexpr (F16) return add(a, b ^ 0x80008000u);
+        else return pk_subs(a, b);
+    }
+    // {x, x}
+    static __device__ __forceinline__ uint32_t splat(int x) {
+        if constexpr (F16) {
+            const float f = (float)x;
+            return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(f, f));
+        } else {
+            return pack2(x);
+        }
+    }
+    // host-built packed int16 constant -> cell format (anything <= -30000 is "-inf")
+    static __device__ __forceinline__ uint32_t from_i16x2(uint32_t w) {
+        if constexpr (F16) {
+            const int lo = (int)(short)(w & 0xffffu), hi = (int)w >> 16;
+            const float fl = lo <= -30000 ? -__builtin_inff() : (float)lo;
+            const float fh = hi <= -30000 ? -__builtin_inff() : (float)hi;
+            return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(fl, fh));
+        } else {
+            return w;
+        }
+    }
+    // the two cells of a word as (saturated) integers
+    static __device__ __forceinline__ void to_int(uint32_t w, int& lo, int& hi) {
+        if constexpr (F16) {
+            uint32_t a, b;
+            asm("v_cvt_i16_f16_e32 %0, %1" : "=v"(a) : "v"(w));
+            asm("v_cvt_i16_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(b) : "v"(w));
+            lo = (int)(short)(a & 0xffffu);
+            hi = (int)(short)(b & 0xffffu);
+        } else {
+            lo = (int)(short)(w & 0xffffu);
+            hi = (int)w >> 16;
+        }
+    }
+};
+
 // acc[lane == slot] = value (wave-uniform value and slot): one v_mov + one v_cndmask with a
 // scalar one-hot mask instead of v_mov + v_cmp + v_cndmask
 __device__ __forceinline__ void acc_put(int& acc, int value, int slot) {

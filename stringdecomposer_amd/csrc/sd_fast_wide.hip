@@ -34,9 +34,19 @@ __device__ __forceinline__ uint32_t add_b8(uint32_t u, uint32_t tb, int pair) {
     return v;
 }
 
+// fp16 variant: the byte pair of a slot holds bf8 (E5M2) values; one gfx950 instruction turns it into
+// the packed fp16 pair {lo plane, hi plane} (exact for the small integers of a score table, -inf pads)
+__device__ __forceinline__ uint32_t cvt_bf8x2(uint32_t tb, int pair) {
+    uint32_t v;
+    const float one = 1.0f;
+    if (pair == 0) asm("v_cvt_scalef32_pk_f16_bf8 %0, %1, %2" : "=v"(v) : "v"(tb), "v"(one));
+    else asm("v_cvt_scalef32_pk_f16_bf8 %0, %1, %2 op_sel:[1,0,0]" : "=v"(v) : "v"(tb), "v"(one));
+    return v;
+}
+
 }  // namespace
 
-template <int P, bool RANKED>
+template <int P, bool RANKED, bool F16>
 __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
@@ -52,10 +62,16 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
         *reinterpret_cast<uint4*>(&lds[idx]) = *reinterpret_cast<const uint4*>(&table[idx]);
     __syncthreads();
 
+    using CO = CellOps<F16>;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nw = (int)(blockDim.x >> 6);
     const int lane = threadIdx.x & 63;
     (void)wave; (void)nw;
+    // table value of a slot added to u: two SDWA byte adds (int8 table) or convert + packed add (bf8 table)
+    auto add_tbl = [&](uint32_t u, uint32_t tb, int pair) {
+        if constexpr (F16) return CO::add(u, cvt_bf8x2(tb, pair));
+        else return add_b8(u, tb, pair);
+    };
     ChunkSched sched;
     sched.init(queue, order, n_chunks);
     for (int c = sched.next(); c >= 0; c = sched.next()) {
@@ -67,10 +83,10 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
     const uint32_t* lc = lane_consts + lane * FAST_LANE_WORDS;
     const uint32_t endOffPlan = lc[FLC_ENDOFF];
     // --ed_thr: per-chunk end offsets (-inf for dropped templates) and tie-break ranks
-    const uint32_t endOff = RANKED ? cendoff[(size_t)c * 64 + lane] : endOffPlan;
+    const uint32_t endOff = CO::from_i16x2(RANKED ? cendoff[(size_t)c * 64 + lane] : endOffPlan);
     const uint32_t rank2 = RANKED ? crank[(size_t)c * 64 + lane] : 0u;
-    const uint32_t row0adj = lc[FLC_ROW0];
-    const uint32_t ins2 = pack2(sc.ins);
+    const uint32_t row0adj = CO::from_i16x2(lc[FLC_ROW0]);
+    const uint32_t ins2 = CO::splat(sc.ins);
 
     int32_t* Bc = Bout + cd.row0 + (uint64_t)c;
     uint32_t* ck = ckpt + (uint64_t)cd.pad * (uint64_t)(P * 64) + lane;
@@ -90,9 +106,9 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
         tbg[buf][4] = q1.x; tbg[buf][5] = q1.y; tbg[buf][6] = q1.z; tbg[buf][7] = q1.w;
     };
     auto reduce_ends = [&](uint32_t Eend, int row) {
-        const uint32_t val = pk_adds(Eend, endOff);
-        const int lo = (int)(short)(val & 0xffffu);
-        const int hi = (int)val >> 16;
+        const uint32_t val = CO::add(Eend, endOff);
+        int lo, hi;
+        CO::to_int(val, lo, hi);
         const int b = wave_max(max(lo, hi));
         unsigned long long mlo, mhi;
         if (RANKED) {
@@ -127,8 +143,8 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int q = 16 * g + s;
-                const uint32_t t16 = add_b8(q == 0 ? row0adj : ins2, tbg[0][s >> 1], s & 1);
-                run = q == 0 ? t16 : pk_max(run, t16);
+                const uint32_t t16 = add_tbl(q == 0 ? row0adj : ins2, tbg[0][s >> 1], s & 1);
+                run = q == 0 ? t16 : CO::mx(run, t16);
                 L[q] = run;
             }
             pin = run;
@@ -142,21 +158,46 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
         const int rcur = rnext;
         if ((i & (FAST_R - 1)) == 0) {
             if ((i & (FAST_REBASE - 1)) == 0) {
-                const uint32_t d2 = pack2(Brel - tp * sc.ins);
+                const uint32_t d2 = CO::splat(Brel - tp * sc.ins);
                 base += Brel;
                 Brel = 0;
                 tp = 0;
 #pragma unroll
-                for (int s = 0; s < P; ++s) L[s] = pk_subs(L[s], d2);
+                for (int s = 0; s < P; ++s) L[s] = CO::sub(L[s], d2);
             }
             const int q = (i / FAST_R) - 1;
 #pragma unroll
             for (int s = 0; s < P; ++s) ck[(uint64_t)q * (P * 64) + s * 64] = L[s];
             if (lane == 0) ckb[q] = base + tp * sc.ins;
         }
-        uint32_t KB = pack2(Brel + sc.del - tp * sc.ins);  // kept in a VGPR: see the per-step pin below
+        uint32_t KB = CO::splat(Brel + sc.del - tp * sc.ins);  // kept in a VGPR: see the per-step pin below
         uint32_t u_[P], v_[P], c_[P];
         uint32_t run = 0;
+        if constexpr (F16) {
+            // 4 ops per slot: u = max(S[x-1], KB); t = cvt(bf8 pair); v = u + t; S'[x] = max3(S'[x-1], v, S[x])
+            uint32_t t_[P];
+#pragma unroll
+            for (int s = 0; s < P + 4; ++s) {
+                if (s >= 4) {
+                    const int q = s - 4;
+                    L[q] = q == 0 ? v_[0] : CO::mx3(L[q - 1], v_[q], L[q]);  // k == 0: start term only
+                }
+                if (s >= 2 && s - 2 < P) {
+                    const int q = s - 2;
+                    v_[q] = CO::add(u_[q], t_[q]);
+                }
+                if (s < P) {
+                    const int q = s;
+                    u_[q] = q == 0 ? KB : CO::mx(L[q - 1], KB);
+                    t_[q] = cvt_bf8x2(tbg[(q >> 4) & 1][(q & 15) >> 1], q & 1);
+                    if ((q & 15) == 2 && (q >> 4) + 1 < G) load_group(rcur, (q >> 4) + 1, ((q >> 4) + 1) & 1, t_[q]);
+                }
+                uint32_t& pinL = L[s >= 4 ? s - 4 : 0];
+                asm volatile("" : "+v"(KB), "+v"(pinL));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            (void)c_; (void)run;
+        } else {
 #pragma unroll
         for (int s = 0; s < P + 3; ++s) {
             if (s >= 3) {
@@ -184,6 +225,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
             asm volatile("" : "+v"(KB), "+v"(run));
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
         rnext = rs.code(i + 1);
         rs.advance(i + 1);
         load_group(rnext, 0, 0, L[P - 1]);
@@ -202,17 +244,21 @@ void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc
     const int grid = std::min((n_chunks + NW - 1) / NW, n_cu);  // persistent: one workgroup per CU (LDS)
     const size_t lds = (size_t)5 * (plan.P / 16) * 512 * sizeof(uint32_t);
     const bool ranked = cendoff != nullptr;
-#define SD_FILLW_K(PP, RK)                                                                           \
+#define SD_FILLW_K(PP, RK, HF)                                                                       \
     {                                                                                                \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill_wide<PP, RK>),         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill_wide<PP, RK, HF>),     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-        hipLaunchKernelGGL((sd_fast_fill_wide<PP, RK>), dim3(grid), dim3(NW * 64), lds, st, chunks,   \
-                           n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt, ckbase, queue,  \
-                           order, cendoff, crank);                                                   \
+        hipLaunchKernelGGL((sd_fast_fill_wide<PP, RK, HF>), dim3(grid), dim3(NW * 64), lds, st,       \
+                           chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt, ckbase, \
+                           queue, order, cendoff, crank);                                            \
     }
 #define SD_FILLW(PP)                                                                                 \
     case PP:                                                                                         \
-        if (ranked) SD_FILLW_K(PP, true) else SD_FILLW_K(PP, false)                                  \
+        if (plan.f16) {                                                                              \
+            if (ranked) SD_FILLW_K(PP, true, true) else SD_FILLW_K(PP, false, true)                  \
+        } else {                                                                                     \
+            if (ranked) SD_FILLW_K(PP, true, false) else SD_FILLW_K(PP, false, false)                \
+        }                                                                                            \
         break;
     switch (plan.P) {
         SD_FILLW(80) SD_FILLW(96) SD_FILLW(112) SD_FILLW(128) SD_FILLW(144) SD_FILLW(160)

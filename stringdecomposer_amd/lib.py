@@ -269,7 +269,7 @@ class Engine:
         self.L.sd_engine_info(self.h, v)
         return {"n_templates": v[0], "sum_template_len": v[1], "n_chunks": v[2], "rows": v[3],
                 "family": {1: "generic", 2: "fast"}.get(v[4] & 0xff, "?"),
-                "cells": {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table"}.get(v[4] >> 8, "?"),
+                "cells": {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table", 4: "f16/bf8-table"}.get(v[4] >> 8, "?"),
                 "cells_per_lane": v[5],
                 "workspace_bytes": v[6], "fill_launches": v[7]}
 

@@ -195,6 +195,7 @@ def test_64_monomer_set_wide_layout(oracle):
     for sc in [(-1, -1, -1, 1), (-2, -3, -4, 2)]:
         e = lib.Engine(ms, scoring=sc, kernel=lib.KERNEL_FAST)
         assert e.info()["cells_per_lane"] >= 176
+        assert e.info()["cells"] == "f16/bf8-table"   # default scoring: table values 3 and 1 are exact in bf8
         e.load_reads(rs)
         e.run()
         got = e.fetch()
