@@ -62,6 +62,10 @@ typedef struct sd_rec {
 const char* sd_version(void);
 int sd_device_count(void);           /* number of visible HIP devices (0 if none / no runtime)   */
 void sd_free(void* p);               /* frees anything this library returned                     */
+/* Engines return their large device buffers to a process-wide cache instead of the driver (hipMalloc /
+ * hipFree of the multi-GB workspaces can take longer than the kernels); this hands the cached buffers
+ * back.  Environment SD_DEVICE_POOL=0 disables the cache. */
+void sd_release_cache(void);
 
 /* ---- one-shot entry points (replace main.py:194) ------------------------------------------- */
 

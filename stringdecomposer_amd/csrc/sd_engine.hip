@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
+#include <chrono>
 #include <functional>
 #include <cstdlib>
 #include <cstring>
@@ -38,12 +40,61 @@ struct HipFail {
             throw HipFail{std::string(#call) + ": " + hipGetErrorString(_e)};               \
     } while (0)
 
+// Process-wide cache of large device buffers.  hipMalloc / hipFree of the multi-GB workspaces
+// (checkpoints: ~280 B per chunk row) cost anything from 10 ms to more than a second per call, so
+// engines hand their big buffers back to this pool instead of the driver and the next engine (the
+// next sd_decompose / chunk-range call of the process) takes them from here.  sd_release_cache()
+// returns everything to the driver; SD_DEVICE_POOL=0 disables the cache.
+struct DevPool {
+    struct Block { int dev; void* p; size_t bytes; };
+    std::mutex m;
+    std::vector<Block> blocks;
+    static constexpr size_t kMin = (size_t)4 << 20;  // smaller buffers are cheap: plain hipMalloc / hipFree
+    static bool enabled() {
+        static const bool on = [] { const char* e = getenv("SD_DEVICE_POOL"); return !(e && e[0] == '0'); }();
+        return on;
+    }
+    void* take(int dev, size_t bytes, size_t& got) {
+        std::lock_guard<std::mutex> g(m);
+        size_t best = blocks.size();
+        for (size_t i = 0; i < blocks.size(); ++i)
+            if (blocks[i].dev == dev && blocks[i].bytes >= bytes && blocks[i].bytes <= 2 * bytes + ((size_t)64 << 20) &&
+                (best == blocks.size() || blocks[i].bytes < blocks[best].bytes))
+                best = i;
+        if (best == blocks.size()) return nullptr;
+        void* p = blocks[best].p;
+        got = blocks[best].bytes;
+        blocks.erase(blocks.begin() + (long)best);
+        return p;
+    }
+    void give(int dev, void* p, size_t bytes) {
+        std::lock_guard<std::mutex> g(m);
+        blocks.push_back(Block{dev, p, bytes});
+    }
+    void release_all() {
+        std::lock_guard<std::mutex> g(m);
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (const Block& b : blocks) {
+            (void)hipSetDevice(b.dev);
+            (void)hipFree(b.p);
+        }
+        blocks.clear();
+        (void)hipSetDevice(cur);
+    }
+};
+DevPool g_pool;
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    int dev = 0;
     void free_() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            if (DevPool::enabled() && cap * sizeof(T) >= DevPool::kMin) g_pool.give(dev, p, cap * sizeof(T));
+            else (void)hipFree(p);
+        }
         p = nullptr;
         n = 0;
         cap = 0;
@@ -53,8 +104,22 @@ struct DevBuf {
         if (count == 0) count = 1;
         if (count > cap) {
             free_();
-            SD_HIP(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
-            cap = count;
+            SD_HIP(hipGetDevice(&dev));
+            const size_t bytes = count * sizeof(T);
+            size_t got = 0;
+            void* q = (DevPool::enabled() && bytes >= DevPool::kMin) ? g_pool.take(dev, bytes, got) : nullptr;
+            if (q) {
+                p = static_cast<T*>(q);
+                cap = got / sizeof(T);
+            } else {
+                hipError_t er = hipMalloc(reinterpret_cast<void**>(&p), bytes);
+                if (er != hipSuccess) {  // give the cached blocks back to the driver and retry once
+                    (void)hipGetLastError();
+                    g_pool.release_all();
+                    SD_HIP(hipMalloc(reinterpret_cast<void**>(&p), bytes));
+                }
+                cap = count;
+            }
         }
         n = count;
     }
@@ -669,8 +734,18 @@ static int run_chunk_batches(const std::vector<ReadView>& reads, const std::vect
                              const BatchSink& sink) {
     char eb[1024] = {0};
     sd_engine* eng = nullptr;
+    const bool timing = getenv("SD_TIMING") != nullptr;  // developer knob: stage times on stderr
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const double t = now();
+        std::fprintf(stderr, "[sd timing] %-28s %8.3f ms\n", what, (t - t_prev) * 1e3);
+        t_prev = t;
+    };
     int rc = sd_engine_create(&eng, p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size(), eb, sizeof eb);
     if (rc) { err = eb; return rc; }
+    lap("engine create");
     // default: batches of <= 48 M rows (~900 reads of 50 kb): large enough to fill the GPU twice over,
     // small enough that the host/device pipeline below has stages to overlap and buffers are reused
     int64_t row_budget = (int64_t)48 << 20;
@@ -712,13 +787,17 @@ static int run_chunk_batches(const std::vector<ReadView>& reads, const std::vect
         if (r2 == SD_OK) r2 = sd_engine_run(engs[b & 1], streams[b & 1], eb, sizeof eb);
         return r2;
     };
+    lap("second engine, streams");
     if (!batches.empty()) rc = submit(0);
+    lap("submit batch 0");
     for (size_t b = 0; b < batches.size() && rc == SD_OK; ++b) {
-        if (b + 1 < batches.size()) rc = submit(b + 1);
+        if (b + 1 < batches.size()) { rc = submit(b + 1); lap("submit next batch"); }
         sd_rec* recs = nullptr; int64_t* roff = nullptr;
         if (rc == SD_OK) rc = sd_engine_fetch(engs[b & 1], &recs, &roff, eb, sizeof eb);
+        lap("fetch");
         if (rc == SD_OK) sink(batches[b].first, batches[b].second, recs, roff);
         std::free(recs); std::free(roff);
+        lap("sink (assemble/format)");
     }
     if (rc != SD_OK) (void)hipDeviceSynchronize();  // nothing may still be running on buffers we free
     for (hipStream_t st : streams)
@@ -726,6 +805,7 @@ static int run_chunk_batches(const std::vector<ReadView>& reads, const std::vect
     if (eng2) sd_engine_destroy(eng2);
     if (rc) err = eb;
     sd_engine_destroy(eng);
+    lap("destroy engines");
     return rc;
 }
 
@@ -764,13 +844,27 @@ struct ReadAssembler {
                 chunks_seen = 0;
             }
         }
-        std::vector<std::string> parts(done_ids.size());
-        sd::parallel_for((int64_t)done_ids.size(), threads, 4, [&](int64_t q) {
-            sd::seam_merge(done_rows[(size_t)q]);
-            const ReadView& rd = reads[done_ids[(size_t)q]];
-            sd::format_rows(parts[(size_t)q], rd.name, rd.name_len, tnames, done_rows[(size_t)q].data(),
-                            done_rows[(size_t)q].size());
+        sd::parallel_for((int64_t)done_ids.size(), threads, 4,
+                         [&](int64_t q) { sd::seam_merge(done_rows[(size_t)q]); });
+        // text in slices of 32 k rows, so that one huge read (a whole chromosome) is formatted by all
+        // host threads as well; a slice only needs the end of the row before it (SaveBatch's prev_end)
+        struct Slice { size_t q, r0, r1; };
+        std::vector<Slice> slices;
+        const size_t step = 32768;
+        for (size_t q = 0; q < done_ids.size(); ++q)
+            for (size_t r0 = 0; r0 < done_rows[q].size(); r0 += step)
+                slices.push_back(Slice{q, r0, std::min(done_rows[q].size(), r0 + step)});
+        std::vector<std::string> parts(slices.size());
+        sd::parallel_for((int64_t)slices.size(), threads, 1, [&](int64_t x) {
+            const Slice& sl = slices[(size_t)x];
+            const ReadView& rd = reads[done_ids[sl.q]];
+            const std::vector<sd_rec>& rows = done_rows[sl.q];
+            sd::format_rows(parts[(size_t)x], rd.name, rd.name_len, tnames, rows.data() + sl.r0, sl.r1 - sl.r0,
+                            sl.r0 ? rows[sl.r0 - 1].end : 0);
         });
+        size_t total = tsv.size();
+        for (const std::string& part : parts) total += part.size();
+        tsv.reserve(std::max(total, tsv.capacity()));
         for (const std::string& part : parts) tsv += part;
     }
 };
@@ -865,6 +959,8 @@ int sd_decompose_files(const char* reads_fa, const char* monomers_fa, const sd_p
 // -------------------------------------------------------------------------------------------
 // chunk-range form: multi-GPU sharding of one job, one process per GPU
 // -------------------------------------------------------------------------------------------
+void sd_release_cache(void) { g_pool.release_all(); }
+
 int64_t sd_chunk_table_size(const int64_t* read_lens, int32_t n_reads, int32_t part_size, int32_t overlap) {
     if (!read_lens || n_reads < 0 || part_size <= 0 || overlap < 0) return -1;
     int64_t n = 0;

@@ -164,8 +164,8 @@ inline void put_int(std::string& o, int64_t v) {
 // identity is an integer-valued float (|v| < 1e6 < 2^24 by the range check in the engine), so
 // "%f" is exactly "<int>.000000".
 inline void format_rows(std::string& o, const char* read_name, size_t read_name_len,
-                        const std::vector<std::string>& tnames, const sd_rec* rows, size_t n) {
-    int prev_end = 0;
+                        const std::vector<std::string>& tnames, const sd_rec* rows, size_t n,
+                        int prev_end = 0) {  // prev_end: end of the row before rows[0] (0 at a read's start)
     for (size_t x = 0; x < n; ++x) {
         const sd_rec& r = rows[x];
         o.append(read_name, read_name_len);

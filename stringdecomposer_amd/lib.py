@@ -30,7 +30,7 @@ EXPORTS = [
     "sd_engine_run", "sd_engine_fetch", "sd_engine_assemble", "sd_engine_timings",
     "sd_engine_info", "sd_chunk_plan", "sd_seam_merge", "sd_format_rows", "sd_fasta_load",
     "sd_fasta_free", "sd_nw_identity_batch", "sd_identity_segments", "sd_chunk_table_size",
-    "sd_decompose_chunk_range", "sd_assemble_tsv",
+    "sd_decompose_chunk_range", "sd_assemble_tsv", "sd_release_cache",
 ]
 
 
@@ -137,6 +137,11 @@ def make_params(scoring=(-1, -1, -1, 1), part_size=5000, overlap=500, ed_thr=-1,
     p.threads, p.device, p.kernel = int(threads), int(device), int(kernel)
     p.max_batch_rows = int(max_batch_rows)
     return p
+
+
+def release_cache():
+    """Return the library's cached device buffers to the driver."""
+    load().sd_release_cache()
 
 
 def device_count():
