@@ -77,6 +77,16 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=32)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started without the launcher: run it as a child process (nothing has touched the GPU yet)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
     rank, local_rank, ws = shard.world()
     if args.gpus != ws and ws > 1:
