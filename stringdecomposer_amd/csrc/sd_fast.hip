@@ -694,7 +694,10 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
                       uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order, int n_cu,
                       const uint32_t* cendoff, const uint32_t* crank) {
     const int NW = SD_FILL_NW;
-    const int grid = std::min((n_chunks + NW - 1) / NW, (16 / NW) * n_cu);  // persistent: 16 waves per CU
+    #ifndef SD_FILL_WPC
+#define SD_FILL_WPC 16   // resident fill waves per CU (4 per SIMD)
+#endif
+    const int grid = std::min((n_chunks + NW - 1) / NW, (SD_FILL_WPC / NW) * n_cu);  // persistent
     (void)hipMemsetAsync(queue, 0, sizeof(int), st);
     if (plan.wide) {
         launch_fast_fill_wide(plan, st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt,
