@@ -89,7 +89,11 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     const uint32_t cont2Mask = lc[FLC_CONT2];
     const uint32_t endOffPlan = lc[FLC_ENDOFF];
     // --ed_thr: per-chunk end offsets (-inf for dropped templates) and tie-break ranks
-    const uint32_t endOff = CO::from_i16x2(RANKED ? cendoff[(size_t)c * 64 + lane] : endOffPlan);
+    // fp16, unranked: the whole B reduction stays in fp16 (no per-row int conversions); `del` is folded
+    // into the end offsets so that the wave maximum is directly the start term B_i + del of the next row
+    constexpr bool HRED = F16 && !RANKED;
+    const uint32_t endOff = HRED ? CO::from_i16x2(pk_adds(endOffPlan, pack2(sc.del)))
+                                 : CO::from_i16x2(RANKED ? cendoff[(size_t)c * 64 + lane] : endOffPlan);
     const uint32_t rank2 = RANKED ? crank[(size_t)c * 64 + lane] : 0u;
     const uint32_t row0adj = CO::from_i16x2(lc[FLC_ROW0]);
     const uint32_t ins2 = CO::splat(sc.ins);
@@ -102,6 +106,7 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     uint32_t tb[P4];
     uint32_t K = NEGC;
     int base = 0, Brel = 0, tp = 0;
+    uint32_t bdel16 = 0;  // HRED: fp16 bits of (row maximum + del), relative like the cells
     int accBV = 0;  // (B << 7 | arg-max virtual lane) of the last <=64 rows, one row per lane
 
     // `after` pins the LDS reads behind the value it names (the last slot of the row being
@@ -130,6 +135,41 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     };
     // B_{row} (relative to base) = max over template ends; arg = smallest virtual lane attaining it
     auto reduce_ends = [&](uint32_t Eend, int row) {
+        if constexpr (HRED) {
+            const uint32_t val = CO::add(Eend, endOff);
+            uint32_t m;
+            asm("v_max_f16_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+                "s_nop 1\n\t"
+                "v_max_f16_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_max_f16_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_max_f16_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_max_f16_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_max_f16_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                "s_nop 1\n\t"
+                "v_max_f16_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                : "=&v"(m) : "v"(val));
+            const uint32_t b16 = (uint32_t)__builtin_amdgcn_readlane((int)m, 63) & 0xffffu;
+            unsigned long long mlo, mhi;
+            asm("v_cmp_eq_f16_e64 %0, %1, %2" : "=s"(mlo) : "v"(val), "s"(b16));
+            asm("v_cmp_eq_f16_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:WORD_0" : "=s"(mhi) : "v"(val), "s"(b16));
+            const int v = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
+            bdel16 = b16;
+            const int slot = (row - 1) & 63;
+            acc_put(accBV, (int)((b16 << 7) | (uint32_t)v), slot);
+            if (slot == 63 || row == n) {
+                // 64 rows at once: fp16 -> int, B = base + (b + del) - del + tp_row * ins
+                const uint32_t w = (uint32_t)accBV;
+                const int bi = (int)(float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 7));
+                const int tpl = tp - (slot - lane);
+                const int Bv = base + bi - sc.del + tpl * sc.ins;
+                if (lane <= slot) Bc[row - slot + lane] = (int)(((uint32_t)Bv << 7) | (w & 127u));
+            }
+            return;
+        }
         const uint32_t val = CO::add(Eend, endOff);
         int lo, hi;
         CO::to_int(val, lo, hi);
@@ -172,10 +212,14 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
         if ((i & (FAST_R - 1)) == 0) {
             if ((i & (FAST_REBASE - 1)) == 0) {
                 // rebase the int16 state on B_i and fold the row offset tp*ins back in
+                if constexpr (HRED)
+                    Brel = __builtin_amdgcn_readfirstlane((int)(float)__builtin_bit_cast(_Float16, (unsigned short)bdel16)) -
+                           sc.del + tp * sc.ins;
                 const uint32_t d2 = CO::splat(F16 ? -(Brel - tp * sc.ins) : Brel - tp * sc.ins);
                 base += Brel;
                 Brel = 0;
                 tp = 0;
+                if constexpr (HRED) bdel16 = __builtin_amdgcn_readfirstlane((int)(CO::splat(sc.del) & 0xffffu));
                 if constexpr (F16) {
                     K = bfi(startMask, NEGC, CO::add(K, d2));
                     Eend = CO::add(Eend, d2);
@@ -194,7 +238,13 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
             for (int s = 0; s < P; ++s) ck[(uint64_t)q * (P * 64) + s * 64] = CO::mx(L[s], K);
             if (lane == 0) ckb[q] = base + tp * sc.ins;
         }
-        const uint32_t KB = CO::mx(K, CO::splat(Brel + sc.del - tp * sc.ins));
+        uint32_t KB;
+        if constexpr (HRED) {
+            // max(K, {b+del, b+del}): the scalar's low half feeds both lanes of the packed op
+            asm("v_pk_max_f16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(KB) : "v"(K), "s"(bdel16));
+        } else {
+            KB = CO::mx(K, CO::splat(Brel + sc.del - tp * sc.ins));
+        }
         const uint32_t pd0 = bfi(startMask, NEGC, lane_up(Eend, 1));
         const uint32_t w0 = bfi(startMask, NEGC, L[0]);
         uint32_t u_[P], v_[P], c_[P];
