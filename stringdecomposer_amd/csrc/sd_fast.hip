@@ -92,7 +92,16 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     // fp16, unranked: the whole B reduction stays in fp16 (no per-row int conversions); `del` is folded
     // into the end offsets so that the wave maximum is directly the start term B_i + del of the next row
     constexpr bool HRED = F16 && !RANKED;
-    const uint32_t endOff = HRED ? CO::from_i16x2(pk_adds(endOffPlan, pack2(sc.del)))
+    // HRED row tail.  With a_l = max(last slot, K_l) the total of virtual lane l:
+    //   * the end cell of a template is the maximum of a_l over ALL its lanes (prefix maximum along the
+    //     template), so the B reduction takes every lane's total with its template's end offset
+    //     (FLC_ENDALL) and does not need the scanned value of the end lane;
+    //   * the carry K_l of the row (exclusive scan of a over the template's earlier lanes) is also the
+    //     true last-slot value of lane l-1, i.e. the diagonal input of slot 0 in the next row, and
+    //     KB = max(K, B+del) >= K: slot 0's u is KB itself;
+    //   * totals never decrease from row to row in the stored domain (the insertion move is "keep"),
+    //     so the new carry replaces the old one without a max.
+    const uint32_t endOff = HRED ? CO::from_i16x2(pk_adds(lc[FLC_ENDALL], pack2(sc.del)))
                                  : CO::from_i16x2(RANKED ? cendoff[(size_t)c * 64 + lane] : endOffPlan);
     const uint32_t rank2 = RANKED ? crank[(size_t)c * 64 + lane] : 0u;
     const uint32_t row0adj = CO::from_i16x2(lc[FLC_ROW0]);
@@ -204,9 +213,10 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     for (int q = 1; q < P; ++q) L[q] = CO::mx(L[q - 1], CO::add(tb[q], ins2));
     load_table(rs.code(1), L[P - 1]);
     rs.advance(1);
+    if constexpr (HRED) reduce_ends(L[P - 1], 1);
     K = excl_scan(L[P - 1]);
     uint32_t Eend = CO::mx(L[P - 1], K);
-    reduce_ends(Eend, 1);
+    if constexpr (!HRED) reduce_ends(Eend, 1);
 
     for (int i = 1; i < n; ++i) {
         if ((i & (FAST_R - 1)) == 0) {
@@ -245,7 +255,8 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
         } else {
             KB = CO::mx(K, CO::splat(Brel + sc.del - tp * sc.ins));
         }
-        const uint32_t pd0 = bfi(startMask, NEGC, lane_up(Eend, 1));
+        uint32_t pd0 = K;  // HRED: unused (slot 0's u is KB)
+        if constexpr (!HRED) pd0 = bfi(startMask, NEGC, lane_up(Eend, 1));
         const uint32_t w0 = bfi(startMask, NEGC, L[0]);
         uint32_t u_[P], v_[P], c_[P];
         uint32_t run = 0;
@@ -264,7 +275,8 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
                 }
                 if (s < P) {
                     const int q = s;
-                    u_[q] = CO::mx(q == 0 ? pd0 : L[q - 1], KB);
+                    if (HRED && q == 0) u_[q] = KB;
+                    else u_[q] = CO::mx(q == 0 ? pd0 : L[q - 1], KB);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -295,11 +307,16 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
         load_table(rs.code(i + 1), L[P - 1]);  // unconditional (clamped): keeps tb[] out of phi copies
         rs.advance(i + 1);
         const uint32_t a = CO::mx(L[P - 1], K);
-        const uint32_t X = excl_scan(a);
-        K = CO::mx(K, X);
-        Eend = CO::mx(a, X);
         ++tp;
-        reduce_ends(Eend, i + 1);
+        if constexpr (HRED) {
+            reduce_ends(a, i + 1);
+            K = excl_scan(a);
+        } else {
+            const uint32_t X = excl_scan(a);
+            K = CO::mx(K, X);
+            Eend = CO::mx(a, X);
+            reduce_ends(Eend, i + 1);
+        }
     }
     }  // chunk queue
 }
@@ -647,6 +664,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         put(lc[FLC_ROW0], plane, (j >= 0 && uidx[(size_t)v] == 0) ? sc.ins + sc.del : sc.ins);
         put(lc[FLC_TMPL], plane, j >= 0 ? j : 0xffff);
         put(lc[FLC_CONT2], plane, (j >= 0 && uidx[(size_t)v] >= 2) ? 0xffff : 0);
+        put(lc[FLC_ENDALL], plane, j >= 0 ? ((int)tseq[(size_t)j].size() - 1) * sc.del : NEG16);
     }
     if (wide) {
         // int8 table [5][G][2 halves][64 lanes][4 dwords]; dword d of half h of group g holds slots

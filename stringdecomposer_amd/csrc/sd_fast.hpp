@@ -31,6 +31,7 @@ enum FastLaneConst {
     FLC_ROW0,          // row-0 adjustment of slot 0: ins+del on start lanes, ins elsewhere
     FLC_TMPL,          // template index per plane (for the traceback: vlane -> template)
     FLC_CONT2,         // 0xffff where virtual lane v-2 belongs to the same template
+    FLC_ENDALL,        // (L-1)*del on EVERY virtual lane of a template, NEG on idle lanes
 };
 
 struct FastPlan {
