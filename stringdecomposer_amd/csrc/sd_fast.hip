@@ -267,7 +267,9 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
             for (int s = 0; s < P + 4; ++s) {
                 if (s >= 4) {
                     const int q = s - 4;
-                    L[q] = q == 0 ? CO::mx(v_[0], w0) : CO::mx3(L[q - 1], v_[q], L[q]);
+                    // slot 0 (HRED): the old carry K joins the chain here, so that the last slot is the
+                    // lane total without a separate max(L[P-1], K) at the end of the row
+                    L[q] = q == 0 ? (HRED ? CO::mx3(v_[0], w0, K) : CO::mx(v_[0], w0)) : CO::mx3(L[q - 1], v_[q], L[q]);
                 }
                 if (s >= 2 && s - 2 < P) {
                     const int q = s - 2;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
         }
         load_table(rs.code(i + 1), L[P - 1]);  // unconditional (clamped): keeps tb[] out of phi copies
         rs.advance(i + 1);
-        const uint32_t a = CO::mx(L[P - 1], K);
+        const uint32_t a = HRED ? L[P - 1] : CO::mx(L[P - 1], K);
         ++tp;
         if constexpr (HRED) {
             reduce_ends(a, i + 1);
