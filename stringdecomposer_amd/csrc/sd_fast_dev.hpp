@@ -185,21 +185,25 @@ struct ReadCursor {
 // Sequential reader: one scalar load per 16 rows, issued 16 rows ahead of its first use.
 struct ReadStream {
     const uint32_t* w;
-    const uint32_t* nm;
+    const uint32_t* nmp;  // N mask words; without a mask it aliases w so that every load is unconditional
+    bool has_n;           // (conditional loads would put the wave-uniform words into VGPRs)
     int last;            // n - 1
     uint32_t cur, nxt;   // words holding rows [16k, 16k+16) and the following 16
     uint32_t ncur;
     __device__ __forceinline__ void init(const uint32_t* w_, const uint32_t* nm_, int n) {
-        w = w_; nm = nm_; last = n - 1;
+        w = w_; has_n = nm_ != nullptr; nmp = has_n ? nm_ : w_; last = n - 1;
         cur = w[0];
         nxt = w[last >= 16 ? 1 : 0];
-        ncur = nm ? nm[0] : 0u;
+        ncur = nmp[0];
     }
     // code of row i; rows must be requested in non-decreasing order (clamped to the last row)
     __device__ __forceinline__ int code(int i) {
         i = i < last ? i : last;
         int r = (cur >> (2 * (i & 15))) & 3;
-        if (nm && ((ncur >> (i & 31)) & 1)) r = 4;
+        if (has_n) {  // a real branch (readfirstlane is not speculated): chunks without N pay nothing
+            const uint32_t nc = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncur);
+            if ((nc >> (i & 31)) & 1) r = 4;
+        }
         return r;
     }
     // call after consuming row i
@@ -208,7 +212,7 @@ struct ReadStream {
             cur = nxt;
             const int k = (i >> 4) + 2;
             nxt = w[(k << 4) <= last ? k : (last >> 4)];
-            if (nm && (i & 31) == 31) ncur = nm[(i >> 5) + 1];
+            if ((i & 31) == 31) ncur = nmp[(i >> 5) + 1];
         }
     }
 };
