@@ -134,13 +134,14 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     // H = Vmax-1 carry hops of one lane each (DPP wave_shr:1)
     auto excl_scan = [&](uint32_t a) {
         uint32_t inc = a;
-        if (H == 3 || H == 4) {  // doubling: window of 4 previous lanes (masks keep it inside the template)
+        if (H <= 4) {  // doubling: window of 4 previous lanes (the masks keep it inside the template;
+                       // with H = 0 they are all zero and the result is -inf everywhere)
             inc = CO::mx(inc, bfi(contMask, lane_up(inc, 1), NEGC));
             inc = CO::mx(inc, bfi(cont2Mask, lane_up(lane_up(inc, 1), 1), NEGC));
         } else {
             for (int h = 1; h < H; ++h) inc = CO::mx(a, bfi(contMask, lane_up(inc, 1), NEGC));
         }
-        return H > 0 ? bfi(contMask, lane_up(inc, 1), NEGC) : NEGC;
+        return bfi(contMask, lane_up(inc, 1), NEGC);
     };
     // B_{row} (relative to base) = max over template ends; arg = smallest virtual lane attaining it
     auto reduce_ends = [&](uint32_t Eend, int row) {
