@@ -166,7 +166,8 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
             unsigned long long mlo, mhi;
             asm("v_cmp_eq_f16_e64 %0, %1, %2" : "=s"(mlo) : "v"(val), "s"(b16));
             asm("v_cmp_eq_f16_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:WORD_0" : "=s"(mhi) : "v"(val), "s"(b16));
-            const int v = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
+            const int vlo = __ffsll((long long)mlo) - 1, vhi = 63 + __ffsll((long long)mhi);  // both scalar
+            const int v = vlo >= 0 ? vlo : vhi;
             bdel16 = b16;
             const int slot = (row - 1) & 63;
             acc_put(accBV, (int)((b16 << 7) | (uint32_t)v), slot);

@@ -194,16 +194,13 @@ struct ReadStream {
         w = w_; has_n = nm_ != nullptr; nmp = has_n ? nm_ : w_; last = n - 1;
         cur = w[0];
         nxt = w[last >= 16 ? 1 : 0];
-        ncur = nmp[0];
+        ncur = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmp[0]);
     }
     // code of row i; rows must be requested in non-decreasing order (clamped to the last row)
     __device__ __forceinline__ int code(int i) {
         i = i < last ? i : last;
         int r = (cur >> (2 * (i & 15))) & 3;
-        if (has_n) {  // a real branch (readfirstlane is not speculated): chunks without N pay nothing
-            const uint32_t nc = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncur);
-            if ((nc >> (i & 31)) & 1) r = 4;
-        }
+        r = (has_n && ((ncur >> (i & 31)) & 1)) ? 4 : r;  // scalar select, no branch
         return r;
     }
     // call after consuming row i
@@ -212,7 +209,7 @@ struct ReadStream {
             cur = nxt;
             const int k = (i >> 4) + 2;
             nxt = w[(k << 4) <= last ? k : (last >> 4)];
-            if ((i & 31) == 31) ncur = nmp[(i >> 5) + 1];
+            if ((i & 31) == 31) ncur = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmp[(i >> 5) + 1]);
         }
     }
 };
