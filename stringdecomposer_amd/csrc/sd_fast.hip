@@ -344,11 +344,11 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
     constexpr int QP = QK <= 4 ? 4 : 8;       // cells per lane rounded up to whole int4 loads
     using pt_t = std::conditional_t<(QK <= 4), uint8_t, uint16_t>;
     __shared__ pt_t pt_all[4][FAST_R][64];      // 2-bit moves of the lane's cells
-    __shared__ int32_t mt_all[4][5][64][QP];    // (mm - del) of the lane's cells for the 5 read symbols
+    __shared__ int16_t mt_all[4][5][64][QP];    // (mm - del) of the lane's cells for the 5 read symbols
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     pt_t(*pt)[64] = pt_all[wave];
-    int32_t(*mt)[64][QP] = mt_all[wave];
+    int16_t(*mt)[64][QP] = mt_all[wave];
     ChunkSched sched;
     sched.init(queue, order, n_chunks);
     for (int c = sched.next(); c >= 0; c = sched.next()) {
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
                 cl.code[q] = kk < Lj ? (int)tcodes[x0 + kk] : 7;
                 cl.slot[q] = kk < Lj ? (int)slot_of[x0 + kk] : 0;
 #pragma unroll
-                for (int b = 0; b < 5; ++b) mt[b][lane][q] = cl.code[q] == b ? mD : xD;
+                for (int b = 0; b < 5; ++b) mt[b][lane][q] = (int16_t)(cl.code[q] == b ? mD : xD);
             }
             return cl;
         };
@@ -462,8 +462,9 @@ __global__ __launch_bounds__(256) void sd_fast_trace(
                 int32_t mm4[QQP];
 #pragma unroll
                 for (int h = 0; h < QQP / 4; ++h) {
-                    const int4 mrow = *reinterpret_cast<const int4*>(&mt[r][lane][4 * h]);
-                    mm4[4 * h + 0] = mrow.x; mm4[4 * h + 1] = mrow.y; mm4[4 * h + 2] = mrow.z; mm4[4 * h + 3] = mrow.w;
+                    const uint2 mrow = *reinterpret_cast<const uint2*>(&mt[r][lane][4 * h]);  // 4 x int16
+                    mm4[4 * h + 0] = (int)(short)(mrow.x & 0xffffu); mm4[4 * h + 1] = (int)mrow.x >> 16;
+                    mm4[4 * h + 2] = (int)(short)(mrow.y & 0xffffu); mm4[4 * h + 3] = (int)mrow.y >> 16;
                 }
 #pragma unroll
                 for (int q = 0; q < QQ; ++q) {
