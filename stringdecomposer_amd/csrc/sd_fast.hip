@@ -328,11 +328,14 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
 // ---------------------------------------------------------------------------------------------
 // traceback with per-template recomputation
 // ---------------------------------------------------------------------------------------------
+#ifndef SD_TRACE_MINW
+#define SD_TRACE_MINW 7   // VGPR budget 72: 62 registers at QK = 3 without spills -> 8 waves per SIMD
+#endif
 #ifndef SD_TRACE_ADAPT
 #define SD_TRACE_ADAPT 1
 #endif
 template <int QK>
-__global__ __launch_bounds__(256) void sd_fast_trace(
+__global__ __launch_bounds__(256, SD_TRACE_MINW) void sd_fast_trace(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint16_t* __restrict__ slot_of,
     const uint8_t* __restrict__ tcodes, const uint32_t* __restrict__ lane_consts,
