@@ -257,8 +257,8 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
         } else {
             KB = CO::mx(K, CO::splat(Brel + sc.del - tp * sc.ins));
         }
-        uint32_t pd0 = K;  // HRED: unused (slot 0's u is KB)
-        if constexpr (!HRED) pd0 = bfi(startMask, NEGC, lane_up(Eend, 1));
+        // slot 0's diagonal input is the true last slot of the previous lane = this lane's carry K, and
+        // KB >= K: its u is KB itself (all variants)
         const uint32_t w0 = bfi(startMask, NEGC, L[0]);
         uint32_t u_[P], v_[P], c_[P];
         uint32_t run = 0;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
                     const int q = s - 4;
                     // slot 0 (HRED): the old carry K joins the chain here, so that the last slot is the
                     // lane total without a separate max(L[P-1], K) at the end of the row
-                    L[q] = q == 0 ? (HRED ? CO::mx3(v_[0], w0, K) : CO::mx(v_[0], w0)) : CO::mx3(L[q - 1], v_[q], L[q]);
+                    L[q] = q == 0 ? CO::mx3(v_[0], w0, K) : CO::mx3(L[q - 1], v_[q], L[q]);
                 }
                 if (s >= 2 && s - 2 < P) {
                     const int q = s - 2;
@@ -279,8 +279,8 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
                 }
                 if (s < P) {
                     const int q = s;
-                    if (HRED && q == 0) u_[q] = KB;
-                    else u_[q] = CO::mx(q == 0 ? pd0 : L[q - 1], KB);
+                    if (q == 0) u_[q] = KB;
+                    else u_[q] = CO::mx(L[q - 1], KB);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -303,22 +303,21 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
             }
             if (s < P) {
                 const int q = s;
-                u_[q] = pk_max(q == 0 ? pd0 : L[q - 1], KB);
+                u_[q] = q == 0 ? KB : pk_max(L[q - 1], KB);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         }
         load_table(rs.code(i + 1), L[P - 1]);  // unconditional (clamped): keeps tb[] out of phi copies
         rs.advance(i + 1);
-        const uint32_t a = HRED ? L[P - 1] : CO::mx(L[P - 1], K);
+        const uint32_t a = F16 ? L[P - 1] : CO::mx(L[P - 1], K);  // fp16: K already joined the chain
         ++tp;
         if constexpr (HRED) {
             reduce_ends(a, i + 1);
             K = excl_scan(a);
         } else {
-            const uint32_t X = excl_scan(a);
-            K = CO::mx(K, X);
-            Eend = CO::mx(a, X);
+            K = excl_scan(a);           // totals never decrease: the new carry replaces the old one
+            Eend = CO::mx(a, K);
             reduce_ends(Eend, i + 1);
         }
     }
@@ -335,7 +334,7 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
 #define SD_TRACE_ADAPT 1
 #endif
 template <int QK>
-__global__ __launch_bounds__(256, SD_TRACE_MINW) void sd_fast_trace(
+__global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_trace(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint16_t* __restrict__ slot_of,
     const uint8_t* __restrict__ tcodes, const uint32_t* __restrict__ lane_consts,
