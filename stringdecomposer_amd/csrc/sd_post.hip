@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <cstring>
@@ -243,5 +244,67 @@ extern "C" int sd_identity_segments(const char* seq, int64_t seqlen, const int64
         for (int k = 0; k < nt; ++k) th.emplace_back(work);
         for (auto& x : th) x.join();
     }
+    return SD_OK;
+}
+
+
+// Text of the _alt.tsv rows of one read (main.py:161-165): for every kept block, one line per monomer
+// name:  read \t name \t start \t end \t "{:.2f}".format(identity) \t ('*' for the block's own monomer,
+// '-' otherwise).  printf("%.2f") and Python's format both print the correctly rounded decimal of the
+// double.  Multi-threaded over blocks.
+extern "C" int sd_format_alt_rows(const char* read_name, const char* const* key_names, int32_t n_keys,
+                                  const int64_t* starts, const int64_t* ends, const int32_t* own_key,
+                                  const double* vals, int64_t n_rows, int32_t threads, char** txt,
+                                  size_t* txt_len) {
+    if (!txt || !txt_len || !read_name || n_rows < 0 || n_keys < 0 ||
+        (n_rows && n_keys && (!key_names || !starts || !ends || !own_key || !vals)))
+        return SD_ERR_PARAM;
+    *txt = nullptr;
+    *txt_len = 0;
+    const std::string head = std::string(read_name) + "\t";
+    std::vector<std::string> keys;
+    for (int k = 0; k < n_keys; ++k) keys.emplace_back(key_names[k]);
+    const int64_t grain = 256;
+    const int64_t n_blocks = (n_rows + grain - 1) / grain;
+    std::vector<std::string> parts((size_t)n_blocks);
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n_blocks));
+    std::atomic<int64_t> next{0};
+    auto work = [&]() {
+        char num[64];
+        for (;;) {
+            const int64_t b = next.fetch_add(1);
+            if (b >= n_blocks) break;
+            std::string& o = parts[(size_t)b];
+            const int64_t r1 = std::min(n_rows, (b + 1) * grain);
+            for (int64_t r = b * grain; r < r1; ++r) {
+                char mid[64];
+                const int ml = std::snprintf(mid, sizeof mid, "\t%lld\t%lld\t", (long long)starts[r], (long long)ends[r]);
+                for (int k = 0; k < n_keys; ++k) {
+                    o += head;
+                    o += keys[(size_t)k];
+                    o.append(mid, (size_t)ml);
+                    const int nl = std::snprintf(num, sizeof num, "%.2f", vals[(size_t)r * n_keys + k]);
+                    o.append(num, (size_t)nl);
+                    o += (k == own_key[r]) ? "\t*\n" : "\t-\n";
+                }
+            }
+        }
+    };
+    if (nt == 1) {
+        work();
+    } else {
+        std::vector<std::thread> th;
+        for (int k = 0; k < nt; ++k) th.emplace_back(work);
+        for (auto& x : th) x.join();
+    }
+    size_t total = 0;
+    for (const std::string& p : parts) total += p.size();
+    char* out = static_cast<char*>(std::malloc(total + 1));
+    if (!out) return SD_ERR_PARAM;
+    size_t pos = 0;
+    for (const std::string& p : parts) { std::memcpy(out + pos, p.data(), p.size()); pos += p.size(); }
+    out[total] = 0;
+    *txt = out;
+    *txt_len = total;
     return SD_OK;
 }

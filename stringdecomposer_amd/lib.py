@@ -30,7 +30,7 @@ EXPORTS = [
     "sd_engine_run", "sd_engine_fetch", "sd_engine_assemble", "sd_engine_timings",
     "sd_engine_info", "sd_chunk_plan", "sd_seam_merge", "sd_format_rows", "sd_fasta_load",
     "sd_fasta_free", "sd_nw_identity_batch", "sd_identity_segments", "sd_chunk_table_size",
-    "sd_decompose_chunk_range", "sd_assemble_tsv", "sd_release_cache",
+    "sd_decompose_chunk_range", "sd_assemble_tsv", "sd_release_cache", "sd_format_alt_rows",
 ]
 
 
@@ -104,6 +104,8 @@ def load():
     L.sd_identity_segments.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                        P(C.c_char_p), P(C.c_int32), C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sd_format_alt_rows.argtypes = [C.c_char_p, P(C.c_char_p), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int64, C.c_int32, P(C.c_void_p), P(C.c_size_t)]
     L.sd_chunk_table_size.restype = C.c_int64
     L.sd_chunk_table_size.argtypes = [P(C.c_int64), C.c_int32, C.c_int32, C.c_int32]
     L.sd_decompose_chunk_range.argtypes = [P(C.c_char_p), P(C.c_int64), C.c_int32, P(C.c_char_p), P(C.c_int32),
@@ -430,5 +432,26 @@ def assemble_tsv(read_names, read_lens, mono_names, recs, rec_off, **kw):
     if rc != SD_OK:
         raise SdError(rc, err.value.decode(errors="replace"))
     data = C.string_at(out, ln.value)
+    L.sd_free(out)
+    return data
+
+
+def format_alt_rows(read_name, key_names, starts, ends, own_key, vals, threads=1):
+    """Text (str) of one read's _alt.tsv rows; vals is a [n_rows, n_keys] float64 array."""
+    import numpy as np
+    L = load()
+    v = np.ascontiguousarray(vals, dtype=np.float64)
+    n, nk = (int(v.shape[0]), int(v.shape[1])) if v.ndim == 2 else (0, len(key_names))
+    st = np.ascontiguousarray(starts, dtype=np.int64)
+    en = np.ascontiguousarray(ends, dtype=np.int64)
+    ow = np.ascontiguousarray(own_key, dtype=np.int32)
+    out = C.c_void_p()
+    ln = C.c_size_t()
+    rc = L.sd_format_alt_rows(_b(read_name), _strs([_b(k) for k in key_names]), nk, st.ctypes.data,
+                              en.ctypes.data, ow.ctypes.data, v.ctypes.data, n, threads, C.byref(out),
+                              C.byref(ln))
+    if rc != SD_OK:
+        raise SdError(rc, "sd_format_alt_rows")
+    data = C.string_at(out, ln.value).decode()
     L.sd_free(out)
     return data

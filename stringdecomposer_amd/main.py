@@ -230,7 +230,7 @@ def print_read(fout, fout_alt, dec, read, monomers, identity_th, light, threads,
     """main.py:153-165."""
     dec = convert_read(dec, read, monomers, light, threads, coef)
     f2 = "{:.2f}".format
-    out, out_alt = [], []
+    out, kept = [], []
     for d in dec:
         if d["score"] >= identity_th:
             out.append("\t".join([read.name, d["m"], d["start"], d["end"], f2(d["score"]),
@@ -239,14 +239,14 @@ def print_read(fout, fout_alt, dec, read, monomers, identity_th, light, threads,
                                   d["homo_second_best"], f2(d["homo_second_best_score"]),
                                   d["q"]]) + "\n")
             if d["alt"]:
-                keys, row = d["alt"]
-                head = read.name + "\t"
-                tail = "\t" + d["start"] + "\t" + d["end"] + "\t"
-                own = d["m"]
-                for a, v in zip(keys, row.tolist()):
-                    out_alt.append(head + a + tail + f2(v) + ("\t*\n" if a == own else "\t-\n"))
+                kept.append(d)
     fout.write("".join(out))
-    fout_alt.write("".join(out_alt))
+    if kept:  # the _alt rows (one per block and monomer name) are formatted natively
+        keys = kept[0]["alt"][0]
+        kidx = {k: x for x, k in enumerate(keys)}
+        fout_alt.write(lib.format_alt_rows(read.name, keys, [int(d["start"]) for d in kept],
+                                           [int(d["end"]) for d in kept], [kidx[d["m"]] for d in kept],
+                                           np.stack([d["alt"][1] for d in kept]), threads))
 
 
 def convert_tsv(decomposition, reads, monomers, outfile, identity_th, light, threads=1):

@@ -240,3 +240,26 @@ def test_convert_read_dict_semantics_with_repeated_names(oracle):
         assert [g["homo_second_best"], g["homo_second_best_score"]] == hs[1]
         keys, row = g["alt"]
         assert list(keys) == list(scores) and row.tolist() == [scores[k] for k in keys]
+
+
+def test_native_alt_row_formatting_equals_python_format():
+    """sd_format_alt_rows prints "%.2f"; Python prints "{:.2f}": both are the correctly rounded decimal of
+    the double, also at the x.xx5 ties that a decimal reading would round the other way."""
+    rng = np.random.default_rng(5)
+    n, nk = 700, 5
+    vals = rng.uniform(0, 100, size=(n, nk))
+    vals[:50, 0] = np.arange(50) + 0.125            # exact ties in binary: round-half-even
+    vals[50:100, 1] = np.arange(50) + 0.005         # inexact: whichever side the double falls on
+    vals[100:150, 2] = (np.arange(50) * 7 + 1) / 3 * 100 / 57
+    vals[150, 3] = 0.0
+    vals[151, 3] = 100.0
+    keys = ["m%d" % k if k != 3 else "m3'" for k in range(nk)]
+    starts = np.arange(n) * 171
+    ends = starts + 170
+    own = rng.integers(0, nk, size=n)
+    got = lib.format_alt_rows("read/1", keys, starts, ends, own, vals, threads=3)
+    exp = "".join("read/1\t%s\t%d\t%d\t%s\t%s\n" % (keys[k], starts[i], ends[i], "{:.2f}".format(vals[i, k]),
+                                                   "*" if k == own[i] else "-")
+                  for i in range(n) for k in range(nk))
+    assert got == exp
+    assert lib.format_alt_rows("r", keys, [], [], [], np.zeros((0, nk)), threads=2) == ""
