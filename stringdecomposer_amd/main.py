@@ -158,30 +158,27 @@ def classify(score, second_best_score, coef):
     return X.dot(np.array(coef, dtype=np.float64)) > 0
 
 
-def convert_read(decomposition, read, monomers, light, threads, coef):
-    """main.py:107-150.  Returns the list of per-block dicts of the reference (scores as floats)."""
-    res = []
+def _convert_read_arrays(decomposition, read, monomers, light, threads, coef):
+    """main.py:107-150 on arrays: one entry per block.  Returns a dict of columns (lists / arrays)."""
     n = len(decomposition)
-    if n == 0:
-        return res
+    starts = np.array([d["start"] for d in decomposition], dtype=np.int64)
+    ends = np.array([d["end"] for d in decomposition], dtype=np.int64)
+    own_names = [d["m"] for d in decomposition]
+    col = {"m": own_names, "start": starts, "end": ends, "alt_keys": None}
     if light:
         by_name = {}
         for x, m in enumerate(monomers):
             by_name[m.name] = x  # the reference keeps the last monomer of a given name
-        starts = np.array([d["start"] for d in decomposition], dtype=np.int64)
-        ends = np.array([d["end"] for d in decomposition], dtype=np.int64)
-        pair = np.array([by_name[d["m"]] for d in decomposition], dtype=np.int32)
-        scores = _identity_percent(*lib.identity_segments(read.seq, starts, ends, [m.seq for m in monomers],
-                                                          False, threads, pair_tmpl=pair)).tolist()
-        for d, sc in zip(decomposition, scores):
-            res.append({"m": d["m"], "start": str(d["start"]), "end": str(d["end"]), "score": sc,
-                        "second_best": "None", "second_best_score": -1,
-                        "homo_best": "None", "homo_best_score": -1,
-                        "homo_second_best": "None", "homo_second_best_score": -1,
-                        "alt": {}, "q": "+"})
+        pair = np.array([by_name[nm] for nm in own_names], dtype=np.int32)
+        col["score"] = _identity_percent(*lib.identity_segments(read.seq, starts, ends, [m.seq for m in monomers],
+                                                                False, threads, pair_tmpl=pair))
+        col["second_best"] = ["None"] * n
+        col["second_best_score"] = np.full(n, -1.0)
+        col["homo_best"] = ["None"] * n
+        col["homo_best_score"] = np.full(n, -1.0)
+        col["homo_second_best"] = ["None"] * n
+        col["homo_second_best_score"] = np.full(n, -1.0)
     else:
-        starts = np.array([d["start"] for d in decomposition], dtype=np.int64)
-        ends = np.array([d["end"] for d in decomposition], dtype=np.int64)
         seqs = [m.seq for m in monomers]
         names = [m.name for m in monomers]
         vals = _identity_percent(*lib.identity_segments(read.seq, starts, ends, seqs, False, threads))
@@ -193,60 +190,85 @@ def convert_read(decomposition, read, monomers, light, threads, coef):
             first.setdefault(nm, x)
             last[nm] = x
         keys = list(first)
+        kidx = {k: x for x, k in enumerate(keys)}
         kcol = np.array([last[k] for k in keys], dtype=np.int64)
         kvals = vals[:, kcol]                                  # [n, len(keys)] in dict order
-        own = np.array([keys.index(d["m"]) if d["m"] in first else -1 for d in decomposition])
-        if (own < 0).any():
-            raise KeyError(decomposition[int(np.argmax(own < 0))]["m"])
+        for nm in own_names:
+            if nm not in kidx:
+                raise KeyError(nm)
+        own = np.array([kidx[nm] for nm in own_names], dtype=np.int64)
         rows = np.arange(n)
         masked = kvals.copy()
         masked[rows, own] = -np.inf
-        sb = np.argmax(masked, axis=1) if len(keys) > 1 else np.full(n, -1)   # first maximum
-        horder = np.argsort(-hvals, axis=1, kind="stable")
-        for i, d in enumerate(decomposition):
-            if len(keys) > 1 and keys[sb[i]] != "":
-                secondbest, secondbest_score = keys[sb[i]], float(masked[i, sb[i]])
-            else:  # `not secondbest` quirk of main.py:127 for an empty name / single key
+        if len(keys) > 1 and "" not in kidx:
+            sb = np.argmax(masked, axis=1)                     # first maximum among the other names
+            col["second_best"] = [keys[x] for x in sb.tolist()]
+            col["second_best_score"] = masked[rows, sb]
+        else:  # `not secondbest` quirk of main.py:127 for an empty name / a single key
+            sbn, sbs = [], []
+            for i in range(n):
                 secondbest, secondbest_score = None, -1
                 for kx, m in enumerate(keys):
                     if kx != own[i]:
                         if not secondbest or secondbest_score < kvals[i, kx]:
                             secondbest, secondbest_score = m, float(kvals[i, kx])
-            h0, h1 = int(horder[i, 0]), int(horder[i, 1])
-            res.append({"m": d["m"], "start": str(d["start"]), "end": str(d["end"]),
-                        "score": float(kvals[i, own[i]]),
-                        "second_best": str(secondbest), "second_best_score": secondbest_score,
-                        "homo_best": names[h0], "homo_best_score": float(hvals[i, h0]),
-                        "homo_second_best": names[h1], "homo_second_best_score": float(hvals[i, h1]),
-                        "alt": (keys, kvals[i]), "q": "+"})
-    keep = classify([r["score"] for r in res], [r["second_best_score"] for r in res], coef)
-    for r, k in zip(res, keep):
-        if not k:
-            r["q"] = "?"
+                sbn.append(str(secondbest))
+                sbs.append(secondbest_score)
+            col["second_best"] = sbn
+            col["second_best_score"] = np.array(sbs, dtype=np.float64)
+        horder = np.argsort(-hvals, axis=1, kind="stable")
+        h0, h1 = horder[:, 0], horder[:, 1]
+        col["score"] = kvals[rows, own]
+        col["homo_best"] = [names[x] for x in h0.tolist()]
+        col["homo_best_score"] = hvals[rows, h0]
+        col["homo_second_best"] = [names[x] for x in h1.tolist()]
+        col["homo_second_best_score"] = hvals[rows, h1]
+        col["alt_keys"], col["alt_vals"], col["own_key"] = keys, kvals, own
+    keep = classify(col["score"], col["second_best_score"], coef)
+    col["q"] = ["+" if k else "?" for k in keep.tolist()]
+    return col
+
+
+def convert_read(decomposition, read, monomers, light, threads, coef):
+    """main.py:107-150.  Returns the list of per-block dicts of the reference (scores as floats)."""
+    if not decomposition:
+        return []
+    c = _convert_read_arrays(decomposition, read, monomers, light, threads, coef)
+    res = []
+    for i in range(len(decomposition)):
+        res.append({"m": c["m"][i], "start": str(int(c["start"][i])), "end": str(int(c["end"][i])),
+                    "score": float(c["score"][i]),
+                    "second_best": c["second_best"][i],
+                    "second_best_score": -1 if light else float(c["second_best_score"][i]),
+                    "homo_best": c["homo_best"][i], "homo_best_score": -1 if light else float(c["homo_best_score"][i]),
+                    "homo_second_best": c["homo_second_best"][i],
+                    "homo_second_best_score": -1 if light else float(c["homo_second_best_score"][i]),
+                    "alt": {} if c["alt_keys"] is None else (c["alt_keys"], c["alt_vals"][i]), "q": c["q"][i]})
     return res
 
 
 def print_read(fout, fout_alt, dec, read, monomers, identity_th, light, threads, coef):
     """main.py:153-165."""
-    dec = convert_read(dec, read, monomers, light, threads, coef)
+    if not dec:
+        return
+    c = _convert_read_arrays(dec, read, monomers, light, threads, coef)
+    keep = np.nonzero(c["score"] >= identity_th)[0]
     f2 = "{:.2f}".format
-    out, kept = [], []
-    for d in dec:
-        if d["score"] >= identity_th:
-            out.append("\t".join([read.name, d["m"], d["start"], d["end"], f2(d["score"]),
-                                  d["second_best"], f2(d["second_best_score"]),
-                                  d["homo_best"], f2(d["homo_best_score"]),
-                                  d["homo_second_best"], f2(d["homo_second_best_score"]),
-                                  d["q"]]) + "\n")
-            if d["alt"]:
-                kept.append(d)
-    fout.write("".join(out))
-    if kept:  # the _alt rows (one per block and monomer name) are formatted natively
-        keys = kept[0]["alt"][0]
-        kidx = {k: x for x, k in enumerate(keys)}
-        fout_alt.write(lib.format_alt_rows(read.name, keys, [int(d["start"]) for d in kept],
-                                           [int(d["end"]) for d in kept], [kidx[d["m"]] for d in kept],
-                                           np.stack([d["alt"][1] for d in kept]), threads))
+    ks = keep.tolist()
+    sc = [f2(x) for x in c["score"][keep].tolist()]
+    s2 = [f2(x) for x in c["second_best_score"][keep].tolist()]
+    h1 = [f2(x) for x in c["homo_best_score"][keep].tolist()]
+    h2 = [f2(x) for x in c["homo_second_best_score"][keep].tolist()]
+    st = c["start"][keep].tolist()
+    en = c["end"][keep].tolist()
+    name = read.name
+    m, sbn, hb, hsb, q = c["m"], c["second_best"], c["homo_best"], c["homo_second_best"], c["q"]
+    fout.write("".join(["%s\t%s\t%d\t%d\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\n" %
+                        (name, m[i], st[j], en[j], sc[j], sbn[i], s2[j], hb[i], h1[j], hsb[i], h2[j], q[i])
+                        for j, i in enumerate(ks)]))
+    if c["alt_keys"] is not None and len(ks):  # one row per block and monomer name, formatted natively
+        fout_alt.write(lib.format_alt_rows(name, c["alt_keys"], c["start"][keep], c["end"][keep],
+                                           c["own_key"][keep], c["alt_vals"][keep], threads))
 
 
 def convert_tsv(decomposition, reads, monomers, outfile, identity_th, light, threads=1):
