@@ -158,20 +158,33 @@ def classify(score, second_best_score, coef):
     return X.dot(np.array(coef, dtype=np.float64)) > 0
 
 
-def _convert_read_arrays(decomposition, read, monomers, light, threads, coef):
-    """main.py:107-150 on arrays: one entry per block.  Returns a dict of columns (lists / arrays)."""
-    n = len(decomposition)
-    starts = np.array([d["start"] for d in decomposition], dtype=np.int64)
-    ends = np.array([d["end"] for d in decomposition], dtype=np.int64)
-    own_names = [d["m"] for d in decomposition]
-    col = {"m": own_names, "start": starts, "end": ends, "alt_keys": None}
+def _identities(seq, starts, ends, monomers, light, threads, own_names=None):
+    """The NW identities convert_read needs for the blocks [starts, ends] of `seq`:
+    light -> (scores,) against each block's own monomer; else -> (vals, hvals) against all monomers,
+    plain and homopolymer-compressed."""
+    seqs = [m.seq for m in monomers]
     if light:
         by_name = {}
         for x, m in enumerate(monomers):
             by_name[m.name] = x  # the reference keeps the last monomer of a given name
         pair = np.array([by_name[nm] for nm in own_names], dtype=np.int32)
-        col["score"] = _identity_percent(*lib.identity_segments(read.seq, starts, ends, [m.seq for m in monomers],
-                                                                False, threads, pair_tmpl=pair))
+        return (_identity_percent(*lib.identity_segments(seq, starts, ends, seqs, False, threads, pair_tmpl=pair)),)
+    return (_identity_percent(*lib.identity_segments(seq, starts, ends, seqs, False, threads)),
+            _identity_percent(*lib.identity_segments(seq, starts, ends, seqs, True, threads)))
+
+
+def _convert_read_arrays(decomposition, read, monomers, light, threads, coef, pre=None):
+    """main.py:107-150 on arrays: one entry per block.  Returns a dict of columns (lists / arrays).
+    `pre` = this read's slice of identities computed for a batch of reads (see convert_tsv)."""
+    n = len(decomposition)
+    starts = np.array([d["start"] for d in decomposition], dtype=np.int64)
+    ends = np.array([d["end"] for d in decomposition], dtype=np.int64)
+    own_names = [d["m"] for d in decomposition]
+    col = {"m": own_names, "start": starts, "end": ends, "alt_keys": None}
+    if pre is None:
+        pre = _identities(read.seq, starts, ends, monomers, light, threads, own_names)
+    if light:
+        col["score"] = pre[0]
         col["second_best"] = ["None"] * n
         col["second_best_score"] = np.full(n, -1.0)
         col["homo_best"] = ["None"] * n
@@ -179,10 +192,8 @@ def _convert_read_arrays(decomposition, read, monomers, light, threads, coef):
         col["homo_second_best"] = ["None"] * n
         col["homo_second_best_score"] = np.full(n, -1.0)
     else:
-        seqs = [m.seq for m in monomers]
         names = [m.name for m in monomers]
-        vals = _identity_percent(*lib.identity_segments(read.seq, starts, ends, seqs, False, threads))
-        hvals = _identity_percent(*lib.identity_segments(read.seq, starts, ends, seqs, True, threads))
+        vals, hvals = pre
         # scores is a dict keyed by monomer name in the reference: a repeated name keeps its first
         # position and its last value
         first, last = {}, {}
@@ -247,11 +258,11 @@ def convert_read(decomposition, read, monomers, light, threads, coef):
     return res
 
 
-def print_read(fout, fout_alt, dec, read, monomers, identity_th, light, threads, coef):
+def print_read(fout, fout_alt, dec, read, monomers, identity_th, light, threads, coef, pre=None):
     """main.py:153-165."""
     if not dec:
         return
-    c = _convert_read_arrays(dec, read, monomers, light, threads, coef)
+    c = _convert_read_arrays(dec, read, monomers, light, threads, coef, pre)
     keep = np.nonzero(c["score"] >= identity_th)[0]
     f2 = "{:.2f}".format
     ks = keep.tolist()
@@ -268,27 +279,51 @@ def print_read(fout, fout_alt, dec, read, monomers, identity_th, light, threads,
                         for j, i in enumerate(ks)]))
     if c["alt_keys"] is not None and len(ks):  # one row per block and monomer name, formatted natively
         fout_alt.write(lib.format_alt_rows(name, c["alt_keys"], c["start"][keep], c["end"][keep],
-                                           c["own_key"][keep], c["alt_vals"][keep], threads))
+                                           c["own_key"][keep], c["alt_vals"][keep],
+                                           max(1, min(threads, len(ks) // 512))))
 
 
 def convert_tsv(decomposition, reads, monomers, outfile, identity_th, light, threads=1):
-    """main.py:168-184."""
+    """main.py:168-184.  Reads are post-processed in the order of the raw file; the NW identities are
+    computed for batches of reads at a time (one native call per ~64 k blocks instead of one per read)."""
     coef = _lr_coef()
+    per_read = []            # [(read name, [block dicts])] in file order
+    prev_read = None
+    for ln in decomposition.split("\n")[:-1]:
+        read, monomer, start, end = ln.split("\t")[:4]
+        read = read.split()[0]
+        monomer = monomer.split()[0]
+        if read != prev_read:
+            per_read.append((read, []))
+        prev_read = read
+        per_read[-1][1].append({"m": monomer, "start": int(start), "end": int(end)})
     with open(outfile[:-len(".tsv")] + "_alt.tsv", "w") as fout_alt:
         with open(outfile, "w") as fout:
-            cur_dec = []
-            prev_read = None
-            for ln in decomposition.split("\n")[:-1]:
-                read, monomer, start, end = ln.split("\t")[:4]
-                read = read.split()[0]
-                monomer = monomer.split()[0]
-                if read != prev_read and prev_read is not None:
-                    print_read(fout, fout_alt, cur_dec, reads[prev_read], monomers, identity_th, light, threads, coef)
-                    cur_dec = []
-                prev_read = read
-                cur_dec.append({"m": monomer, "start": int(start), "end": int(end)})
-            if len(cur_dec) > 0:
-                print_read(fout, fout_alt, cur_dec, reads[prev_read], monomers, identity_th, light, threads, coef)
+            i = 0
+            while i < len(per_read):
+                j, blocks = i, 0
+                while j < len(per_read) and (j == i or blocks + len(per_read[j][1]) <= 65536):
+                    blocks += len(per_read[j][1])
+                    j += 1
+                batch = per_read[i:j]
+                # one sequence for the batch: blocks never cross a read, so shifted coordinates are exact
+                seqs, off, pos = [], [], 0
+                for name, _ in batch:
+                    sq = reads[name].seq
+                    off.append(pos)
+                    seqs.append(sq)
+                    pos += len(sq)
+                starts = np.array([d["start"] + o for (_, dec), o in zip(batch, off) for d in dec], dtype=np.int64)
+                ends = np.array([d["end"] + o for (_, dec), o in zip(batch, off) for d in dec], dtype=np.int64)
+                own = [d["m"] for _, dec in batch for d in dec]
+                pre = _identities("".join(seqs), starts, ends, monomers, light, threads, own)
+                at = 0
+                for name, dec in batch:
+                    sl = slice(at, at + len(dec))
+                    print_read(fout, fout_alt, dec, reads[name], monomers, identity_th, light, threads, coef,
+                               tuple(p[sl] for p in pre))
+                    at += len(dec)
+                i = j
 
 
 def run(sequences, monomers, num_threads, scoring, batch_size, raw_file, ed_thr, overlap, logger,
