@@ -190,12 +190,14 @@ int sd_identity_segments(const char* seq, int64_t seqlen, const int64_t* starts,
                          const int32_t* pair_tmpl, int32_t homo, int32_t threads, int32_t* dist,
                          int32_t* matches, int32_t* columns);
 
-/* Text of one read's `_alt.tsv` rows (main.py:161-165): for each of n_rows kept blocks one line per
- * monomer name (key): read, name, start, end, "%.2f" of vals[row * n_keys + key], '*' if key ==
- * own_key[row] else '-'.  *txt is malloc'ed (sd_free).  Host only, multi-threaded. */
-int sd_format_alt_rows(const char* read_name, const char* const* key_names, int32_t n_keys,
-                       const int64_t* starts, const int64_t* ends, const int32_t* own_key,
-                       const double* vals, int64_t n_rows, int32_t threads, char** txt, size_t* txt_len);
+/* Text of `_alt.tsv` rows (main.py:161-165): for each of n_rows kept blocks one line per monomer name
+ * (key): read, name, start, end, "%.2f" of vals[row * n_keys + key], '*' if key == own_key[row] else
+ * '-'.  The read of a row is read_names[row_read[row]] (row_read == NULL: read_names[0] for all rows).
+ * *txt is malloc'ed (sd_free).  Host only, multi-threaded. */
+int sd_format_alt_rows(const char* const* read_names, int32_t n_reads, const int32_t* row_read,
+                       const char* const* key_names, int32_t n_keys, const int64_t* starts,
+                       const int64_t* ends, const int32_t* own_key, const double* vals, int64_t n_rows,
+                       int32_t threads, char** txt, size_t* txt_len);
 
 #ifdef __cplusplus
 }

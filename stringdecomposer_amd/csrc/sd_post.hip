@@ -248,20 +248,25 @@ extern "C" int sd_identity_segments(const char* seq, int64_t seqlen, const int64
 }
 
 
-// Text of the _alt.tsv rows of one read (main.py:161-165): for every kept block, one line per monomer
+// Text of _alt.tsv rows (main.py:161-165) of one read or of a batch of reads (row_read = index of each
+// block's read in read_names; NULL = all rows belong to read_names[0]): for every kept block, one line per monomer
 // name:  read \t name \t start \t end \t "{:.2f}".format(identity) \t ('*' for the block's own monomer,
 // '-' otherwise).  printf("%.2f") and Python's format both print the correctly rounded decimal of the
 // double.  Multi-threaded over blocks.
-extern "C" int sd_format_alt_rows(const char* read_name, const char* const* key_names, int32_t n_keys,
-                                  const int64_t* starts, const int64_t* ends, const int32_t* own_key,
-                                  const double* vals, int64_t n_rows, int32_t threads, char** txt,
-                                  size_t* txt_len) {
-    if (!txt || !txt_len || !read_name || n_rows < 0 || n_keys < 0 ||
+extern "C" int sd_format_alt_rows(const char* const* read_names, int32_t n_reads, const int32_t* row_read,
+                                  const char* const* key_names, int32_t n_keys, const int64_t* starts,
+                                  const int64_t* ends, const int32_t* own_key, const double* vals,
+                                  int64_t n_rows, int32_t threads, char** txt, size_t* txt_len) {
+    if (!txt || !txt_len || !read_names || n_reads < 1 || n_rows < 0 || n_keys < 0 ||
         (n_rows && n_keys && (!key_names || !starts || !ends || !own_key || !vals)))
         return SD_ERR_PARAM;
     *txt = nullptr;
     *txt_len = 0;
-    const std::string head = std::string(read_name) + "\t";
+    if (row_read)
+        for (int64_t r = 0; r < n_rows; ++r)
+            if (row_read[r] < 0 || row_read[r] >= n_reads) return SD_ERR_PARAM;
+    std::vector<std::string> heads;
+    for (int r = 0; r < n_reads; ++r) heads.push_back(std::string(read_names[r]) + "\t");
     std::vector<std::string> keys;
     for (int k = 0; k < n_keys; ++k) keys.emplace_back(key_names[k]);
     const int64_t grain = 256;
@@ -279,6 +284,7 @@ extern "C" int sd_format_alt_rows(const char* read_name, const char* const* key_
             for (int64_t r = b * grain; r < r1; ++r) {
                 char mid[64];
                 const int ml = std::snprintf(mid, sizeof mid, "\t%lld\t%lld\t", (long long)starts[r], (long long)ends[r]);
+                const std::string& head = heads[row_read ? (size_t)row_read[r] : 0];
                 for (int k = 0; k < n_keys; ++k) {
                     o += head;
                     o += keys[(size_t)k];

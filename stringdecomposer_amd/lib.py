@@ -104,8 +104,9 @@ def load():
     L.sd_identity_segments.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                        P(C.c_char_p), P(C.c_int32), C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
-    L.sd_format_alt_rows.argtypes = [C.c_char_p, P(C.c_char_p), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
-                                     C.c_void_p, C.c_int64, C.c_int32, P(C.c_void_p), P(C.c_size_t)]
+    L.sd_format_alt_rows.argtypes = [P(C.c_char_p), C.c_int32, C.c_void_p, P(C.c_char_p), C.c_int32, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, P(C.c_void_p),
+                                     P(C.c_size_t)]
     L.sd_chunk_table_size.restype = C.c_int64
     L.sd_chunk_table_size.argtypes = [P(C.c_int64), C.c_int32, C.c_int32, C.c_int32]
     L.sd_decompose_chunk_range.argtypes = [P(C.c_char_p), P(C.c_int64), C.c_int32, P(C.c_char_p), P(C.c_int32),
@@ -436,10 +437,13 @@ def assemble_tsv(read_names, read_lens, mono_names, recs, rec_off, **kw):
     return data
 
 
-def format_alt_rows(read_name, key_names, starts, ends, own_key, vals, threads=1):
-    """Text (str) of one read's _alt.tsv rows; vals is a [n_rows, n_keys] float64 array."""
+def format_alt_rows(read_name, key_names, starts, ends, own_key, vals, threads=1, row_read=None):
+    """Text (str) of _alt.tsv rows; vals is a [n_rows, n_keys] float64 array.  read_name: one name, or a
+    list of names with row_read giving each row's index into it."""
     import numpy as np
     L = load()
+    names = [read_name] if isinstance(read_name, (str, bytes)) else list(read_name)
+    rr = None if row_read is None else np.ascontiguousarray(row_read, dtype=np.int32)
     v = np.ascontiguousarray(vals, dtype=np.float64)
     n, nk = (int(v.shape[0]), int(v.shape[1])) if v.ndim == 2 else (0, len(key_names))
     st = np.ascontiguousarray(starts, dtype=np.int64)
@@ -447,9 +451,9 @@ def format_alt_rows(read_name, key_names, starts, ends, own_key, vals, threads=1
     ow = np.ascontiguousarray(own_key, dtype=np.int32)
     out = C.c_void_p()
     ln = C.c_size_t()
-    rc = L.sd_format_alt_rows(_b(read_name), _strs([_b(k) for k in key_names]), nk, st.ctypes.data,
-                              en.ctypes.data, ow.ctypes.data, v.ctypes.data, n, threads, C.byref(out),
-                              C.byref(ln))
+    rc = L.sd_format_alt_rows(_strs([_b(x) for x in names]), len(names), None if rr is None else rr.ctypes.data,
+                              _strs([_b(k) for k in key_names]), nk, st.ctypes.data, en.ctypes.data,
+                              ow.ctypes.data, v.ctypes.data, n, threads, C.byref(out), C.byref(ln))
     if rc != SD_OK:
         raise SdError(rc, "sd_format_alt_rows")
     data = C.string_at(out, ln.value).decode()

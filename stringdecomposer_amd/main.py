@@ -258,8 +258,9 @@ def convert_read(decomposition, read, monomers, light, threads, coef):
     return res
 
 
-def print_read(fout, fout_alt, dec, read, monomers, identity_th, light, threads, coef, pre=None):
-    """main.py:153-165."""
+def print_read(fout, fout_alt, dec, read, monomers, identity_th, light, threads, coef, pre=None, alt_acc=None):
+    """main.py:153-165.  With alt_acc (a list) the _alt rows are not written but appended to it as
+    (read name, keys, starts, ends, own key, values) for one formatting call per batch of reads."""
     if not dec:
         return
     c = _convert_read_arrays(dec, read, monomers, light, threads, coef, pre)
@@ -277,7 +278,9 @@ def print_read(fout, fout_alt, dec, read, monomers, identity_th, light, threads,
     fout.write("".join(["%s\t%s\t%d\t%d\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\n" %
                         (name, m[i], st[j], en[j], sc[j], sbn[i], s2[j], hb[i], h1[j], hsb[i], h2[j], q[i])
                         for j, i in enumerate(ks)]))
-    if c["alt_keys"] is not None and len(ks):  # one row per block and monomer name, formatted natively
+    if c["alt_keys"] is not None and len(ks) and alt_acc is not None:
+        alt_acc.append((name, c["alt_keys"], c["start"][keep], c["end"][keep], c["own_key"][keep], c["alt_vals"][keep]))
+    elif c["alt_keys"] is not None and len(ks):  # one row per block and monomer name, formatted natively
         fout_alt.write(lib.format_alt_rows(name, c["alt_keys"], c["start"][keep], c["end"][keep],
                                            c["own_key"][keep], c["alt_vals"][keep],
                                            max(1, min(threads, len(ks) // 512))))
@@ -318,11 +321,18 @@ def convert_tsv(decomposition, reads, monomers, outfile, identity_th, light, thr
                 own = [d["m"] for _, dec in batch for d in dec]
                 pre = _identities("".join(seqs), starts, ends, monomers, light, threads, own)
                 at = 0
+                alt_acc = []
                 for name, dec in batch:
                     sl = slice(at, at + len(dec))
                     print_read(fout, fout_alt, dec, reads[name], monomers, identity_th, light, threads, coef,
-                               tuple(p[sl] for p in pre))
+                               tuple(p[sl] for p in pre), alt_acc)
                     at += len(dec)
+                if alt_acc:  # the key list is the same for every read (it depends on the monomers only)
+                    fout_alt.write(lib.format_alt_rows(
+                        [a[0] for a in alt_acc], alt_acc[0][1], np.concatenate([a[2] for a in alt_acc]),
+                        np.concatenate([a[3] for a in alt_acc]), np.concatenate([a[4] for a in alt_acc]),
+                        np.concatenate([a[5] for a in alt_acc]), threads,
+                        row_read=np.concatenate([np.full(len(a[2]), x, dtype=np.int32) for x, a in enumerate(alt_acc)])))
                 i = j
 
 
