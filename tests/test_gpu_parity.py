@@ -395,3 +395,20 @@ def test_cli_two_processes_on_one_gpu(tmp_path):
     for fn in ("final_decomposition_raw.tsv", "final_decomposition.tsv", "final_decomposition_alt.tsv"):
         with open(os.path.join(outs[0], fn), "rb") as a, open(os.path.join(outs[1], fn), "rb") as b:
             assert a.read() == b.read(), fn
+
+
+def test_device_buffer_cache_reuse_and_release(oracle):
+    """Engines hand their large device buffers to a process-wide cache; a later engine with other sizes
+    and another template set must get correct results from recycled (stale) buffers, also after the
+    cache was released."""
+    mn1, ms1 = synth.make_monomers(12, seed=21)
+    mn2, ms2 = synth.make_monomers(5, seed=22)
+    rn1, rs1 = synth.make_reads(ms1, 40, read_len=30000, seed=21)
+    rn2, rs2 = synth.make_reads(ms2, 3, read_len=9000, seed=22)
+    a1 = lib.decompose(rn1, rs1, mn1, ms1)
+    b1 = lib.decompose(rn2, rs2, mn2, ms2, scoring=(-1, -2, -1, 1))
+    lib.release_cache()
+    b2 = lib.decompose(rn2, rs2, mn2, ms2, scoring=(-1, -2, -1, 1))
+    a2 = lib.decompose(rn1, rs1, mn1, ms1)
+    assert a1 == a2 and b1 == b2
+    assert b1 == oracle.decompose(rn2, rs2, mn2, ms2, threads=8, sc=(-1, -2, -1, 1))
