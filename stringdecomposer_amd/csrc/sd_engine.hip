@@ -136,7 +136,8 @@ struct DevBuf {
 struct sd_engine {
     sd_params p{};
     int device = 0;
-    sd::ScoreArgs sc{};
+    sd::ScoreArgs sc{};      // scores used on the device: the caller's divided by score_scale
+    int score_scale = 1;
     // templates (monomers + reverse complements, main.cpp:364-371)
     std::vector<std::string> tseq;
     std::vector<int32_t> tlen, toff;
@@ -298,7 +299,16 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
     if (n_mono <= 0) { set_err(errbuf, errlen, "no monomers"); return SD_ERR_PARAM; }
     std::unique_ptr<sd_engine> e(new sd_engine);
     e->p = *p;
-    e->sc = sd::ScoreArgs{p->ins, p->del, p->mismatch, p->match};
+    // A common factor of the four scores scales every DP value, every difference and every tie alike:
+    // the device works with the reduced scores (more scorings fit the packed fp16 / int16 cells) and
+    // the record scores are multiplied back when they are fetched.
+    {
+        auto gcd = [](int a, int b) { a = a < 0 ? -a : a; b = b < 0 ? -b : b; while (b) { const int t = a % b; a = b; b = t; } return a; };
+        int g = gcd(gcd(p->ins, p->del), gcd(p->mismatch, p->match));
+        if (g < 1) g = 1;
+        e->score_scale = g;
+        e->sc = sd::ScoreArgs{p->ins / g, p->del / g, p->mismatch / g, p->match / g};
+    }
     e->T = 2 * n_mono;
     e->tseq.resize((size_t)e->T);
     for (int j = 0; j < n_mono; ++j) {
@@ -612,6 +622,8 @@ int sd_engine_fetch(sd_engine* e, sd_rec** recs, int64_t** rec_off, char* errbuf
         sd_rec* out = static_cast<sd_rec*>(std::malloc(sizeof(sd_rec) * (size_t)std::max<int64_t>(total, 1)));
         static_assert(sizeof(sd_rec) == sizeof(sd::DevRec), "record layout");
         if (total > 0) SD_HIP(hipMemcpy(out, e->d_dense.p, sizeof(sd_rec) * (size_t)total, hipMemcpyDeviceToHost));
+        if (e->score_scale != 1)
+            for (int64_t x = 0; x < total; ++x) out[x].score *= e->score_scale;
         *recs = out;
         *rec_off = off;
     } catch (const HipFail& f) {

@@ -156,7 +156,9 @@ def test_full_c2_size_families_agree():
 
 
 @pytest.mark.parametrize("sc,cells", [((-2, -1, -3, 6), "f16"), ((-2, -2, -3, 7), "int16"),
-                                      ((-1, -1, -1, 1), "f16"), ((0, 0, -1, 11), "f16"), ((0, 0, -1, 12), "int16")])
+                                      ((-1, -1, -1, 1), "f16"), ((0, 0, -1, 11), "f16"), ((0, 0, -1, 12), "int16"),
+                                      # a common factor is divided out on the device and multiplied back
+                                      ((-10, -10, -10, 10), "f16"), ((-4, -6, -8, 4), "f16"), ((0, 0, -3, 36), "int16")])
 def test_fill_cell_format_switch_at_the_fp16_range_limit(oracle, sc, cells):
     """The fill uses packed fp16 cells while the score range keeps every value an exact integer
     (fast_plan_build), packed int16 beyond.  Scorings on both sides of the switch, on reads that
