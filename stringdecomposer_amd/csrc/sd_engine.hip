@@ -906,13 +906,22 @@ int sd_decompose(const char* const* read_names, const char* const* read_seqs,
     *tsv = nullptr;
     *tsv_len = 0;
     std::string err;
+    {
+        const int vrc = validate_params(p, err);  // before anything walks the chunk table (part_size > 0)
+        if (vrc) { set_err(errbuf, errlen, err); return vrc; }
+        if (n_reads < 0 || n_mono < 0 || (n_reads && (!read_names || !read_seqs || !read_lens)) ||
+            (n_mono && (!mono_names || !mono_seqs || !mono_lens))) {
+            set_err(errbuf, errlen, "null input array");
+            return SD_ERR_PARAM;
+        }
+    }
     std::vector<ReadView> reads((size_t)std::max(n_reads, 0));
     std::vector<sd::Seq> monos((size_t)std::max(n_mono, 0));
     {
         // alphabet check of all reads on the host threads; the first offending read (in input
         // order) is reported, as load_fasta does (main.cpp:329-341)
         std::vector<int> bad((size_t)std::max(n_reads, 0), 0);
-        sd::parallel_for(n_reads, p ? p->threads : 1, 8, [&](int64_t r) {
+        sd::parallel_for(n_reads, p->threads, 8, [&](int64_t r) {
             reads[(size_t)r] = ReadView{read_names[r], std::strlen(read_names[r]), read_seqs[r], read_lens[r]};
             std::string e2;
             bad[(size_t)r] = sd::check_alphabet(read_names[r], read_seqs[r], read_lens[r], e2) != SD_OK;

@@ -438,8 +438,15 @@ def main(argv=None):
     logger.info("Transforming raw alignments...")
 
     convert_tsv_fn = os.path.join(args.out_dir, args.out_file + ".tsv")
-    convert_tsv(raw_decomposition, reads, monomers, convert_tsv_fn, int(args.min_identity),
-                not args.second_best, threads=max(1, int(args.threads)))
+    try:
+        convert_tsv(raw_decomposition, reads, monomers, convert_tsv_fn, int(args.min_identity),
+                    not args.second_best, threads=max(1, int(args.threads)))
+    except lib.SdError as e:
+        # e.g. a block longer than the identity kernel accepts (-b >= 65000 with a degenerate scoring):
+        # the raw decomposition is already on disk; end with a message, not a traceback
+        sys.stderr.write("post-processing failed: " + e.msg + "\n")
+        logger.info("Transformation failed (%s); the raw decomposition is in %s" % (e.msg, raw_decomp_fn))
+        sys.exit(e.code if 0 < e.code < 256 else 1)
     logger.info("Transformation finished. Results can be found in " + convert_tsv_fn)
 
     logger.info("Thank you for using StringDecomposer!")

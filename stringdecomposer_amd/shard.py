@@ -78,6 +78,18 @@ def sum_over_ranks(dist, value, device="cpu"):
     return int(t.item())
 
 
+def _name_reads(msg, read_names):
+    """The chunk-range entry point knows reads by index only ("Sequence #12 ..."): put the read's
+    name back so that the text equals the single-process / reference message (main.cpp:335)."""
+    import re
+
+    def sub(m):
+        i = int(m.group(1))
+        nm = read_names[i] if 0 <= i < len(read_names) else m.group(0)
+        return "Sequence " + (nm.decode() if isinstance(nm, bytes) else str(nm))
+    return re.sub(r"Sequence #(\d+)", sub, msg)
+
+
 def decompose_sharded(read_names, read_seqs, mono_names, mono_seqs, dist=None, range_fn=None, **params):
     """Raw TSV (bytes) of the whole job on rank 0, None on the other ranks.
 
@@ -96,7 +108,22 @@ def decompose_sharded(read_names, read_seqs, mono_names, mono_seqs, dist=None, r
     if range_fn is None:
         params = dict(params, device=params.get("device", local_rank))
         range_fn = lib.decompose_chunk_range
-    recs, off = range_fn(read_seqs, mono_seqs, lo, hi, **params)
+    # A rank whose range holds an undefined symbol (or whose device fails) must not leave the others
+    # blocked in the gather: every rank first learns every rank's status and all of them raise the
+    # error of the lowest-numbered failing rank -- its range comes first in the chunk table, so that
+    # is the read the reference (which checks reads in input order, main.cpp:329-341) would report.
+    failure = None
+    recs = off = None
+    try:
+        recs, off = range_fn(read_seqs, mono_seqs, lo, hi, **params)
+    except lib.SdError as e:
+        failure = (e.code, _name_reads(e.msg, read_names))
+    if dist is not None and ws > 1:
+        status = [None] * ws
+        dist.all_gather_object(status, failure)
+        failure = next((s for s in status if s is not None), None)
+    if failure is not None:
+        raise lib.SdError(*failure)
     recs = np.ascontiguousarray(recs)
     off = np.ascontiguousarray(off, dtype=np.int64)
     if dist is None or ws == 1:

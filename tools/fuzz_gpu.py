@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity campaign (developer tool, needs a GPU): random template sets, scorings,
 chunk sizes, N densities and --ed_thr values through libsd_hip vs the CPU oracle.
-usage: python tools/fuzz_gpu.py [cases] [seed]"""
+usage: python tools/fuzz_gpu.py [cases] [seed] [log file to append the summary to]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -92,5 +92,15 @@ for case in range(cases):
         synth.write_fasta(os.path.join(d, "r.fa"), rn, reads)
         synth.write_fasta(os.path.join(d, "m.fa"), mn, ms)
         open(os.path.join(d, "params.txt"), "w").write(repr((sc, part, ov, ed)))
-print("fuzz: %d cases, %d mismatches, %.1fs" % (cases, bad, time.time() - t0))
+summary = "fuzz: seed %d, %d cases, %d mismatches, %.1fs" % (seed, cases, bad, time.time() - t0)
+print(summary)
+if len(sys.argv) > 3:   # append to a log (copied to profiles/ after the run): which build, which seeds
+    import hashlib
+    src = hashlib.sha256()
+    cs = os.path.join(ROOT, "stringdecomposer_amd", "csrc")
+    for fn in sorted(os.listdir(cs)):
+        if fn.endswith((".hip", ".hpp")):
+            src.update(open(os.path.join(cs, fn), "rb").read())
+    with open(sys.argv[3], "a") as f:
+        f.write("%s  csrc-sha256 %s  %s\n" % (time.strftime("%Y-%m-%d %H:%M:%S"), src.hexdigest()[:16], summary))
 sys.exit(1 if bad else 0)
