@@ -145,6 +145,34 @@ int sd_engine_timings(sd_engine* e, float ms[4]);
  * [6] bytes of HBM workspace allocated [7] number of fill launches per run */
 int sd_engine_info(sd_engine* e, int64_t info[8]);
 
+/* ---- streaming form: sequences in host memory -> rows in host memory ------------------------
+ * AlignReadsSet (main.cpp:67-122) without the text: chunk table (:70-81), DP + traceback per chunk
+ * (:84-102), per-read flush with chunk offsets and seam merge (:104-117).  A stream keeps two device
+ * batches in flight: every submitted job (a read set) is cut into `sub_batches` device batches of
+ * consecutive chunks; while the device works on one batch the host packs and uploads the next (pinned
+ * staging, asynchronous copies) and assembles the previous one, across job boundaries.  This is the
+ * region SURVEY.md 8(d) defines the throughput metric on, and what bench.py times.
+ * Sequences are NOT validated here (they went through sd_fasta_load / sd_decompose's check). */
+typedef struct sd_stream sd_stream;
+int sd_stream_create(sd_stream** out, const sd_params* p, const char* const* mono_seqs,
+                     const int32_t* mono_lens, int32_t n_mono, int32_t sub_batches, char* errbuf,
+                     size_t errlen);
+void sd_stream_destroy(sd_stream* s);
+/* Packs, uploads and enqueues the job's batches; returns while the last ones are still running.  The
+ * read buffers are no longer needed when it returns. */
+int sd_stream_submit(sd_stream* s, const char* const* read_seqs, const int64_t* read_lens,
+                     int32_t n_reads, char* errbuf, size_t errlen);
+/* Rows of the oldest submitted job (FIFO): read r owns rows[row_off[r] .. row_off[r+1]), read-global
+ * coordinates, seam-merged.  Both arrays are malloc'ed (sd_free). */
+int sd_stream_collect(sd_stream* s, sd_rec** rows, int64_t** row_off, int64_t* n_rows, char* errbuf,
+                      size_t errlen);
+/* Accumulated over all collected batches: [0] fill [1] traceback [2] compaction [3] whole-run HIP-event
+ * ms (per-batch spans; batches on the two streams overlap, so these do not add up to wall time),
+ * [4] fill launches [5] batches [6] chunk rows, host ms: [7] pack+enqueue [8] wait for the device
+ * [9] assembly [10] inside submit [11] inside collect, [12] jobs [13] sub_batches [14] row budget. */
+int sd_stream_stats(sd_stream* s, double out[16]);
+int sd_stream_info(sd_stream* s, int64_t info[8]);   /* as sd_engine_info, of the stream's engine */
+
 /* ---- host-side pieces of the path, exported for CPU-only tests ----------------------------- */
 
 /* chunk plan of one read (main.cpp:70-81): up to cap (offset,len) pairs; returns the count */
@@ -155,6 +183,10 @@ int32_t sd_seam_merge(sd_rec* recs, int32_t n);
 /* SaveBatch text of one read's rows (main.cpp:272-285); *txt malloc'ed (sd_free) */
 int sd_format_rows(const char* read_name, const char* const* tmpl_names, const sd_rec* rows,
                    int32_t n_rows, char** txt, size_t* txt_len);
+/* 2-bit packing of a chunk as the device reads it (16 bases per dword, base i at bits 2*(i&15), A,C,G,T
+ * = 0..3, N = 0 + a set bit in the optional 1-bit mask); returns 1 if the chunk holds an N, -1 on bad
+ * arguments.  words: (n+15)/16 dwords, nmask (may be NULL): (n+31)/32 dwords. */
+int32_t sd_pack_bases(const char* seq, int64_t n, uint32_t* words, uint32_t* nmask);
 /* FASTA validation + load with the reference's semantics (main.cpp:314-346).  Arrays malloc'ed,
  * free with sd_fasta_free. */
 typedef struct sd_fasta {

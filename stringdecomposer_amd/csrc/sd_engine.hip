@@ -131,6 +131,27 @@ struct DevBuf {
     ~DevBuf() { free_(); }
 };
 
+// Page-locked host buffer (grow-only): staging for asynchronous H2D / D2H copies.
+template <class T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    void alloc(size_t count) {
+        if (count == 0) count = 1;
+        if (count <= cap) return;
+        free_();
+        const size_t want = count + count / 8;  // a little slack: batches of similar size reuse it
+        SD_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocDefault));
+        cap = want;
+    }
+    void free_() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    ~PinBuf() { free_(); }
+};
+
 }  // namespace
 
 struct sd_engine {
@@ -167,7 +188,6 @@ struct sd_engine {
     DevBuf<int32_t> d_endvl, d_endoff, d_dist;
     DevBuf<uint32_t> d_cendoff, d_crank;
     DevBuf<int> d_queue;             // work-queue heads of the persistent kernels (fill, trace)
-    DevBuf<int> d_order;             // chunk indices, longest first
     int n_cu = 256;
 
     // batch
@@ -177,8 +197,18 @@ struct sd_engine {
     std::vector<int32_t> read_nchunks;
     int32_t n_reads = 0;
     int64_t rows = 0;
-    DevBuf<sd::ChunkDesc> d_chunks;
-    DevBuf<uint32_t> d_bases2, d_nmask;
+    // batch input: one pinned staging buffer and one device buffer, sections [chunk descriptors]
+    // [chunk order, longest first][2-bit bases][N mask], one asynchronous H2D copy per load
+    PinBuf<uint8_t> h_in;
+    DevBuf<uint8_t> d_in;
+    sd::ChunkDesc* dp_chunks = nullptr;
+    int* dp_order = nullptr;
+    uint32_t* dp_bases2 = nullptr;
+    uint32_t* dp_nmask = nullptr;
+    hipEvent_t ev_in = nullptr;       // the H2D copy of the staging buffer has completed
+    bool in_pending = false;
+    PinBuf<int64_t> h_roff;           // record offsets of the last run (copied right behind the compaction)
+    PinBuf<sd_rec> h_recs;            // compact records of the last fetch
     DevBuf<int32_t> d_B, d_argB, d_cnt;
     DevBuf<sd::DevRec> d_recs, d_dense;
     DevBuf<int64_t> d_roff;
@@ -194,14 +224,14 @@ struct sd_engine {
     ~sd_engine() {
         for (hipEvent_t e : ev_fill) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_trace) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {ev_run0, ev_run1, ev_cmp0, ev_cmp1})
+        for (hipEvent_t e : {ev_run0, ev_run1, ev_cmp0, ev_cmp1, ev_in})
             if (e) (void)hipEventDestroy(e);
     }
 
     size_t workspace_bytes() const {
         return d_tmeta.bytes() + d_tend_kd.bytes() + d_tend_j.bytes() + d_ptr.bytes() +
                d_ftable.bytes() + d_flane.bytes() + d_fslot.bytes() + d_ftcodes.bytes() + d_fckpt.bytes() +
-               d_fckbase.bytes() + d_chunks.bytes() + d_bases2.bytes() + d_nmask.bytes() +
+               d_fckbase.bytes() + d_in.bytes() +
                d_B.bytes() + d_argB.bytes() + d_cnt.bytes() + d_recs.bytes() + d_dense.bytes() +
                d_roff.bytes();
     }
@@ -387,6 +417,7 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
         SD_HIP(hipEventCreate(&e->ev_run1));
         SD_HIP(hipEventCreate(&e->ev_cmp0));
         SD_HIP(hipEventCreate(&e->ev_cmp1));
+        SD_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
     } catch (const HipFail& f) {
         set_err(errbuf, errlen, f.msg);
         return SD_ERR_HIP;
@@ -401,80 +432,106 @@ void sd_engine_destroy(sd_engine* e) {
     delete e;
 }
 
-// Packs the given chunks (pointer + length each), uploads them and sizes the per-batch device
-// buffers.  e->chunks must be empty on entry; chunk c refers to cptr[c][0 .. clen[c]).
+// Packs the given chunks (pointer + length each) into the pinned staging buffer, starts their copy to
+// the device on `st` (asynchronous) and sizes the per-batch device buffers.  Chunk c refers to
+// cptr[c][0 .. clen[c]).  The kernels of sd_engine_run must be enqueued on the same stream (or after
+// a synchronisation with it).
 static int load_chunks_impl(sd_engine* e, const std::vector<const char*>& cptr,
-                            const std::vector<int32_t>& clen, char* errbuf, size_t errlen) {
+                            const std::vector<int32_t>& clen, hipStream_t st, char* errbuf, size_t errlen) {
     e->ran = false;
     e->chunks.clear();
-    std::vector<uint32_t> bases2, nmask;
+    const size_t C = cptr.size();
+    e->chunks.resize(C);
     uint64_t row0 = 0;
     size_t words_total = 0;
-    for (size_t c = 0; c < cptr.size(); ++c) {
-        sd::ChunkDesc cd{};
+    for (size_t c = 0; c < C; ++c) {
+        sd::ChunkDesc& cd = e->chunks[c];
+        cd = sd::ChunkDesc{};
         cd.woff = (uint32_t)words_total;
         cd.n = clen[c];
         cd.noff = -1;
         cd.row0 = row0;
         row0 += (uint64_t)clen[c];
         words_total += ((size_t)clen[c] + 15) / 16;
-        e->chunks.push_back(cd);
     }
     if (words_total >= (1ull << 31)) {
         set_err(errbuf, errlen, "batch too large: split the reads into smaller groups");
         return SD_ERR_UNSUPPORTED;
     }
-    bases2.assign(words_total, 0u);
-    {
-        const size_t C0 = e->chunks.size();
-        std::vector<uint8_t> hasn(C0, 0);
-        sd::parallel_for((int64_t)C0, e->p.threads, 16, [&](int64_t c) {
-            const sd::ChunkDesc& cd = e->chunks[(size_t)c];
-            hasn[(size_t)c] = sd::pack_chunk(cptr[(size_t)c], cd.n, bases2.data() + cd.woff) ? 1 : 0;
-        });
-        size_t nwords = 0;
-        for (size_t c = 0; c < C0; ++c)
-            if (hasn[c]) {
-                e->chunks[c].noff = (int32_t)nwords;
-                nwords += ((size_t)e->chunks[c].n + 31) / 32;
-            }
-        nmask.assign(nwords, 0u);
-        if (nwords)
-            sd::parallel_for((int64_t)C0, e->p.threads, 16, [&](int64_t c) {
-                const sd::ChunkDesc& cd = e->chunks[(size_t)c];
-                if (cd.noff < 0) return;
-                const char* s = cptr[(size_t)c];
-                for (int32_t i = 0; i < cd.n; ++i)
-                    if (s[i] == 'N') nmask[(size_t)cd.noff + (size_t)(i >> 5)] |= 1u << (i & 31);
-            });
-    }
     e->rows = (int64_t)row0;
-    const size_t C = e->chunks.size();
     try {
         SD_HIP(hipSetDevice(e->device));
-        const int64_t nck = e->family == 2 ? sd::fast_ckpt_rows_total(e->fplan, e->chunks) : 0;
-        e->d_chunks.upload(e->chunks);
-        {
-            std::vector<int> order(C);
-            for (size_t c = 0; c < C; ++c) order[c] = (int)c;
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return e->chunks[(size_t)a].n > e->chunks[(size_t)b].n; });
-            e->d_order.upload(order);
+        if (e->in_pending) {  // the previous batch's copy still reads the staging buffer
+            SD_HIP(hipEventSynchronize(e->ev_in));
+            e->in_pending = false;
         }
-        e->d_bases2.upload(bases2);
-        e->d_nmask.upload(nmask);
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t o_chunks = 0;
+        const size_t o_order = al(o_chunks + C * sizeof(sd::ChunkDesc));
+        const size_t o_bases = al(o_order + C * sizeof(int));
+        const size_t o_nmask = al(o_bases + words_total * sizeof(uint32_t));
+        // worst-case N mask (every chunk has N): one bit per base
+        size_t nwords_max = 0;
+        for (size_t c = 0; c < C; ++c) nwords_max += ((size_t)clen[c] + 31) / 32;
+        e->h_in.alloc(o_nmask + nwords_max * sizeof(uint32_t) + 256);
+        uint32_t* bases2 = reinterpret_cast<uint32_t*>(e->h_in.p + o_bases);
+        uint32_t* nmask = reinterpret_cast<uint32_t*>(e->h_in.p + o_nmask);
+        size_t nwords = 0;
+        {
+            std::vector<uint8_t> hasn(C, 0);
+            sd::parallel_for((int64_t)C, e->p.threads, 16, [&](int64_t c) {
+                const sd::ChunkDesc& cd = e->chunks[(size_t)c];
+                hasn[(size_t)c] = sd::pack_chunk(cptr[(size_t)c], cd.n, bases2 + cd.woff) ? 1 : 0;
+            });
+            for (size_t c = 0; c < C; ++c)
+                if (hasn[c]) {
+                    e->chunks[c].noff = (int32_t)nwords;
+                    nwords += ((size_t)e->chunks[c].n + 31) / 32;
+                }
+            if (nwords) {
+                std::memset(nmask, 0, nwords * sizeof(uint32_t));
+                sd::parallel_for((int64_t)C, e->p.threads, 16, [&](int64_t c) {
+                    const sd::ChunkDesc& cd = e->chunks[(size_t)c];
+                    if (cd.noff < 0) return;
+                    const char* s = cptr[(size_t)c];
+                    for (int32_t i = 0; i < cd.n; ++i)
+                        if (s[i] == 'N') nmask[(size_t)cd.noff + (size_t)(i >> 5)] |= 1u << (i & 31);
+                });
+            }
+        }
+        const int64_t nck = e->family == 2 ? sd::fast_ckpt_rows_total(e->fplan, e->chunks) : 0;
+        if (C) std::memcpy(e->h_in.p + o_chunks, e->chunks.data(), C * sizeof(sd::ChunkDesc));
+        {
+            // longest chunks first; almost every chunk has the full length, so a counting pass over the
+            // two or three distinct lengths would do as well -- the sort is O(C log C) on ints
+            int* order = reinterpret_cast<int*>(e->h_in.p + o_order);
+            for (size_t c = 0; c < C; ++c) order[c] = (int)c;
+            std::stable_sort(order, order + C, [&](int a, int b) { return e->chunks[(size_t)a].n > e->chunks[(size_t)b].n; });
+        }
+        const size_t in_bytes = o_nmask + nwords * sizeof(uint32_t);
+        e->d_in.alloc(o_nmask + nwords_max * sizeof(uint32_t) + 256);
+        e->dp_chunks = reinterpret_cast<sd::ChunkDesc*>(e->d_in.p + o_chunks);
+        e->dp_order = reinterpret_cast<int*>(e->d_in.p + o_order);
+        e->dp_bases2 = reinterpret_cast<uint32_t*>(e->d_in.p + o_bases);
+        e->dp_nmask = reinterpret_cast<uint32_t*>(e->d_in.p + o_nmask);
+        SD_HIP(hipMemcpyAsync(e->d_in.p, e->h_in.p, in_bytes, hipMemcpyHostToDevice, st));
+        SD_HIP(hipEventRecord(e->ev_in, st));
+        e->in_pending = true;
         e->d_B.alloc((size_t)e->rows + C);
         e->d_argB.alloc((size_t)e->rows + C);
         e->d_cnt.alloc(C);
         e->d_roff.alloc(C + 1);
+        e->h_roff.alloc(C + 1);
         e->d_recs.alloc((size_t)e->rows);
         e->dense_cap = std::max<int64_t>(4096, e->rows / 16);
         e->d_dense.alloc((size_t)e->dense_cap);
+        e->dense_cap = (int64_t)e->d_dense.cap;
         e->subs.clear();
         if (e->family == 1) {
             // pointer workspace: sub-batches of consecutive chunks within the budget
             size_t free_b = 0, total_b = 0;
             SD_HIP(hipMemGetInfo(&free_b, &total_b));
-            size_t budget = std::min<size_t>(free_b / 2, (size_t)48 << 30);
+            size_t budget = std::min<size_t>(free_b / 2 + e->d_ptr.bytes(), (size_t)48 << 30);
             size_t max_sub = 0, cur = 0;
             int begin = 0;
             for (size_t c = 0; c < C; ++c) {
@@ -533,7 +590,15 @@ int sd_engine_load_reads(sd_engine* e, const char* const* read_seqs, const int64
         e->read_nchunks[(size_t)r] = cnt;
     }
     if (n_chunks) *n_chunks = (int64_t)cptr.size();
-    return load_chunks_impl(e, cptr, clen, errbuf, errlen);
+    // default (null) stream: a later sd_engine_run on any blocking stream is ordered behind the copy;
+    // the explicit wait also covers non-blocking streams
+    const int rc = load_chunks_impl(e, cptr, clen, nullptr, errbuf, errlen);
+    if (rc == SD_OK && hipEventSynchronize(e->ev_in) != hipSuccess) {
+        set_err(errbuf, errlen, "H2D copy of the packed reads failed");
+        return SD_ERR_HIP;
+    }
+    e->in_pending = false;
+    return rc;
 }
 
 int sd_engine_run(sd_engine* e, void* hip_stream, char* errbuf, size_t errlen) {
@@ -550,13 +615,13 @@ int sd_engine_run(sd_engine* e, void* hip_stream, char* errbuf, size_t errlen) {
                     const int b = e->subs[s].first, n_sub = e->subs[s].second - b;
                     const uint64_t row0_base = e->chunks[(size_t)b].row0;
                     SD_HIP(hipEventRecord(e->ev_fill[2 * s], st));
-                    sd::launch_generic_fill(e->Q, e->threads, n_sub, st, e->d_chunks.p, b,
-                                            e->d_bases2.p, e->d_nmask.p, e->d_tmeta.p,
+                    sd::launch_generic_fill(e->Q, e->threads, n_sub, st, e->dp_chunks, b,
+                                            e->dp_bases2, e->dp_nmask, e->d_tmeta.p,
                                             e->d_tend_kd.p, e->d_tend_j.p, e->sc, e->rowBytes,
                                             e->d_ptr.p, row0_base, e->d_B.p, e->d_argB.p);
                     SD_HIP(hipEventRecord(e->ev_fill[2 * s + 1], st));
                     SD_HIP(hipEventRecord(e->ev_trace[2 * s], st));
-                    sd::launch_generic_trace(n_sub, st, e->d_chunks.p, b, e->d_ptr.p, row0_base,
+                    sd::launch_generic_trace(n_sub, st, e->dp_chunks, b, e->d_ptr.p, row0_base,
                                              e->rowBytes, e->d_B.p, e->d_argB.p, e->d_toff.p,
                                              e->d_tlen.p, e->d_recs.p, e->d_cnt.p);
                     SD_HIP(hipEventRecord(e->ev_trace[2 * s + 1], st));
@@ -565,28 +630,31 @@ int sd_engine_run(sd_engine* e, void* hip_stream, char* errbuf, size_t errlen) {
             } else {
                 const bool ranked = e->p.ed_thr > -1;
                 if (ranked)  // main.cpp:91-93: per-chunk template prefilter
-                    sd::launch_edthr_filter(st, e->d_chunks.p, C, e->T, e->p.ed_thr, e->d_bases2.p,
-                                            e->d_nmask.p, e->d_peq.p, e->d_tlen.p, e->d_endvl.p,
+                    sd::launch_edthr_filter(st, e->dp_chunks, C, e->T, e->p.ed_thr, e->dp_bases2,
+                                            e->dp_nmask, e->d_peq.p, e->d_tlen.p, e->d_endvl.p,
                                             e->d_endoff.p, e->d_dist.p, e->d_cendoff.p, e->d_crank.p);
                 SD_HIP(hipEventRecord(e->ev_fill[0], st));
-                sd::launch_fast_fill(e->fplan, st, e->d_chunks.p, C, e->d_bases2.p, e->d_nmask.p,
+                sd::launch_fast_fill(e->fplan, st, e->dp_chunks, C, e->dp_bases2, e->dp_nmask,
                                      e->d_ftable.p, e->d_flane.p, e->sc, e->d_B.p, e->d_argB.p,
-                                     e->d_fckpt.p, e->d_fckbase.p, e->d_queue.p, e->d_order.p, e->n_cu,
+                                     e->d_fckpt.p, e->d_fckbase.p, e->d_queue.p, e->dp_order, e->n_cu,
                                      ranked ? e->d_cendoff.p : nullptr, ranked ? e->d_crank.p : nullptr);
                 SD_HIP(hipEventRecord(e->ev_fill[1], st));
                 SD_HIP(hipEventRecord(e->ev_trace[0], st));
-                sd::launch_fast_trace(e->fplan, st, e->d_chunks.p, C, e->d_bases2.p, e->d_nmask.p,
+                sd::launch_fast_trace(e->fplan, st, e->dp_chunks, C, e->dp_bases2, e->dp_nmask,
                                       e->d_fslot.p, e->d_ftcodes.p, e->d_flane.p, e->d_toff.p,
                                       e->d_tlen.p, e->sc, e->d_B.p, e->d_argB.p, e->d_fckpt.p,
-                                      e->d_fckbase.p, e->d_recs.p, e->d_cnt.p, e->d_queue.p + 1, e->d_order.p,
+                                      e->d_fckbase.p, e->d_recs.p, e->d_cnt.p, e->d_queue.p + 1, e->dp_order,
                                       e->n_cu);
                 SD_HIP(hipEventRecord(e->ev_trace[1], st));
                 e->fill_launches = 1;
             }
             SD_HIP(hipEventRecord(e->ev_cmp0, st));
-            sd::launch_compact(st, e->d_chunks.p, C, e->d_cnt.p, e->d_roff.p, e->d_recs.p,
+            sd::launch_compact(st, e->dp_chunks, C, e->d_cnt.p, e->d_roff.p, e->d_recs.p,
                                e->d_dense.p, e->dense_cap, true);
             SD_HIP(hipEventRecord(e->ev_cmp1, st));
+            // the record offsets travel right behind the compaction: the fetch then knows the record
+            // count as soon as the stream is idle, without a second round trip
+            SD_HIP(hipMemcpyAsync(e->h_roff.p, e->d_roff.p, sizeof(int64_t) * ((size_t)C + 1), hipMemcpyDeviceToHost, st));
         }
         SD_HIP(hipEventRecord(e->ev_run1, st));
         SD_HIP(hipGetLastError());
@@ -599,37 +667,55 @@ int sd_engine_run(sd_engine* e, void* hip_stream, char* errbuf, size_t errlen) {
     return SD_OK;
 }
 
-int sd_engine_fetch(sd_engine* e, sd_rec** recs, int64_t** rec_off, char* errbuf, size_t errlen) {
-    if (!e || !recs || !rec_off) return SD_ERR_PARAM;
-    *recs = nullptr;
-    *rec_off = nullptr;
+// Waits for the last run and brings its compact records into the pinned buffers h_roff / h_recs
+// (valid until the next load / run of this engine).
+static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errlen) {
+    total = 0;
     if (!e->ran) { set_err(errbuf, errlen, "sd_engine_fetch before sd_engine_run"); return SD_ERR_PARAM; }
     const size_t C = e->chunks.size();
     try {
         SD_HIP(hipSetDevice(e->device));
         SD_HIP(hipStreamSynchronize(e->last_stream));
-        int64_t* off = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * (C + 1)));
-        off[0] = 0;
-        if (C > 0) SD_HIP(hipMemcpy(off, e->d_roff.p, sizeof(int64_t) * (C + 1), hipMemcpyDeviceToHost));
-        const int64_t total = C > 0 ? off[C] : 0;
+        e->in_pending = false;
+        if (C == 0) { e->h_roff.alloc(1); e->h_roff.p[0] = 0; return SD_OK; }
+        total = e->h_roff.p[C];
         if (total > e->dense_cap) {
-            e->dense_cap = total;
             e->d_dense.alloc((size_t)total);
-            sd::launch_compact(e->last_stream, e->d_chunks.p, (int)C, e->d_cnt.p, e->d_roff.p,
+            e->dense_cap = (int64_t)e->d_dense.cap;
+            sd::launch_compact(e->last_stream, e->dp_chunks, (int)C, e->d_cnt.p, e->d_roff.p,
                                e->d_recs.p, e->d_dense.p, e->dense_cap, false);
             SD_HIP(hipStreamSynchronize(e->last_stream));
         }
-        sd_rec* out = static_cast<sd_rec*>(std::malloc(sizeof(sd_rec) * (size_t)std::max<int64_t>(total, 1)));
+        e->h_recs.alloc((size_t)std::max<int64_t>(total, 1));
         static_assert(sizeof(sd_rec) == sizeof(sd::DevRec), "record layout");
-        if (total > 0) SD_HIP(hipMemcpy(out, e->d_dense.p, sizeof(sd_rec) * (size_t)total, hipMemcpyDeviceToHost));
+        if (total > 0) {
+            SD_HIP(hipMemcpyAsync(e->h_recs.p, e->d_dense.p, sizeof(sd_rec) * (size_t)total, hipMemcpyDeviceToHost, e->last_stream));
+            SD_HIP(hipStreamSynchronize(e->last_stream));
+        }
         if (e->score_scale != 1)
-            for (int64_t x = 0; x < total; ++x) out[x].score *= e->score_scale;
-        *recs = out;
-        *rec_off = off;
+            for (int64_t x = 0; x < total; ++x) e->h_recs.p[x].score *= e->score_scale;
     } catch (const HipFail& f) {
         set_err(errbuf, errlen, f.msg);
         return SD_ERR_HIP;
     }
+    return SD_OK;
+}
+
+int sd_engine_fetch(sd_engine* e, sd_rec** recs, int64_t** rec_off, char* errbuf, size_t errlen) {
+    if (!e || !recs || !rec_off) return SD_ERR_PARAM;
+    *recs = nullptr;
+    *rec_off = nullptr;
+    int64_t total = 0;
+    const int rc = fetch_pinned(e, total, errbuf, errlen);
+    if (rc) return rc;
+    const size_t C = e->chunks.size();
+    int64_t* off = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * (C + 1)));
+    sd_rec* out = static_cast<sd_rec*>(std::malloc(sizeof(sd_rec) * (size_t)std::max<int64_t>(total, 1)));
+    if (!off || !out) { std::free(off); std::free(out); set_err(errbuf, errlen, "out of host memory"); return SD_ERR_INTERNAL; }
+    std::memcpy(off, e->h_roff.p, sizeof(int64_t) * (C + 1));
+    if (total > 0) std::memcpy(out, e->h_recs.p, sizeof(sd_rec) * (size_t)total);
+    *recs = out;
+    *rec_off = off;
     return SD_OK;
 }
 
@@ -735,89 +821,170 @@ struct TemplateSet {
 };
 }  // namespace
 
+// Device pipeline: up to two batches of chunks in flight on two engines / two non-blocking streams.
+// push() packs a batch into the engine's pinned staging buffer, starts its H2D copy and enqueues its
+// kernels (all asynchronous); pop() waits for the oldest batch, brings its records into pinned host
+// memory and hands them to that batch's sink.  While the device works on batch b the host packs and
+// enqueues b+1 and then assembles b; kernels of consecutive batches sit on different streams, so the
+// tail of one launch overlaps the head of the next.
+using RecSink = std::function<void(const sd_rec*, const int64_t*, size_t)>;  // recs, rec_off (n+1), n chunks
+namespace {
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Pipeline {
+    static constexpr int NS = 2;
+    sd_params p{};
+    std::vector<const char*> mseq;
+    std::vector<int32_t> mlen;
+    sd_engine* eng[NS] = {nullptr, nullptr};
+    hipStream_t st[NS] = {nullptr, nullptr};
+    RecSink sinks[NS];
+    uint64_t pushed = 0, popped = 0;
+    char eb[1024] = {0};
+    // accumulated over all batches: HIP-event kernel times (ms) and host stage times (s)
+    double fill_ms = 0, trace_ms = 0, compact_ms = 0, run_ms = 0;
+    double pack_s = 0, wait_s = 0, sink_s = 0;
+    int64_t launches = 0, batches = 0, rows = 0;
+
+    int create(const sd_params* pp, const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono) {
+        p = *pp;
+        mseq.assign(mono_seqs, mono_seqs + n_mono);
+        mlen.assign(mono_lens, mono_lens + n_mono);
+        return sd_engine_create(&eng[0], &p, mseq.data(), mlen.data(), n_mono, eb, sizeof eb);
+    }
+    // rows one batch may hold: <= 48 M (~900 reads of 50 kb: fills the GPU twice over and still leaves the
+    // host/device pipeline stages to overlap) and <= 27 % of the free HBM
+    int64_t row_budget() const {
+        int64_t budget = (int64_t)48 << 20;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            // per row: B + argB + records (24 B) + fast-family checkpoints (P*256 B every FAST_R rows)
+            const double per_row = 26.0 + (eng[0]->family == 2 ? eng[0]->fplan.P * 256.0 / sd::FAST_R : 0.0);
+            budget = std::min<int64_t>(budget, (int64_t)(0.27 * (double)(free_b + held_bytes()) / per_row));
+            budget = std::max<int64_t>(budget, (int64_t)p.part_size + p.overlap);
+        }
+        if (p.max_batch_rows > 0) budget = p.max_batch_rows;  // explicit cap (tests, small GPUs)
+        return budget;
+    }
+    size_t held_bytes() const {
+        size_t h = 0;
+        for (sd_engine* e : eng) if (e) h += e->workspace_bytes();
+        return h;
+    }
+    int inflight() const { return (int)(pushed - popped); }
+    int push(const std::vector<const char*>& cptr, const std::vector<int32_t>& clen, RecSink sink) {
+        int rc = SD_OK;
+        if (inflight() == NS) rc = pop();
+        if (rc) return rc;
+        const int k = (int)(pushed % NS);
+        if (!eng[k]) {
+            rc = sd_engine_create(&eng[k], &p, mseq.data(), mlen.data(), (int32_t)mseq.size(), eb, sizeof eb);
+            if (rc) return rc;
+        }
+        if (!st[k] && pushed > 0) {  // a lone batch runs on the null stream; a second one brings the streams in
+            for (int q = 0; q < NS; ++q)
+                if (!st[q] && hipStreamCreateWithFlags(&st[q], hipStreamNonBlocking) != hipSuccess) st[q] = nullptr;
+        }
+        const double t0 = now_s();
+        rc = load_chunks_impl(eng[k], cptr, clen, st[k], eb, sizeof eb);
+        if (rc == SD_OK) rc = sd_engine_run(eng[k], st[k], eb, sizeof eb);
+        pack_s += now_s() - t0;
+        if (rc) return rc;
+        sinks[k] = std::move(sink);
+        ++pushed;
+        return SD_OK;
+    }
+    int pop() {
+        if (inflight() == 0) return SD_OK;
+        const int k = (int)(popped % NS);
+        int64_t total = 0;
+        double t0 = now_s();
+        int rc = fetch_pinned(eng[k], total, eb, sizeof eb);
+        wait_s += now_s() - t0;
+        ++popped;
+        if (rc) return rc;
+        float ms[4];
+        if (sd_engine_timings(eng[k], ms) == SD_OK) { fill_ms += ms[0]; trace_ms += ms[1]; compact_ms += ms[2]; run_ms += ms[3]; }
+        launches += eng[k]->fill_launches;
+        ++batches;
+        rows += eng[k]->rows;
+        t0 = now_s();
+        if (sinks[k]) sinks[k](eng[k]->h_recs.p, eng[k]->h_roff.p, eng[k]->chunks.size());
+        sinks[k] = nullptr;
+        sink_s += now_s() - t0;
+        return SD_OK;
+    }
+    int drain() {
+        int rc = SD_OK;
+        while (inflight() > 0) {
+            const int r2 = pop();
+            if (r2 && !rc) rc = r2;
+        }
+        return rc;
+    }
+    ~Pipeline() {
+        if (inflight() > 0) (void)hipDeviceSynchronize();  // nothing may still run on buffers we free
+        for (hipStream_t s2 : st)
+            if (s2) (void)hipStreamDestroy(s2);
+        for (sd_engine* e : eng)
+            if (e) sd_engine_destroy(e);
+    }
+};
+
+// Cuts the chunks [c_lo, c_hi) of a table into device batches of consecutive chunks: at most `budget`
+// rows each, and at least `min_batches` batches (when there are that many chunks) of about equal rows.
+void plan_batches(const std::vector<CRef>& table, size_t c_lo, size_t c_hi, int64_t budget, int min_batches,
+                  std::vector<std::pair<size_t, size_t>>& out) {
+    out.clear();
+    if (min_batches > 1) {
+        int64_t tot = 0;
+        for (size_t c = c_lo; c < c_hi; ++c) tot += table[c].len;
+        budget = std::min<int64_t>(budget, std::max<int64_t>(1, (tot + min_batches - 1) / min_batches));
+    }
+    for (size_t c0 = c_lo; c0 < c_hi;) {
+        int64_t rows = 0;
+        size_t c1 = c0;
+        while (c1 < c_hi && (c1 == c0 || rows + table[c1].len <= budget)) rows += table[c1++].len;
+        out.emplace_back(c0, c1);
+        c0 = c1;
+    }
+}
+}  // namespace
+
 // Runs the chunks [c_lo, c_hi) of `table` through the device in batches of consecutive chunks sized to
-// the free HBM, so a single 200-Mb sequence and a million reads take the same path.  Two engines on two
-// non-blocking streams form a software pipeline: while the device works on batch b, the host packs +
-// uploads batch b+1 and enqueues it, then hands the records of batch b to `sink(c0, c1, recs, rec_off)`
-// (chunk-local coordinates, rec_off relative to the batch).
+// the free HBM, so a single 200-Mb sequence and a million reads take the same path; the records of
+// every batch go to `sink(c0, c1, recs, rec_off)` in table order (chunk-local coordinates, rec_off
+// relative to the batch).
 using BatchSink = std::function<void(size_t, size_t, const sd_rec*, const int64_t*)>;
 static int run_chunk_batches(const std::vector<ReadView>& reads, const std::vector<CRef>& table, size_t c_lo,
                              size_t c_hi, const TemplateSet& ts, const sd_params* p, std::string& err,
                              const BatchSink& sink) {
-    char eb[1024] = {0};
-    sd_engine* eng = nullptr;
     const bool timing = getenv("SD_TIMING") != nullptr;  // developer knob: stage times on stderr
-    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_prev = now();
-    auto lap = [&](const char* what) {
-        if (!timing) return;
-        const double t = now();
-        std::fprintf(stderr, "[sd timing] %-28s %8.3f ms\n", what, (t - t_prev) * 1e3);
-        t_prev = t;
-    };
-    int rc = sd_engine_create(&eng, p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size(), eb, sizeof eb);
-    if (rc) { err = eb; return rc; }
-    lap("engine create");
-    // default: batches of <= 48 M rows (~900 reads of 50 kb): large enough to fill the GPU twice over,
-    // small enough that the host/device pipeline below has stages to overlap and buffers are reused
-    int64_t row_budget = (int64_t)48 << 20;
-    {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            // per row: B + argB + records (24 B) + fast-family checkpoints (P*256 B every FAST_R rows)
-            const double per_row = 26.0 + (eng->family == 2 ? eng->fplan.P * 256.0 / sd::FAST_R : 0.0);
-            row_budget = std::min<int64_t>(row_budget, (int64_t)(0.27 * (double)free_b / per_row));
-            row_budget = std::max<int64_t>(row_budget, (int64_t)p->part_size + p->overlap);
-        }
-        if (p->max_batch_rows > 0) row_budget = p->max_batch_rows;  // explicit cap (tests, small GPUs)
-    }
-    sd_engine* eng2 = nullptr;
-    hipStream_t streams[2] = {nullptr, nullptr};
+    const double t_begin = now_s();
+    Pipeline pipe;
+    int rc = pipe.create(p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size());
+    if (rc) { err = pipe.eb; return rc; }
     std::vector<std::pair<size_t, size_t>> batches;
-    for (size_t c0 = c_lo; c0 < c_hi;) {
-        int64_t rows = 0;
-        size_t c1 = c0;
-        while (c1 < c_hi && (c1 == c0 || rows + table[c1].len <= row_budget)) rows += table[c1++].len;
-        batches.emplace_back(c0, c1);
-        c0 = c1;
-    }
-    if (batches.size() > 1) {
-        rc = sd_engine_create(&eng2, p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size(), eb, sizeof eb);
-        if (rc) { err = eb; sd_engine_destroy(eng); return rc; }
-        for (hipStream_t& st : streams)
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
-    }
-    sd_engine* engs[2] = {eng, eng2 ? eng2 : eng};
-    auto submit = [&](size_t b) -> int {
-        std::vector<const char*> cptr;
-        std::vector<int32_t> clen;
-        for (size_t c = batches[b].first; c < batches[b].second; ++c) {
+    plan_batches(table, c_lo, c_hi, pipe.row_budget(), 1, batches);
+    std::vector<const char*> cptr;
+    std::vector<int32_t> clen;
+    for (size_t b = 0; b < batches.size() && rc == SD_OK; ++b) {
+        const size_t c0 = batches[b].first, c1 = batches[b].second;
+        cptr.clear();
+        clen.clear();
+        for (size_t c = c0; c < c1; ++c) {
             cptr.push_back(reads[(size_t)table[c].read].seq + table[c].off);
             clen.push_back(table[c].len);
         }
-        int r2 = load_chunks_impl(engs[b & 1], cptr, clen, eb, sizeof eb);
-        if (r2 == SD_OK) r2 = sd_engine_run(engs[b & 1], streams[b & 1], eb, sizeof eb);
-        return r2;
-    };
-    lap("second engine, streams");
-    if (!batches.empty()) rc = submit(0);
-    lap("submit batch 0");
-    for (size_t b = 0; b < batches.size() && rc == SD_OK; ++b) {
-        if (b + 1 < batches.size()) { rc = submit(b + 1); lap("submit next batch"); }
-        sd_rec* recs = nullptr; int64_t* roff = nullptr;
-        if (rc == SD_OK) rc = sd_engine_fetch(engs[b & 1], &recs, &roff, eb, sizeof eb);
-        lap("fetch");
-        if (rc == SD_OK) sink(batches[b].first, batches[b].second, recs, roff);
-        std::free(recs); std::free(roff);
-        lap("sink (assemble/format)");
+        rc = pipe.push(cptr, clen, [&sink, c0, c1](const sd_rec* r, const int64_t* ro, size_t) { sink(c0, c1, r, ro); });
     }
-    if (rc != SD_OK) (void)hipDeviceSynchronize();  // nothing may still be running on buffers we free
-    for (hipStream_t st : streams)
-        if (st) (void)hipStreamDestroy(st);
-    if (eng2) sd_engine_destroy(eng2);
-    if (rc) err = eb;
-    sd_engine_destroy(eng);
-    lap("destroy engines");
+    const int rc2 = pipe.drain();
+    if (rc == SD_OK) rc = rc2;
+    if (rc) err = pipe.eb;
+    if (timing)
+        std::fprintf(stderr, "[sd timing] %zu batches: pack+enqueue %.1f ms, wait %.1f ms, sink %.1f ms, kernels fill %.1f "
+                     "trace %.1f compact %.2f ms, total %.1f ms\n", batches.size(), pipe.pack_s * 1e3, pipe.wait_s * 1e3,
+                     pipe.sink_s * 1e3, pipe.fill_ms, pipe.trace_ms, pipe.compact_ms, (now_s() - t_begin) * 1e3);
     return rc;
 }
 
@@ -1100,6 +1267,252 @@ int sd_assemble_tsv(const char* const* read_names, const int64_t* read_lens, int
     *tsv = o;
     *tsv_len = out.size();
     return SD_OK;
+}
+
+// -------------------------------------------------------------------------------------------
+// streaming form: sequences in host memory -> rows in host memory (AlignReadsSet, main.cpp:67-122,
+// without the text), jobs pipelined through the device in sub-batches
+// -------------------------------------------------------------------------------------------
+namespace {
+// Per-read assembly of one job into rows (chunk offsets main.cpp:109-111, seam merge :116, :287-302).
+// Batches arrive in chunk-table order; reads that lie completely inside a batch are assembled in
+// parallel, a read that spans batches goes through `carry`.
+struct RowJob {
+    std::vector<CRef> table;
+    std::vector<int32_t> nch;
+    int32_t n_reads = 0;
+    int threads = 1;
+    sd_rec* rows = nullptr;       // malloc'ed, handed to the caller by collect
+    size_t n_rows = 0, cap_rows = 0;
+    int64_t* row_off = nullptr;   // n_reads + 1
+    std::vector<sd_rec> carry, tmp;
+    size_t next_read = 0;         // first read not complete yet
+    int32_t chunks_seen = 0;      // chunks of next_read already in carry
+    int batches_left = 0;
+    bool oom = false;
+    ~RowJob() { std::free(rows); std::free(row_off); }
+    void reserve(size_t need) {
+        if (need <= cap_rows) return;
+        size_t nc = std::max<size_t>(need, cap_rows * 2 + 4096);
+        sd_rec* q = static_cast<sd_rec*>(std::realloc(rows, nc * sizeof(sd_rec)));
+        if (!q) { oom = true; return; }
+        rows = q;
+        cap_rows = nc;
+    }
+    void emit(size_t read, const sd_rec* r, size_t n) {
+        reserve(n_rows + n);
+        if (oom) return;
+        if (n) std::memcpy(rows + n_rows, r, n * sizeof(sd_rec));
+        n_rows += n;
+        row_off[read + 1] = (int64_t)n_rows;
+    }
+    void add(size_t c0, size_t c1, const sd_rec* recs, const int64_t* roff) {
+        size_t c = c0;
+        // (1) the read that began in an earlier batch
+        if (chunks_seen > 0) {
+            while (c < c1 && chunks_seen < nch[next_read]) {
+                const int32_t add = (int32_t)table[c].off;
+                for (int64_t x = roff[c - c0]; x < roff[c - c0 + 1]; ++x) {
+                    sd_rec t = recs[x];
+                    t.start += add; t.end += add;
+                    carry.push_back(t);
+                }
+                ++c; ++chunks_seen;
+            }
+            if (chunks_seen < nch[next_read]) return;  // still open
+            emit(next_read, carry.data(), sd::seam_merge_inplace(carry.data(), carry.size()));
+            carry.clear();
+            chunks_seen = 0;
+            ++next_read;
+        }
+        // (2) reads completely inside [c, c1): parallel
+        struct Item { size_t read, ca, cb; size_t n; };
+        std::vector<Item> items;
+        size_t r = next_read, cc = c;
+        while (r < (size_t)n_reads && cc + (size_t)nch[r] <= c1) {
+            items.push_back(Item{r, cc, cc + (size_t)nch[r], 0});
+            cc += (size_t)nch[r];
+            ++r;
+        }
+        if (!items.empty()) {
+            const int64_t lo = roff[c - c0], hi = roff[cc - c0];
+            tmp.resize((size_t)(hi - lo));
+            sd::parallel_for((int64_t)items.size(), threads, 8, [&](int64_t q) {
+                Item& it = items[(size_t)q];
+                sd_rec* dst = tmp.data() + (roff[it.ca - c0] - lo);
+                size_t k = 0;
+                for (size_t ch = it.ca; ch < it.cb; ++ch) {
+                    const int32_t add = (int32_t)table[ch].off;
+                    for (int64_t x = roff[ch - c0]; x < roff[ch - c0 + 1]; ++x) {
+                        sd_rec t = recs[x];
+                        t.start += add; t.end += add;
+                        dst[k++] = t;
+                    }
+                }
+                it.n = sd::seam_merge_inplace(dst, k);
+            });
+            size_t total = 0;
+            for (const Item& it : items) total += it.n;
+            reserve(n_rows + total);
+            if (oom) return;
+            for (const Item& it : items) {
+                std::memcpy(rows + n_rows, tmp.data() + (roff[it.ca - c0] - lo), it.n * sizeof(sd_rec));
+                n_rows += it.n;
+                row_off[it.read + 1] = (int64_t)n_rows;
+            }
+            next_read = r;
+            c = cc;
+        }
+        // (3) the read that continues in the next batch
+        while (c < c1) {
+            const int32_t add = (int32_t)table[c].off;
+            for (int64_t x = roff[c - c0]; x < roff[c - c0 + 1]; ++x) {
+                sd_rec t = recs[x];
+                t.start += add; t.end += add;
+                carry.push_back(t);
+            }
+            ++c; ++chunks_seen;
+        }
+    }
+};
+}  // namespace
+
+struct sd_stream {
+    sd_params p{};
+    std::vector<std::string> mono;       // owned copies
+    Pipeline pipe;
+    int sub_batches = 1;
+    std::vector<std::unique_ptr<RowJob>> jobs;   // FIFO: submitted, not collected yet
+    int64_t budget = 0;
+    double submit_s = 0, collect_s = 0;
+    int64_t n_jobs = 0;
+};
+
+int sd_stream_create(sd_stream** out, const sd_params* p, const char* const* mono_seqs,
+                     const int32_t* mono_lens, int32_t n_mono, int32_t sub_batches, char* errbuf, size_t errlen) {
+    if (!out) return SD_ERR_PARAM;
+    *out = nullptr;
+    std::string err;
+    int rc = validate_params(p, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    if (n_mono <= 0 || !mono_seqs || !mono_lens) { set_err(errbuf, errlen, "no monomers"); return SD_ERR_PARAM; }
+    std::unique_ptr<sd_stream> s(new sd_stream);
+    s->p = *p;
+    s->sub_batches = std::max(1, (int)sub_batches);
+    std::vector<const char*> ms;
+    for (int32_t m = 0; m < n_mono; ++m) {
+        if (mono_lens[m] <= 0) { set_err(errbuf, errlen, "ERROR: empty monomer sequence"); return SD_ERR_EMPTY; }
+        s->mono.emplace_back(mono_seqs[m], (size_t)mono_lens[m]);
+    }
+    for (const std::string& m : s->mono) ms.push_back(m.data());
+    rc = s->pipe.create(p, ms.data(), mono_lens, n_mono);
+    if (rc) { set_err(errbuf, errlen, s->pipe.eb); return rc; }
+    s->budget = s->pipe.row_budget();
+    *out = s.release();
+    return SD_OK;
+}
+
+void sd_stream_destroy(sd_stream* s) { delete s; }
+
+int sd_stream_submit(sd_stream* s, const char* const* read_seqs, const int64_t* read_lens, int32_t n_reads,
+                     char* errbuf, size_t errlen) {
+    if (!s || n_reads < 0 || (n_reads && (!read_seqs || !read_lens))) return SD_ERR_PARAM;
+    const double t0 = now_s();
+    std::unique_ptr<RowJob> job(new RowJob);
+    job->n_reads = n_reads;
+    job->threads = s->p.threads;
+    job->nch.assign((size_t)n_reads, 0);
+    for (int32_t r = 0; r < n_reads; ++r) {
+        if (read_lens[r] <= 0) { set_err(errbuf, errlen, "ERROR: Sequence #" + std::to_string(r) + " is empty"); return SD_ERR_EMPTY; }
+        job->nch[(size_t)r] = sd::chunk_plan(read_lens[r], s->p.part_size, s->p.overlap,
+                                             [&](int64_t off, int32_t l) { job->table.push_back(CRef{r, off, l}); });
+    }
+    job->row_off = static_cast<int64_t*>(std::calloc((size_t)n_reads + 1, sizeof(int64_t)));
+    if (!job->row_off) { set_err(errbuf, errlen, "out of host memory"); return SD_ERR_INTERNAL; }
+    std::vector<std::pair<size_t, size_t>> batches;
+    plan_batches(job->table, 0, job->table.size(), s->budget, s->sub_batches, batches);
+    job->batches_left = (int)batches.size();
+    RowJob* jp = job.get();
+    s->jobs.push_back(std::move(job));
+    ++s->n_jobs;
+    std::vector<const char*> cptr;
+    std::vector<int32_t> clen;
+    int rc = SD_OK;
+    for (size_t b = 0; b < batches.size() && rc == SD_OK; ++b) {
+        const size_t c0 = batches[b].first, c1 = batches[b].second;
+        cptr.clear();
+        clen.clear();
+        for (size_t c = c0; c < c1; ++c) {
+            cptr.push_back(read_seqs[jp->table[c].read] + jp->table[c].off);
+            clen.push_back(jp->table[c].len);
+        }
+        rc = s->pipe.push(cptr, clen, [jp, c0, c1](const sd_rec* r, const int64_t* ro, size_t) {
+            jp->add(c0, c1, r, ro);
+            --jp->batches_left;
+        });
+    }
+    if (rc) {
+        set_err(errbuf, errlen, s->pipe.eb);
+        (void)s->pipe.drain();   // sinks of older jobs still run; this job is dropped
+        for (size_t j = 0; j < s->jobs.size(); ++j)
+            if (s->jobs[j].get() == jp) { s->jobs.erase(s->jobs.begin() + (long)j); break; }
+    }
+    s->submit_s += now_s() - t0;
+    return rc;
+}
+
+int sd_stream_collect(sd_stream* s, sd_rec** rows, int64_t** row_off, int64_t* n_rows, char* errbuf, size_t errlen) {
+    if (!s || !rows || !row_off) return SD_ERR_PARAM;
+    *rows = nullptr;
+    *row_off = nullptr;
+    if (n_rows) *n_rows = 0;
+    if (s->jobs.empty()) { set_err(errbuf, errlen, "sd_stream_collect without a submitted job"); return SD_ERR_PARAM; }
+    const double t0 = now_s();
+    RowJob* job = s->jobs.front().get();
+    int rc = SD_OK;
+    while (job->batches_left > 0 && rc == SD_OK) {
+        if (s->pipe.inflight() == 0) { set_err(errbuf, errlen, "stream lost a batch"); rc = SD_ERR_INTERNAL; break; }
+        rc = s->pipe.pop();
+        if (rc) set_err(errbuf, errlen, s->pipe.eb);
+    }
+    if (rc == SD_OK && job->oom) { set_err(errbuf, errlen, "out of host memory"); rc = SD_ERR_INTERNAL; }
+    if (rc == SD_OK) {
+        if (!job->rows) job->rows = static_cast<sd_rec*>(std::malloc(sizeof(sd_rec)));
+        *rows = job->rows;
+        *row_off = job->row_off;
+        if (n_rows) *n_rows = (int64_t)job->n_rows;
+        job->rows = nullptr;      // ownership moves to the caller (sd_free)
+        job->row_off = nullptr;
+    }
+    s->jobs.erase(s->jobs.begin());
+    s->collect_s += now_s() - t0;
+    return rc;
+}
+
+int sd_stream_stats(sd_stream* s, double out[16]) {
+    if (!s || !out) return SD_ERR_PARAM;
+    const Pipeline& q = s->pipe;
+    const double v[16] = {q.fill_ms, q.trace_ms, q.compact_ms, q.run_ms, (double)q.launches, (double)q.batches,
+                          (double)q.rows, q.pack_s * 1e3, q.wait_s * 1e3, q.sink_s * 1e3, s->submit_s * 1e3,
+                          s->collect_s * 1e3, (double)s->n_jobs, (double)s->sub_batches, (double)s->budget, 0.0};
+    std::memcpy(out, v, sizeof v);
+    return SD_OK;
+}
+
+int sd_stream_info(sd_stream* s, int64_t info[8]) {
+    if (!s) return SD_ERR_PARAM;
+    return sd_engine_info(s->pipe.eng[0], info);
+}
+
+int32_t sd_pack_bases(const char* seq, int64_t n, uint32_t* words, uint32_t* nmask) {
+    if (!seq || n < 0 || n > 0x7fffffff || !words) return -1;
+    const bool hn = sd::pack_chunk(seq, (int32_t)n, words);
+    if (nmask) {
+        std::memset(nmask, 0, sizeof(uint32_t) * (size_t)((n + 31) / 32));
+        for (int64_t i = 0; i < n; ++i)
+            if (seq[i] == 'N') nmask[i >> 5] |= 1u << (i & 31);
+    }
+    return hn ? 1 : 0;
 }
 
 // -------------------------------------------------------------------------------------------

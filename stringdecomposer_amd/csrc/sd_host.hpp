@@ -9,6 +9,9 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <utility>
@@ -128,26 +131,25 @@ inline int chunk_plan(int64_t len, int part, int overlap, F&& emit) {
 }
 
 // PostProcessing (main.cpp:287-302), literal: after a drop the element behind the dropped run is
-// appended without being compared with its own successors.
-inline void seam_merge(std::vector<sd_rec>& b) {
-    std::vector<sd_rec> res;
-    res.reserve(b.size());
-    size_t i = 0;
-    const size_t N = b.size();
+// appended without being compared with its own successors.  In place: the write position never
+// passes the read position (an iteration appends at most b[i] and b[j+1] while i moves to j+2).
+inline size_t seam_merge_inplace(sd_rec* b, size_t N) {
+    size_t w = 0, i = 0;
     while (i < N) {
         const size_t lim = i + 7 < N ? i + 7 : N;
         for (size_t j = i + 1; j < lim; ++j) {
             if ((b[i].end - b[j].start) * 2 > (b[j].end - b[j].start)) {
-                res.push_back(b[i]);
+                b[w++] = b[i];
                 i = j + 1;
                 break;
             }
         }
-        if (i < N) res.push_back(b[i]);
+        if (i < N) b[w++] = b[i];
         ++i;
     }
-    b.swap(res);
+    return w;
 }
+inline void seam_merge(std::vector<sd_rec>& b) { b.resize(seam_merge_inplace(b.data(), b.size())); }
 
 // decimal text of an int, appended (std::to_string(int), main.cpp:277-281)
 inline void put_int(std::string& o, int64_t v) {
@@ -186,7 +188,75 @@ inline void format_rows(std::string& o, const char* read_name, size_t read_name_
     }
 }
 
-// Minimal fork-join over [0, n): `threads` host threads pull blocks of `grain` indices.
+// Process-wide pool of host worker threads.  The packer, the assembler and the formatter run many
+// short parallel loops per device batch (a few hundred microseconds each); creating 32-64 threads for
+// every loop cost more than the loops, so the threads persist and sleep between loops.  One loop at a
+// time (a second caller waits its turn); a loop started from inside a pool worker runs serially.
+class HostPool {
+  public:
+    static HostPool& get() {
+        static HostPool* p = new HostPool;  // never destroyed: workers may outlive static destructors
+        return *p;
+    }
+    // runs `work()` on the calling thread and on up to helpers pool threads; returns when all are back
+    template <class F>
+    void run(int helpers, F&& work) {
+        if (helpers <= 0 || in_worker()) { work(); return; }
+        std::unique_lock<std::mutex> job(job_m_);   // one loop at a time
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            grow(helpers);
+            fn_ = [&work]() { work(); };
+            slots_ = helpers;
+            ++gen_;
+        }
+        cv_work_.notify_all();
+        in_worker() = true;   // a loop started by `work` itself runs serially (job_m_ is not recursive)
+        work();
+        in_worker() = false;
+        std::unique_lock<std::mutex> lk(m_);
+        slots_ = 0;                                 // nobody joins any more
+        cv_done_.wait(lk, [&] { return running_ == 0; });
+        fn_ = nullptr;
+    }
+
+  private:
+    static bool& in_worker() { static thread_local bool w = false; return w; }
+    void grow(int want) {  // m_ held
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && want > hw) want = hw;
+        while ((int)th_.size() < want) {
+            th_.emplace_back([this] { loop(); });
+            th_.back().detach();
+        }
+    }
+    void loop() {
+        in_worker() = true;
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return gen_ != seen; });
+            seen = gen_;
+            if (slots_ <= 0) continue;
+            --slots_;
+            ++running_;
+            std::function<void()> f = fn_;
+            lk.unlock();
+            f();
+            lk.lock();
+            if (--running_ == 0) cv_done_.notify_all();
+        }
+    }
+    std::mutex job_m_, m_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<std::thread> th_;
+    std::function<void()> fn_;
+    int slots_ = 0, running_ = 0;
+    uint64_t gen_ = 0;
+};
+
+// Fork-join over [0, n): up to `threads` host threads (the caller + pool workers) pull blocks of
+// `grain` indices.
 template <class F>
 inline void parallel_for(int64_t n, int threads, int64_t grain, F&& body) {
     if (n <= 0) return;
@@ -205,27 +275,33 @@ inline void parallel_for(int64_t n, int threads, int64_t grain, F&& body) {
             for (int64_t i = b; i < e; ++i) body(i);
         }
     };
-    std::vector<std::thread> th;
     const int64_t blocks = (n + grain - 1) / grain;
     const int nt = (int)(blocks < threads ? blocks : threads);
-    for (int k = 1; k < nt; ++k) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
+    HostPool::get().run(nt - 1, work);
 }
 
-// 2-bit packing of one chunk (16 bases per dword); returns true if the chunk contains N
+// 2-bit packing of one chunk (16 bases per dword, base i at bits 2*(i&15)); returns true if the chunk
+// contains N (whose 2-bit code is 0; the N mask carries it).  Eight bases per 64-bit step: for the
+// validated alphabet ((c >> 1) ^ (c >> 2)) & 3 maps A,C,G,T to 0,1,2,3 and N to 0.
+inline uint32_t pack8(uint64_t x, uint64_t& nacc) {
+    const uint64_t y = x ^ 0x4E4E4E4E4E4E4E4Eull;                       // a zero byte where the base is 'N'
+    nacc |= (y - 0x0101010101010101ull) & ~y & 0x8080808080808080ull;
+    uint64_t t = ((x >> 1) ^ (x >> 2)) & 0x0303030303030303ull;
+    t = (t | (t >> 6)) & 0x000F000F000F000Full;
+    t = (t | (t >> 12)) & 0x000000FF000000FFull;
+    t = (t | (t >> 24)) & 0xFFFFull;
+    return (uint32_t)t;
+}
 inline bool pack_chunk(const char* s, int32_t l, uint32_t* out) {
-    bool has_n = false;
+    uint64_t nacc = 0;
     const int32_t full = l & ~15;
     for (int32_t i = 0; i < full; i += 16) {
-        uint32_t w = 0;
-        for (int k = 0; k < 16; ++k) {
-            const int code = base_code(s[i + k]);
-            has_n |= code == 4;
-            w |= (uint32_t)(code & 3) << (2 * k);
-        }
-        out[i >> 4] = w;
+        uint64_t a, b;
+        std::memcpy(&a, s + i, 8);
+        std::memcpy(&b, s + i + 8, 8);
+        out[i >> 4] = pack8(a, nacc) | (pack8(b, nacc) << 16);
     }
+    bool has_n = nacc != 0;
     if (full < l) {
         uint32_t w = 0;
         for (int32_t i = full; i < l; ++i) {

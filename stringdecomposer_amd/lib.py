@@ -31,6 +31,8 @@ EXPORTS = [
     "sd_engine_info", "sd_chunk_plan", "sd_seam_merge", "sd_format_rows", "sd_fasta_load",
     "sd_fasta_free", "sd_nw_identity_batch", "sd_identity_segments", "sd_chunk_table_size",
     "sd_decompose_chunk_range", "sd_assemble_tsv", "sd_release_cache", "sd_format_alt_rows",
+    "sd_stream_create", "sd_stream_destroy", "sd_stream_submit", "sd_stream_collect", "sd_stream_stats",
+    "sd_stream_info", "sd_pack_bases",
 ]
 
 
@@ -115,6 +117,15 @@ def load():
     L.sd_assemble_tsv.argtypes = [P(C.c_char_p), P(C.c_int64), C.c_int32, P(C.c_char_p), C.c_int32, P(Params),
                                   C.c_void_p, C.c_void_p, C.c_int64, P(C.c_void_p), P(C.c_size_t),
                                   C.c_char_p, C.c_size_t]
+    L.sd_stream_create.argtypes = [P(C.c_void_p), P(Params), P(C.c_char_p), P(C.c_int32), C.c_int32, C.c_int32,
+                                   C.c_char_p, C.c_size_t]
+    L.sd_stream_destroy.argtypes = [C.c_void_p]
+    L.sd_stream_submit.argtypes = [C.c_void_p, P(C.c_char_p), P(C.c_int64), C.c_int32, C.c_char_p, C.c_size_t]
+    L.sd_stream_collect.argtypes = [C.c_void_p, P(P(Rec)), P(P(C.c_int64)), P(C.c_int64), C.c_char_p, C.c_size_t]
+    L.sd_stream_stats.argtypes = [C.c_void_p, P(C.c_double)]
+    L.sd_stream_info.argtypes = [C.c_void_p, P(C.c_int64)]
+    L.sd_pack_bases.restype = C.c_int32
+    L.sd_pack_bases.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -275,11 +286,108 @@ class Engine:
     def info(self):
         v = (C.c_int64 * 8)()
         self.L.sd_engine_info(self.h, v)
-        return {"n_templates": v[0], "sum_template_len": v[1], "n_chunks": v[2], "rows": v[3],
-                "family": {1: "generic", 2: "fast"}.get(v[4] & 0xff, "?"),
-                "cells": {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table", 4: "f16/bf8-table"}.get(v[4] >> 8, "?"),
-                "cells_per_lane": v[5],
-                "workspace_bytes": v[6], "fill_launches": v[7]}
+        return _info_dict(v)
+
+
+def _info_dict(v):
+    return {"n_templates": v[0], "sum_template_len": v[1], "n_chunks": v[2], "rows": v[3],
+            "family": {1: "generic", 2: "fast"}.get(v[4] & 0xff, "?"),
+            "cells": {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table", 4: "f16/bf8-table"}.get(v[4] >> 8, "?"),
+            "cells_per_lane": v[5], "workspace_bytes": v[6], "fill_launches": v[7]}
+
+
+class ReadSet:
+    """Sequences in host memory, as C arrays (built once, reusable across submits)."""
+
+    def __init__(self, read_seqs):
+        self.seqs = [_b(s) for s in read_seqs]
+        self.n = len(self.seqs)
+        self.ptrs = _strs(self.seqs)
+        self.lens = (C.c_int64 * max(self.n, 1))(*[len(s) for s in self.seqs])
+        self.bp = sum(len(s) for s in self.seqs)
+
+
+class Stream:
+    """Pipelined sequences-in-host-memory -> rows-in-host-memory path (sd_stream_*): submit() read sets,
+    collect() their rows in FIFO order; two device batches are in flight across job boundaries."""
+
+    def __init__(self, mono_seqs, sub_batches=4, **kw):
+        self.L = load()
+        self.params = make_params(**kw)
+        self._err = C.create_string_buffer(4096)
+        ms = [_b(s) for s in mono_seqs]
+        ml = (C.c_int32 * max(len(ms), 1))(*[len(s) for s in ms])
+        self.h = C.c_void_p()
+        self._check(self.L.sd_stream_create(C.byref(self.h), C.byref(self.params), _strs(ms), ml, len(ms),
+                                            int(sub_batches), self._err, 4096))
+        self._n_reads = []
+
+    def _check(self, rc):
+        if rc != SD_OK:
+            raise SdError(rc, self._err.value.decode(errors="replace"))
+
+    def close(self):
+        if self.h:
+            self.L.sd_stream_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def submit(self, reads):
+        rs = reads if isinstance(reads, ReadSet) else ReadSet(reads)
+        self._check(self.L.sd_stream_submit(self.h, rs.ptrs, rs.lens, rs.n, self._err, 4096))
+        self._n_reads.append(rs.n)
+
+    def collect(self, as_lists=False):
+        """Rows of the oldest job: (n_rows,) by default -- the arrays are freed at once -- or, with
+        as_lists, a list over reads of [(tmpl, start, end, score), ...]."""
+        rows = C.POINTER(Rec)()
+        off = C.POINTER(C.c_int64)()
+        n = C.c_int64()
+        self._check(self.L.sd_stream_collect(self.h, C.byref(rows), C.byref(off), C.byref(n), self._err, 4096))
+        nr = self._n_reads.pop(0)
+        out = n.value
+        if as_lists:
+            import numpy as np
+            o = np.ctypeslib.as_array(off, shape=(nr + 1,)).copy()
+            if n.value:
+                r = np.frombuffer(C.string_at(rows, n.value * C.sizeof(Rec)), dtype=_rec_dtype())
+            else:
+                r = np.zeros(0, dtype=_rec_dtype())
+            out = [[(int(x["tmpl"]), int(x["start"]), int(x["end"]), int(x["score"])) for x in r[o[i]:o[i + 1]]]
+                   for i in range(nr)]
+        self.L.sd_free(rows)
+        self.L.sd_free(off)
+        return out
+
+    def stats(self):
+        v = (C.c_double * 16)()
+        self.L.sd_stream_stats(self.h, v)
+        keys = ["fill_ms", "trace_ms", "compact_ms", "run_ms", "fill_launches", "batches", "rows", "host_pack_ms",
+                "host_wait_ms", "host_assemble_ms", "submit_ms", "collect_ms", "jobs", "sub_batches", "row_budget"]
+        return dict(zip(keys, list(v)[:15]))
+
+    def info(self):
+        v = (C.c_int64 * 8)()
+        self.L.sd_stream_info(self.h, v)
+        return _info_dict(v)
+
+
+def pack_bases(seq):
+    """(words uint32[(n+15)//16], nmask uint32[(n+31)//32], has_n) exactly as the device reads a chunk."""
+    import numpy as np
+    L = load()
+    b = _b(seq)
+    w = np.zeros((len(b) + 15) // 16, dtype=np.uint32)
+    m = np.zeros((len(b) + 31) // 32, dtype=np.uint32)
+    rc = L.sd_pack_bases(b, len(b), w.ctypes.data, m.ctypes.data)
+    if rc < 0:
+        raise SdError(SD_ERR_PARAM, "sd_pack_bases")
+    return w, m, bool(rc)
 
 
 def format_rows(read_name, tmpl_names, rows):

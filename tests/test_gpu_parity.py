@@ -414,3 +414,34 @@ def test_device_buffer_cache_reuse_and_release(oracle):
     a2 = lib.decompose(rn1, rs1, mn1, ms1)
     assert a1 == a2 and b1 == b2
     assert b1 == oracle.decompose(rn2, rs2, mn2, ms2, threads=8, sc=(-1, -2, -1, 1))
+
+
+@pytest.mark.parametrize("sub,cap", [(1, 0), (4, 0), (3, 21000), (7, 5600)])
+def test_stream_rows_equal_oracle(oracle, sub, cap):
+    """sd_stream_* (sequences in host memory -> rows in host memory, what bench.py times): jobs submitted
+    back to back and cut into sub-batches -- a long read spans several of them -- give, formatted, the
+    oracle's raw TSV; rows of a job do not depend on what else is in flight."""
+    mn, ms = synth.make_monomers(12, seed=61)
+    tn = list(mn) + [n + "'" for n in mn]
+    rn, rs = synth.make_reads(ms, 9, read_len=17000, seed=62)
+    n1, s1 = synth.make_reads(ms, 1, read_len=93000, seed=63)
+    rs = rs[:4] + s1 + rs[4:]
+    rs[2] = rs[2][:499]
+    rs[7] = rs[7][:5500]
+    rn = ["r%d" % i for i in range(len(rs))]
+    jobs = [(rn, rs), (rn[5:], rs[5:]), (rn[:3], rs[:3]), (rn, rs)]
+    st = lib.Stream(ms, sub_batches=sub, max_batch_rows=cap, threads=6)
+    got = []
+    for k, (_, seqs) in enumerate(jobs):
+        st.submit(seqs)
+        if k >= 1:
+            got.append(st.collect(as_lists=True))
+    got.append(st.collect(as_lists=True))
+    stats = st.stats()
+    st.close()
+    assert stats["jobs"] == 4 and stats["batches"] >= 4 * min(sub, 3)
+    for (names, seqs), rows in zip(jobs, got):
+        txt = b"".join(lib.format_rows(n, tn, r) for n, r in zip(names, rows))
+        assert txt == oracle.decompose(names, seqs, mn, ms, threads=8)
+    with pytest.raises(lib.SdError):
+        lib.Stream(ms).collect()

@@ -263,3 +263,49 @@ def test_native_alt_row_formatting_equals_python_format():
                   for i in range(n) for k in range(nk))
     assert got == exp
     assert lib.format_alt_rows("r", keys, [], [], [], np.zeros((0, nk)), threads=2) == ""
+
+
+def test_pack_bases_matches_the_device_format():
+    """2-bit packing (SWAR, 8 bases per 64-bit step) against a plain restatement of the format the
+    kernels read: base i at bits 2*(i & 15) of word i >> 4, A,C,G,T = 0..3, N = 0 + mask bit."""
+    st = synth.Stream(8, 8)
+    for n in [1, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 255, 1000, 5500]:
+        for with_n in (False, True):
+            b = bytearray(synth._ACGT[st.below(n, 4)].tobytes())
+            if with_n:
+                for p in st.below(max(1, n // 9), n):
+                    b[int(p)] = ord("N")
+            w, m, has_n = lib.pack_bases(bytes(b))
+            code = {65: 0, 67: 1, 71: 2, 84: 3, 78: 0}
+            ew = np.zeros((n + 15) // 16, dtype=np.uint32)
+            em = np.zeros((n + 31) // 32, dtype=np.uint32)
+            for i, ch in enumerate(b):
+                ew[i >> 4] |= np.uint32(code[ch] << (2 * (i & 15)))
+                if ch == 78:
+                    em[i >> 5] |= np.uint32(1 << (i & 31))
+            assert (w == ew).all() and (m == em).all() and has_n == (b"N" in bytes(b)), (n, with_n)
+
+
+def test_host_pool_parallel_loops_are_exact():
+    """The persistent host thread pool behind the library's parallel loops (packing, assembly, TSV
+    formatting): many short loops in a row, from several Python threads at once (ctypes releases the
+    GIL; the pool runs one loop at a time), still assemble every read."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = 700
+    names = ["read%d" % i for i in range(n)]
+    lens = [100 + (i % 50) for i in range(n)]
+    recs = np.zeros(2 * n, dtype=lib._rec_dtype())
+    recs["tmpl"] = np.arange(2 * n) % 6
+    recs["start"] = np.tile([0, 40], n)
+    recs["end"] = np.tile([39, 99], n)
+    recs["score"] = np.arange(2 * n) - 50
+    off = np.arange(n + 1, dtype=np.int64) * 2
+    mn = ["a", "b", "c"]
+    exp = lib.assemble_tsv(names, lens, mn, recs, off, threads=1)
+    assert exp.count(b"\n") == 2 * n
+
+    def one(_):
+        return lib.assemble_tsv(names, lens, mn, recs, off, threads=6)
+
+    with ThreadPoolExecutor(4) as ex:
+        assert all(x == exp for x in ex.map(one, range(40)))
