@@ -96,7 +96,13 @@ def main():
     ap.add_argument("--kernel", choices=["auto", "generic", "fast"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=32)
-    ap.add_argument("--sub-batches", type=int, default=4, help="device batches per step (two in flight)")
+    ap.add_argument("--pipe-mode", type=int, choices=[0, 1], default=0,
+                    help="kernel streams of the timed region: 0 = in order on one stream (clean per-kernel spans), "
+                         "1 = library default, traceback overlapped with the next fill; the other one is reported too")
+    ap.add_argument("--resident-stream", choices=["null", "new"], default="null")
+    ap.add_argument("--sub-batches", type=int, default=1,
+                    help="device batches per step (two batches are in flight, across steps; 1 is fastest: the "
+                         "persistent kernels want >= 2 chunks per resident wave)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -134,32 +140,50 @@ def main():
     # host memory.  Every step submits the rank's whole read set; the stream cuts it into sub-batches
     # and keeps two of them in flight on two HIP streams, across step boundaries (a long job is a
     # stream of such batches), so packing / upload / assembly run under the kernels of the neighbours.
-    stream = lib.Stream(ms, sub_batches=args.sub_batches, device=local_rank, kernel=kernel, threads=threads)
     readset = lib.ReadSet(rs)
-    info = stream.info()
-    for _ in range(args.warmup):
-        stream.submit(readset)
-        stream.collect()
-    s0 = stream.stats()
-    shard.barrier(dist, local_rank if dist else None)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    rows_out = 0
-    for k in range(args.steps):
-        stream.submit(readset)
-        if k > 0:
-            rows_out = stream.collect()     # rows of step k-1 are in host memory
-    if args.steps > 0:
-        rows_out = stream.collect()
-    torch.cuda.synchronize()
-    shard.barrier(dist, local_rank if dist else None)
-    dt = time.perf_counter() - t0
-    s1 = stream.stats()
+
+    def timed_steps(pipe_mode, steps, warmup, bracket):
+        """K pipelined steps of the stream in the given kernel-stream mode; returns (seconds, rows of the
+        last step, stats delta, info)."""
+        # SD_PIPE_MODE (read by the library when a stream starts its first batch): 0 = all kernels of all
+        # batches in order on one HIP stream (per-kernel event spans are clean); 1 = the library default,
+        # traceback + compaction on a second, lower-priority stream so that they share the machine with the
+        # next batch's fill (about 3 % faster, but the fill's event span then contains traceback work)
+        os.environ["SD_PIPE_MODE"] = str(pipe_mode)
+        st = lib.Stream(ms, sub_batches=args.sub_batches, device=local_rank, kernel=kernel, threads=threads)
+        inf = st.info()
+        for _ in range(warmup):
+            st.submit(readset)
+            st.collect()
+        a = st.stats()
+        if bracket:
+            shard.barrier(dist, local_rank if dist else None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nrows = 0
+        for k in range(steps):
+            st.submit(readset)
+            if k > 0:
+                nrows = st.collect()     # rows of step k-1 are in host memory
+        if steps > 0:
+            nrows = st.collect()
+        torch.cuda.synchronize()
+        if bracket:
+            shard.barrier(dist, local_rank if dist else None)
+        sec = time.perf_counter() - t0
+        b = st.stats()
+        st.close()
+        return sec, nrows, {k: b[k] - a[k] for k in b}, inf
+
+    dt, rows_out, d, info = timed_steps(args.pipe_mode, args.steps, args.warmup, True)
     dt = shard.max_over_ranks(dist, dt, dev)
     bp_total = shard.sum_over_ranks(dist, bp_rank, dev)
-    d = {k: s1[k] - s0[k] for k in s1}
     n_chunks = lib.chunk_table_size([len(x) for x in rs])
-    stream.close()
+    other = None
+    if ws == 1:   # the other kernel-stream mode, same K steps (secondary figure)
+        odt, _, od, _ = timed_steps(1 - args.pipe_mode, args.steps, min(args.warmup, 1), False)
+        other = {"pipe_mode": 1 - args.pipe_mode, "bp_per_s": bp_rank * K / odt, "ms_per_step": odt / K * 1e3,
+                 "kernel_event_ms_per_step": {"fill": od["fill_ms"] / K, "traceback": od["trace_ms"] / K}}
 
     # ---- the same K steps with the batch already packed and resident in HBM, one launch per kernel, no
     # overlap: clean per-kernel HIP-event times (device_resident; NOT the headline) ------------------
@@ -168,6 +192,9 @@ def main():
     eng.load_reads(rs)
     t_load = time.perf_counter() - t_load
     tstream = torch.cuda.current_stream().cuda_stream
+    if args.resident_stream == "new":   # developer A/B: a created stream instead of the null stream
+        _keep = torch.cuda.Stream()
+        tstream = _keep.cuda_stream
     for _ in range(min(args.warmup, 1)):
         eng.run(tstream)
         eng.total_rows()
@@ -224,8 +251,10 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": info["cells"].split("/")[0],
         "data": "synthetic",
         "timed_region": "sequences in host memory -> chunk -> 2-bit pack -> H2D -> fill -> traceback -> compaction -> "
-                        "D2H -> per-read assembly -> rows in host memory (SURVEY 8(d)); %d sub-batches per step, two in "
-                        "flight on two HIP streams, pipelined across steps" % args.sub_batches,
+                        "D2H -> per-read assembly -> rows in host memory (SURVEY 8(d)); %d device batch(es) per step, two "
+                        "batches in flight (pinned staging, copies on their own streams), pipelined across steps; kernel "
+                        "streams: %s" % (args.sub_batches, "one, in order (pipe_mode 0)" if args.pipe_mode == 0 else
+                                         "fills on one, traceback + compaction on a lower-priority one (pipe_mode 1)"),
         "config": {"workload": "%s: synthetic %d reads x %d bp per GPU, %d monomers (~171 bp) + reverse complements, "
                                "default scoring -1,-1,-1,1, part 5000 / overlap 500" % (
                                    "C2" if (args.monomers, args.reads, args.read_len) == (12, 1000, 50000) else
@@ -237,7 +266,7 @@ def main():
                    "sub_batches": args.sub_batches, "host_threads": threads,
                    "seed": args.seed, "sharding": "reads dealt to ranks in contiguous blocks, no collective"},
         # contract figure: SURVEY 8(d) algorithmic bytes of a fill launch / its HIP-event duration, launches of
-        # the timed region (they overlap the neighbouring batch's traceback on the other stream)
+        # the timed region
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": None if traffic is None else
@@ -255,6 +284,7 @@ def main():
                                "note": "HIP-event spans per batch, summed; batches on the two streams overlap"},
         "host_ms_per_step": {"pack_upload_enqueue": d["host_pack_ms"] / K, "wait_for_device": d["host_wait_ms"] / K,
                              "d2h_assemble": d["host_assemble_ms"] / K},
+        "other_pipe_mode": other,
         "rows_out_per_gpu": rows_out, "hbm_workspace_bytes": einfo["workspace_bytes"],
         # kernels only, batch packed and resident in HBM before the clock starts, one launch per kernel
         "device_resident": {"bp_per_s": bp_rank * K / dtr, "ms_per_step": dtr / K * 1e3,

@@ -216,6 +216,7 @@ struct sd_engine {
 
     // run state
     hipStream_t last_stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // pipeline: H2D of the batch / D2H of its records (not owned)
     bool ran = false;
     std::vector<hipEvent_t> ev_fill, ev_trace;  // pairs
     hipEvent_t ev_run0 = nullptr, ev_run1 = nullptr, ev_cmp0 = nullptr, ev_cmp1 = nullptr;
@@ -601,12 +602,17 @@ int sd_engine_load_reads(sd_engine* e, const char* const* read_seqs, const int64
     return rc;
 }
 
-int sd_engine_run(sd_engine* e, void* hip_stream, char* errbuf, size_t errlen) {
-    if (!e) return SD_ERR_PARAM;
-    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+// One pass over the loaded batch.  `st` carries the fill (and, for the generic family, everything);
+// with a distinct `ts` the traceback + compaction of the fast family go there behind an event, so that
+// a pipeline can put the next batch's fill on `st` right behind this one: the traceback of batch b
+// then shares the machine with the fill of batch b+1 and runs in the slots its drain leaves free.
+// `in_stream` (may be null) is the stream the batch's H2D copy was issued on.
+static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbuf, size_t errlen) {
     const int C = (int)e->chunks.size();
+    if (e->family == 1) ts = st;
     try {
         SD_HIP(hipSetDevice(e->device));
+        if (e->in_pending) SD_HIP(hipStreamWaitEvent(st, e->ev_in, 0));
         SD_HIP(hipEventRecord(e->ev_run0, st));
         e->fill_launches = 0;
         if (C > 0) {
@@ -639,32 +645,39 @@ int sd_engine_run(sd_engine* e, void* hip_stream, char* errbuf, size_t errlen) {
                                      e->d_fckpt.p, e->d_fckbase.p, e->d_queue.p, e->dp_order, e->n_cu,
                                      ranked ? e->d_cendoff.p : nullptr, ranked ? e->d_crank.p : nullptr);
                 SD_HIP(hipEventRecord(e->ev_fill[1], st));
-                SD_HIP(hipEventRecord(e->ev_trace[0], st));
-                sd::launch_fast_trace(e->fplan, st, e->dp_chunks, C, e->dp_bases2, e->dp_nmask,
+                if (ts != st) SD_HIP(hipStreamWaitEvent(ts, e->ev_fill[1], 0));
+                SD_HIP(hipEventRecord(e->ev_trace[0], ts));
+                sd::launch_fast_trace(e->fplan, ts, e->dp_chunks, C, e->dp_bases2, e->dp_nmask,
                                       e->d_fslot.p, e->d_ftcodes.p, e->d_flane.p, e->d_toff.p,
                                       e->d_tlen.p, e->sc, e->d_B.p, e->d_argB.p, e->d_fckpt.p,
                                       e->d_fckbase.p, e->d_recs.p, e->d_cnt.p, e->d_queue.p + 1, e->dp_order,
                                       e->n_cu);
-                SD_HIP(hipEventRecord(e->ev_trace[1], st));
+                SD_HIP(hipEventRecord(e->ev_trace[1], ts));
                 e->fill_launches = 1;
             }
-            SD_HIP(hipEventRecord(e->ev_cmp0, st));
-            sd::launch_compact(st, e->dp_chunks, C, e->d_cnt.p, e->d_roff.p, e->d_recs.p,
+            SD_HIP(hipEventRecord(e->ev_cmp0, ts));
+            sd::launch_compact(ts, e->dp_chunks, C, e->d_cnt.p, e->d_roff.p, e->d_recs.p,
                                e->d_dense.p, e->dense_cap, true);
-            SD_HIP(hipEventRecord(e->ev_cmp1, st));
+            SD_HIP(hipEventRecord(e->ev_cmp1, ts));
             // the record offsets travel right behind the compaction: the fetch then knows the record
             // count as soon as the stream is idle, without a second round trip
-            SD_HIP(hipMemcpyAsync(e->h_roff.p, e->d_roff.p, sizeof(int64_t) * ((size_t)C + 1), hipMemcpyDeviceToHost, st));
+            SD_HIP(hipMemcpyAsync(e->h_roff.p, e->d_roff.p, sizeof(int64_t) * ((size_t)C + 1), hipMemcpyDeviceToHost, ts));
         }
-        SD_HIP(hipEventRecord(e->ev_run1, st));
+        SD_HIP(hipEventRecord(e->ev_run1, ts));
         SD_HIP(hipGetLastError());
     } catch (const HipFail& f) {
         set_err(errbuf, errlen, f.msg);
         return SD_ERR_HIP;
     }
-    e->last_stream = st;
+    e->last_stream = ts;
     e->ran = true;
     return SD_OK;
+}
+
+int sd_engine_run(sd_engine* e, void* hip_stream, char* errbuf, size_t errlen) {
+    if (!e) return SD_ERR_PARAM;
+    hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    return engine_run2(e, st, st, errbuf, errlen);
 }
 
 // Waits for the last run and brings its compact records into the pinned buffers h_roff / h_recs
@@ -675,8 +688,9 @@ static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errle
     const size_t C = e->chunks.size();
     try {
         SD_HIP(hipSetDevice(e->device));
-        SD_HIP(hipStreamSynchronize(e->last_stream));
+        SD_HIP(hipEventSynchronize(e->ev_run1));
         e->in_pending = false;
+        hipStream_t cs = e->copy_stream ? e->copy_stream : e->last_stream;
         if (C == 0) { e->h_roff.alloc(1); e->h_roff.p[0] = 0; return SD_OK; }
         total = e->h_roff.p[C];
         if (total > e->dense_cap) {
@@ -689,8 +703,8 @@ static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errle
         e->h_recs.alloc((size_t)std::max<int64_t>(total, 1));
         static_assert(sizeof(sd_rec) == sizeof(sd::DevRec), "record layout");
         if (total > 0) {
-            SD_HIP(hipMemcpyAsync(e->h_recs.p, e->d_dense.p, sizeof(sd_rec) * (size_t)total, hipMemcpyDeviceToHost, e->last_stream));
-            SD_HIP(hipStreamSynchronize(e->last_stream));
+            SD_HIP(hipMemcpyAsync(e->h_recs.p, e->d_dense.p, sizeof(sd_rec) * (size_t)total, hipMemcpyDeviceToHost, cs));
+            SD_HIP(hipStreamSynchronize(cs));
         }
         if (e->score_scale != 1)
             for (int64_t x = 0; x < total; ++x) e->h_recs.p[x].score *= e->score_scale;
@@ -837,7 +851,10 @@ struct Pipeline {
     std::vector<const char*> mseq;
     std::vector<int32_t> mlen;
     sd_engine* eng[NS] = {nullptr, nullptr};
-    hipStream_t st[NS] = {nullptr, nullptr};
+    hipStream_t copy_st[NS] = {nullptr, nullptr};  // per slot: H2D of the batch, D2H of its records
+    hipStream_t fill_st = nullptr;                 // fills of all batches, in order
+    hipStream_t trace_st = nullptr;                // traceback + compaction of all batches (lower priority)
+    bool streams_tried = false;
     RecSink sinks[NS];
     uint64_t pushed = 0, popped = 0;
     char eb[1024] = {0};
@@ -852,10 +869,12 @@ struct Pipeline {
         mlen.assign(mono_lens, mono_lens + n_mono);
         return sd_engine_create(&eng[0], &p, mseq.data(), mlen.data(), n_mono, eb, sizeof eb);
     }
-    // rows one batch may hold: <= 48 M (~900 reads of 50 kb: fills the GPU twice over and still leaves the
-    // host/device pipeline stages to overlap) and <= 27 % of the free HBM
+    // rows one batch may hold: <= 64 M (~1200 reads of 50 kb) and <= 27 % of the free HBM.  The kernels are
+    // persistent -- 4096 resident waves pull chunks from a queue -- so a launch is efficient only with a
+    // few chunks per wave: batches are kept as large as the budget allows (C2's 10 000 chunks are ONE batch;
+    // cutting them into 4 x 2 500 costs 1.4x, measured) and overlap comes from pipelining whole batches.
     int64_t row_budget() const {
-        int64_t budget = (int64_t)48 << 20;
+        int64_t budget = (int64_t)64 << 20;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             // per row: B + argB + records (24 B) + fast-family checkpoints (P*256 B every FAST_R rows)
@@ -872,6 +891,27 @@ struct Pipeline {
         return h;
     }
     int inflight() const { return (int)(pushed - popped); }
+    // SD_PIPE_MODE (developer A/B): 0 = every kernel of every batch on one stream; 1 (default) = fills on
+    // one stream, traceback + compaction on a second, lower-priority one
+    void make_streams() {
+        if (streams_tried) return;
+        streams_tried = true;
+        int mode = 1;
+        if (const char* ev = getenv("SD_PIPE_MODE")) mode = atoi(ev);
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least urgent (numerically largest)
+        const char* pe = getenv("SD_PIPE_PRIO");
+        const bool prio = !(pe && pe[0] == '0');
+        const char* ce = getenv("SD_PIPE_COPY");
+        if (!(ce && ce[0] == '0'))
+            for (int q = 0; q < NS; ++q)
+                if (hipStreamCreateWithFlags(&copy_st[q], hipStreamNonBlocking) != hipSuccess) copy_st[q] = nullptr;
+        const char* ne = getenv("SD_PIPE_NULL");
+        if (ne && ne[0] == '1') return;   // kernels on the null stream
+        if (hipStreamCreateWithPriority(&fill_st, hipStreamNonBlocking, prio ? hi : 0) != hipSuccess) fill_st = nullptr;
+        if (mode == 1 && fill_st && hipStreamCreateWithPriority(&trace_st, hipStreamNonBlocking, prio ? lo : 0) != hipSuccess)
+            trace_st = nullptr;
+    }
     int push(const std::vector<const char*>& cptr, const std::vector<int32_t>& clen, RecSink sink) {
         int rc = SD_OK;
         if (inflight() == NS) rc = pop();
@@ -881,13 +921,11 @@ struct Pipeline {
             rc = sd_engine_create(&eng[k], &p, mseq.data(), mlen.data(), (int32_t)mseq.size(), eb, sizeof eb);
             if (rc) return rc;
         }
-        if (!st[k] && pushed > 0) {  // a lone batch runs on the null stream; a second one brings the streams in
-            for (int q = 0; q < NS; ++q)
-                if (!st[q] && hipStreamCreateWithFlags(&st[q], hipStreamNonBlocking) != hipSuccess) st[q] = nullptr;
-        }
+        make_streams();
         const double t0 = now_s();
-        rc = load_chunks_impl(eng[k], cptr, clen, st[k], eb, sizeof eb);
-        if (rc == SD_OK) rc = sd_engine_run(eng[k], st[k], eb, sizeof eb);
+        eng[k]->copy_stream = copy_st[k];
+        rc = load_chunks_impl(eng[k], cptr, clen, copy_st[k] ? copy_st[k] : fill_st, eb, sizeof eb);
+        if (rc == SD_OK) rc = engine_run2(eng[k], fill_st, trace_st ? trace_st : fill_st, eb, sizeof eb);
         pack_s += now_s() - t0;
         if (rc) return rc;
         sinks[k] = std::move(sink);
@@ -924,10 +962,10 @@ struct Pipeline {
     }
     ~Pipeline() {
         if (inflight() > 0) (void)hipDeviceSynchronize();  // nothing may still run on buffers we free
-        for (hipStream_t s2 : st)
-            if (s2) (void)hipStreamDestroy(s2);
         for (sd_engine* e : eng)
             if (e) sd_engine_destroy(e);
+        for (hipStream_t s2 : {copy_st[0], copy_st[1], fill_st, trace_st})
+            if (s2) (void)hipStreamDestroy(s2);
     }
 };
 
@@ -936,10 +974,14 @@ struct Pipeline {
 void plan_batches(const std::vector<CRef>& table, size_t c_lo, size_t c_hi, int64_t budget, int min_batches,
                   std::vector<std::pair<size_t, size_t>>& out) {
     out.clear();
-    if (min_batches > 1) {
+    {
+        // equal shares: the last batch of a job must not be a small remainder (a launch with less than one
+        // chunk per resident wave takes as long as a full round)
         int64_t tot = 0;
         for (size_t c = c_lo; c < c_hi; ++c) tot += table[c].len;
-        budget = std::min<int64_t>(budget, std::max<int64_t>(1, (tot + min_batches - 1) / min_batches));
+        const int64_t nb = std::max<int64_t>(std::max(min_batches, 1), (tot + budget - 1) / std::max<int64_t>(budget, 1));
+        const int64_t lmax = c_lo < c_hi ? table[c_lo].len : 1;   // slack of one chunk: shares need not split evenly
+        budget = std::min<int64_t>(budget, std::max<int64_t>(1, (tot + nb - 1) / nb + (nb > 1 ? lmax : 0)));
     }
     for (size_t c0 = c_lo; c0 < c_hi;) {
         int64_t rows = 0;

@@ -311,7 +311,7 @@ class Stream:
     """Pipelined sequences-in-host-memory -> rows-in-host-memory path (sd_stream_*): submit() read sets,
     collect() their rows in FIFO order; two device batches are in flight across job boundaries."""
 
-    def __init__(self, mono_seqs, sub_batches=4, **kw):
+    def __init__(self, mono_seqs, sub_batches=1, **kw):
         self.L = load()
         self.params = make_params(**kw)
         self._err = C.create_string_buffer(4096)
