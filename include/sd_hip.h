@@ -222,6 +222,17 @@ int sd_identity_segments(const char* seq, int64_t seqlen, const int64_t* starts,
                          const int32_t* pair_tmpl, int32_t homo, int32_t threads, int32_t* dist,
                          int32_t* matches, int32_t* columns);
 
+/* The same on the device (csrc/sd_nw.hip: one lane per (segment, template) pair, Myers bit-vectors with
+ * a per-lane delta history in HBM and edlib's traceback priority): identical results.  Returns
+ * SD_ERR_NO_DEVICE without a GPU and SD_ERR_UNSUPPORTED for input the kernel does not take (a symbol
+ * outside ACGTN, a template longer than 512 bp, a segment longer than 65000 bp) -- callers then use
+ * sd_identity_segments.  Device buffers are kept between calls (sd_nw_release_cache frees them). */
+int sd_identity_segments_dev(const char* seq, int64_t seqlen, const int64_t* starts, const int64_t* ends,
+                             int64_t n_seg, const char* const* tmpl, const int32_t* tlen, int32_t T,
+                             const int32_t* pair_tmpl, int32_t homo, int32_t device, int32_t threads,
+                             int32_t* dist, int32_t* matches, int32_t* columns);
+void sd_nw_release_cache(void);
+
 /* Text of `_alt.tsv` rows (main.py:161-165): for each of n_rows kept blocks one line per monomer name
  * (key): read, name, start, end, "%.2f" of vals[row * n_keys + key], '*' if key == own_key[row] else
  * '-'.  The read of a row is read_names[row_read[row]] (row_read == NULL: read_names[0] for all rows).

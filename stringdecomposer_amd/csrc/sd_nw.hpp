@@ -1,0 +1,17 @@
+// sd_nw.hpp -- launch wrapper of the batched NW identity kernel (sd_nw.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace sd {
+
+// One lane per (segment, template) pair; K = 64-bit words per template (ceil(max tlen / 64), 1..8).
+// hist: grid * 256 lanes x qmax columns x K x 16 B.
+void launch_nw_pairs(int K, hipStream_t st, int grid, const uint8_t* seq, const int64_t* seg_start,
+                     const int32_t* seg_len, int64_t n_seg, int T, const int32_t* pair_tmpl,
+                     const unsigned long long* peq, const int32_t* tlen, int homo, int qmax, void* hist,
+                     int32_t* dist, int32_t* matches);
+
+}  // namespace sd

@@ -32,7 +32,7 @@ EXPORTS = [
     "sd_fasta_free", "sd_nw_identity_batch", "sd_identity_segments", "sd_chunk_table_size",
     "sd_decompose_chunk_range", "sd_assemble_tsv", "sd_release_cache", "sd_format_alt_rows",
     "sd_stream_create", "sd_stream_destroy", "sd_stream_submit", "sd_stream_collect", "sd_stream_stats",
-    "sd_stream_info", "sd_pack_bases",
+    "sd_stream_info", "sd_pack_bases", "sd_identity_segments_dev", "sd_nw_release_cache",
 ]
 
 
@@ -106,6 +106,9 @@ def load():
     L.sd_identity_segments.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                        P(C.c_char_p), P(C.c_int32), C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sd_identity_segments_dev.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                           P(C.c_char_p), P(C.c_int32), C.c_int32, C.c_void_p, C.c_int32,
+                                           C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.sd_format_alt_rows.argtypes = [P(C.c_char_p), C.c_int32, C.c_void_p, P(C.c_char_p), C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, P(C.c_void_p),
                                      P(C.c_size_t)]
@@ -455,10 +458,12 @@ def nw_identity_batch(queries, targets, threads=1):
     return [(d[i], m[i], c[i]) for i in range(n)]
 
 
-def identity_segments(seq, starts, ends, templates, homo=False, threads=1, pair_tmpl=None):
+def identity_segments(seq, starts, ends, templates, homo=False, threads=1, pair_tmpl=None, device=None):
     """(dist, matches, columns) int32 arrays of shape [n_segments, n_templates]: every segment
     seq[starts[s] .. ends[s]] (inclusive) against every template (main.py:107-150 all-vs-all);
-    with pair_tmpl (template index per segment) arrays of shape [n_segments]: that pair only."""
+    with pair_tmpl (template index per segment) arrays of shape [n_segments]: that pair only.
+    device=None: the host implementation (sd_identity_segments); device=<ordinal>: the HIP kernel
+    (sd_identity_segments_dev), with the host implementation for input the kernel does not take."""
     import numpy as np
     L = load()
     sb = _b(seq)
@@ -473,9 +478,18 @@ def identity_segments(seq, starts, ends, templates, homo=False, threads=1, pair_
     d = np.zeros(shape, dtype=np.int32)
     m = np.zeros(shape, dtype=np.int32)
     c = np.zeros(shape, dtype=np.int32)
-    rc = L.sd_identity_segments(sb, len(sb), st.ctypes.data, en.ctypes.data, n, _strs(tb), tl, T,
-                                None if pt is None else pt.ctypes.data, 1 if homo else 0, threads,
-                                d.ctypes.data, m.ctypes.data, c.ctypes.data)
+    tarr = _strs(tb)
+    rc = SD_ERR_UNSUPPORTED
+    if device is not None:
+        rc = L.sd_identity_segments_dev(sb, len(sb), st.ctypes.data, en.ctypes.data, n, tarr, tl, T,
+                                        None if pt is None else pt.ctypes.data, 1 if homo else 0, int(device),
+                                        threads, d.ctypes.data, m.ctypes.data, c.ctypes.data)
+        if rc not in (SD_OK, SD_ERR_UNSUPPORTED):
+            raise SdError(rc, "sd_identity_segments_dev")
+    if rc == SD_ERR_UNSUPPORTED:
+        rc = L.sd_identity_segments(sb, len(sb), st.ctypes.data, en.ctypes.data, n, tarr, tl, T,
+                                    None if pt is None else pt.ctypes.data, 1 if homo else 0, threads,
+                                    d.ctypes.data, m.ctypes.data, c.ctypes.data)
     if rc != SD_OK:
         raise SdError(rc, "sd_identity_segments")
     return d, m, c

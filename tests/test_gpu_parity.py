@@ -445,3 +445,53 @@ def test_stream_rows_equal_oracle(oracle, sub, cap):
         assert txt == oracle.decompose(names, seqs, mn, ms, threads=8)
     with pytest.raises(lib.SdError):
         lib.Stream(ms).collect()
+
+
+@pytest.mark.parametrize("shape", [(12, 160, 180), (64, 165, 178), (5, 20, 70), (3, 300, 500), (2, 1, 5), (7, 120, 260)])
+def test_nw_identity_kernel_equals_host_and_edlib(shape):
+    """K3 (main.py:29-60,107-150): the device identity kernel (one lane per (segment, template) pair) against
+    the host implementation -- itself pinned against the reference's vendored edlib on CPU -- for every pair,
+    all-vs-all and own-template, plain and homopolymer-compressed, and against edlib directly on a sample."""
+    import edlib_ref
+    nm, lo, hi = shape
+    st = synth.Stream(77, nm * 100 + lo)
+    ms = _random_monomers(st, nm, lo, hi, with_n=(nm == 5))
+    tm = [m.decode() for m in ms] + [synth.revcomp_bytes(m).decode() for m in ms]
+    parts = []
+    while sum(len(x) for x in parts) < 40000:
+        j = int(st.below(1, nm)[0])
+        codes = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), np.frombuffer(ms[j].replace(b"N", b"A"), dtype=np.uint8))
+        x = synth._to_ascii(synth.mutate(codes, st, 0.08, 0.04, 0.04)) or b"A"
+        parts.append(synth.revcomp_bytes(x) if st.below(1, 2)[0] else x)
+        if st.below(1, 6)[0] == 0:
+            parts.append(bytes([b"ACGT"[int(st.below(1, 4)[0])]]) * (1 + int(st.below(1, 30)[0])))
+    seq = bytearray(b"".join(parts))
+    for p in st.below(40, len(seq)):
+        seq[int(p)] = ord("N")
+    seq = bytes(seq)
+    n = 300
+    starts = np.sort(st.below(n, len(seq) - 2 * hi - 2))
+    lens = st.below(n, 2 * hi) + 1
+    lens[:5] = [1, 2, 64, 65, 2 * hi]
+    ends = starts + lens - 1
+    pair = st.below(n, len(tm)).astype(np.int32)
+    for homo in (False, True):
+        h = lib.identity_segments(seq, starts, ends, tm, homo, threads=8)
+        d = lib.identity_segments(seq, starts, ends, tm, homo, threads=8, device=0)
+        for a, b in zip(h, d):
+            assert (a == b).all(), (shape, homo)
+        hp = lib.identity_segments(seq, starts, ends, tm, homo, threads=8, pair_tmpl=pair)
+        dp = lib.identity_segments(seq, starts, ends, tm, homo, threads=8, pair_tmpl=pair, device=0)
+        for a, b in zip(hp, dp):
+            assert (a == b).all(), (shape, homo, "pair")
+        for s_ in range(0, n, 37):
+            for t_ in range(0, len(tm), 5):
+                q, t = seq[starts[s_]:ends[s_] + 1].decode(), tm[t_]
+                if homo:
+                    q, t = edlib_ref.homo(q), edlib_ref.homo(t)
+                assert edlib_ref.nw(q, t) == (int(d[0][s_, t_]), int(d[1][s_, t_]), int(d[2][s_, t_]))
+    # input the kernel does not take falls back to the host implementation inside lib.identity_segments
+    bad = seq[:100] + b"R" + seq[101:]
+    a = lib.identity_segments(bad, starts[:20], ends[:20], tm, False, threads=2, device=0)
+    b = lib.identity_segments(bad, starts[:20], ends[:20], tm, False, threads=2)
+    assert all((x == y).all() for x, y in zip(a, b))

@@ -1,22 +1,23 @@
 #!/usr/bin/env python3
-"""Thread scaling of sd_nw_identity_batch (host post-processing) on monomer-sized pairs (developer tool)."""
-import ctypes as C, os, sys, time
+"""Throughput of the NW identity post-processing (developer tool): C2-like blocks x 24 templates
+(--second-best shape), host threads vs the device kernel.  usage: nw_bench.py [blocks] [monomers]"""
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import numpy as np
 from stringdecomposer_amd import lib, synth
-mn, ms = synth.make_monomers(64, seed=1)
-rn, rs = synth.make_reads(ms, 1, read_len=50000, seed=1)
-segs = [rs[0][i * 171:(i + 1) * 171 + 3] for i in range(280)]
-q = [s for s in segs for _ in range(64)] * 4
-t = [m for _ in segs for m in ms] * 4
-L = lib.load()
-n = len(q)
-qa, ta = lib._strs(q), lib._strs(t)
-ql = (C.c_int32 * n)(*[len(x) for x in q])
-tl = (C.c_int32 * n)(*[len(x) for x in t])
-d, m, c = (C.c_int32 * n)(), (C.c_int32 * n)(), (C.c_int32 * n)()
-for th in (1, 2, 4, 8, 16, 32, 64):
-    t0 = time.perf_counter()
-    L.sd_nw_identity_batch(qa, ql, ta, tl, n, th, d, m, c)
-    dt = time.perf_counter() - t0
-    print("%2d threads: %.2f us per alignment, %.2f M alignments/s" % (th, dt / n * 1e6, n / dt / 1e6))
+nb = int(sys.argv[1]) if len(sys.argv) > 1 else 64000
+nm = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+mn, ms = synth.make_monomers(nm, seed=1)
+tm = [m.decode() for m in ms] + [synth.revcomp_bytes(m).decode() for m in ms]
+rn, rs = synth.make_reads(ms, max(1, nb * 171 // 50000 + 1), read_len=50000, seed=3)
+seq = b"".join(rs)
+starts = np.arange(nb, dtype=np.int64) * 171
+ends = starts + 170
+for homo in (False, True):
+    for dev in (None, 0, 0):
+        t0 = time.time()
+        d, m, c = lib.identity_segments(seq, starts, ends, tm, homo, threads=64, device=dev)
+        dt = time.time() - t0
+        print("homo=%d %s: %d pairs in %.3f s = %.1f M pairs/s  checksum %d" % (
+            homo, "host x64" if dev is None else "device", d.size, dt, d.size / dt / 1e6, int(d.sum() + 3 * m.sum())), flush=True)
