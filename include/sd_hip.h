@@ -82,6 +82,23 @@ int sd_decompose(const char* const* read_names, const char* const* read_seqs,
                  const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono,
                  const sd_params* p, char** tsv, size_t* tsv_len, char* errbuf, size_t errlen);
 
+/* The whole CLI job in one call (main.py:186-197 `run` + :168-184 `convert_tsv`): both FASTA files are
+ * mapped and indexed by all host threads, the chunks stream through the device in batches, and every
+ * batch's rows are written three ways -- raw TSV (as sd_decompose_files), final TSV (main.py:157-160) and
+ * _alt TSV (:161-165, empty without second_best) -- with the identities of main.py:29-60 computed by the
+ * device kernel of sd_identity_segments_dev.  lr_coef = the three logistic-regression coefficients of
+ * main.py:25-26.  Nothing is re-read from the raw file. */
+int sd_run_files(const char* reads_fa, const char* monomers_fa, const sd_params* p, const char* raw_tsv_out,
+                 const char* final_tsv_out, const char* alt_tsv_out, int32_t min_identity, int32_t second_best,
+                 const double* lr_coef, char* errbuf, size_t errlen);
+
+/* convert_tsv (main.py:168-184) alone: an existing raw TSV + the two FASTA files -> final TSV and _alt TSV,
+ * streamed in batches of reads.  device < 0: host identities (sd_identity_segments). */
+int sd_convert_raw_tsv(const char* raw_tsv, const char* reads_fa, const char* monomers_fa,
+                       const char* final_tsv_out, const char* alt_tsv_out, int32_t min_identity,
+                       int32_t second_best, const double* lr_coef, int32_t device, int32_t threads,
+                       char* errbuf, size_t errlen);
+
 /* ---- chunk-range form: one job sharded over several GPUs, one process per GPU ---------------
  * The chunks of a read set (main.cpp:70-81, all reads, input order) form one global table; a chunk's
  * DP depends on nothing but its own bases and the template set (main.cpp:88-96), so rank g runs the
@@ -96,6 +113,16 @@ int sd_decompose_chunk_range(const char* const* read_seqs, const int64_t* read_l
                              const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono,
                              const sd_params* p, int64_t chunk_lo, int64_t chunk_hi, sd_rec** recs,
                              int64_t** rec_off, char* errbuf, size_t errlen);
+
+/* File forms, for the multi-process command line: every rank maps + indexes the FASTA (sequences are not
+ * copied), runs its share block_range(n_chunks, rank, world) of the chunk table and validates only the reads
+ * that share touches; rank 0 then turns the gathered records into the raw TSV file. */
+int sd_decompose_files_range(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank,
+                             int32_t world, sd_rec** recs, int64_t** rec_off, int64_t* chunk_lo, int64_t* chunk_hi,
+                             int64_t* n_chunks_total, char* errbuf, size_t errlen);
+int sd_assemble_files_tsv(const char* reads_fa, const char* monomers_fa, const sd_params* p, const sd_rec* recs,
+                          const int64_t* rec_off, int64_t n_chunks, const char* raw_tsv_out, char* errbuf,
+                          size_t errlen);
 
 /* Host only: records of ALL chunks in table order -> raw TSV (chunk offsets main.cpp:109-111, seam
  * merge :287-302, SaveBatch :272-285).  The bytes equal sd_decompose's. */

@@ -1,0 +1,48 @@
+// sd_convert.hpp -- native post-processing (sd_convert.hip): raw monomer alignments of a batch of reads ->
+// rows of final_decomposition.tsv / _alt.tsv (stringdecomposer/main.py:107-165).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/sd_hip.h"
+#include "sd_host.hpp"
+
+namespace sd {
+
+struct PostRead {
+    const char* name; size_t name_len;
+    const char* seq; int64_t len;       // upper-case sequence (main.py:66-67)
+};
+
+class PostProcessor {
+  public:
+    // monomers in file order (names = first header token, sequences upper-case); device < 0: host identities
+    int init(const std::vector<Seq>& monos, int min_identity, bool second_best, const double coef[3], int device,
+             int threads, std::string& err);
+    // rows[row_off[r] .. row_off[r+1]) = blocks of reads[r] (sd_rec.tmpl in the DP's template order: monomers,
+    // then their reverse complements; read-global inclusive coordinates).  Appends the text of the final TSV
+    // rows (main.py:157-160) and, with second_best, of the _alt rows (:161-165).
+    int process(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off, std::string& fin,
+                std::string& alt, std::string& err);
+    int tmpl_of_name(const std::string& nm) const;   // first template of that name in the DP's order, -1 if none
+    std::vector<std::string> tname;                  // the DP's template names: m, ..., m', ...
+
+  private:
+    int identities(const std::vector<std::pair<const char*, int64_t>>& spans, const std::vector<int64_t>& seg_start,
+                   const std::vector<int32_t>& seg_len, const int32_t* pair, bool homo, std::vector<double>& out,
+                   std::string& err);
+    std::vector<std::string> il_name, il_seq;        // interleaved m0, m0', m1, m1', ... (main.py:79-84)
+    std::vector<std::string> keys;                   // distinct names in first-occurrence order
+    std::vector<int> kcol;                           // key -> last interleaved index of that name
+    std::vector<int> key_of_t, own_il_of_t;
+    int min_identity = 0;
+    bool second_best = false;
+    double coef[3] = {0, 0, 0};
+    int device = -1;
+    int threads = 1;
+};
+
+}  // namespace sd

@@ -13,9 +13,11 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sd_hip.h"
+#include "sd_convert.hpp"
 #include "sd_device.hpp"
 #include "sd_fast.hpp"
 #include "sd_host.hpp"
@@ -1164,16 +1166,19 @@ int sd_decompose_files(const char* reads_fa, const char* monomers_fa, const sd_p
     std::string err;
     int rc = validate_params(p, err);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
-    std::vector<sd::Seq> reads, monos;
-    bool hn = false;
-    rc = sd::load_fasta(reads_fa, reads, hn, err);       // main.cpp:394
+    if (!reads_fa || !monomers_fa || !raw_tsv_out) return SD_ERR_PARAM;
+    sd::FastaFile rf, mf;
+    rc = rf.open(reads_fa, p->threads, err);                                  // main.cpp:394
+    if (rc == SD_OK) rc = rf.validate(0, rf.recs.size(), p->threads, err);
+    if (rc == SD_OK) rc = mf.open(monomers_fa, p->threads, err);              // main.cpp:395
+    if (rc == SD_OK) rc = mf.validate(0, mf.recs.size(), p->threads, err);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
-    rc = sd::load_fasta(monomers_fa, monos, hn, err);    // main.cpp:395
-    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    std::vector<sd::Seq> monos;
+    for (const auto& r : mf.recs) monos.push_back(sd::Seq{std::string(r.name, r.name_len), std::string(r.seq, (size_t)r.len)});
     std::string out;
     std::vector<ReadView> views;
-    views.reserve(reads.size());
-    for (const sd::Seq& r : reads) views.push_back(ReadView{r.name.data(), r.name.size(), r.seq.data(), (int64_t)r.seq.size()});
+    views.reserve(rf.recs.size());
+    for (const auto& r : rf.recs) views.push_back(ReadView{r.name, r.name_len, r.seq, r.len});
     rc = decompose_impl(views, monos, p, out, err);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
     FILE* fp = std::fopen(raw_tsv_out, "wb");
@@ -1261,6 +1266,98 @@ int sd_decompose_chunk_range(const char* const* read_seqs, const int64_t* read_l
     std::memcpy(ro, offs.data(), sizeof(int64_t) * offs.size());
     *recs = o;
     *rec_off = ro;
+    return SD_OK;
+}
+
+// File form of the chunk-range call for a job sharded over ranks: every rank maps and indexes the FASTA
+// (no copy of the sequences), takes the contiguous share block_range(n_chunks, rank, world) of the global
+// chunk table and checks the alphabet of the reads that share touches only (main.cpp:329-341 reports the
+// first offending read in file order: the caller raises the error of the lowest failing rank).
+int sd_decompose_files_range(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank,
+                             int32_t world, sd_rec** recs, int64_t** rec_off, int64_t* chunk_lo, int64_t* chunk_hi,
+                             int64_t* n_chunks_total, char* errbuf, size_t errlen) {
+    if (!recs || !rec_off || !reads_fa || !monomers_fa || world < 1 || rank < 0 || rank >= world) return SD_ERR_PARAM;
+    *recs = nullptr;
+    *rec_off = nullptr;
+    std::string err;
+    int rc = validate_params(p, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    sd::FastaFile rf, mf;
+    rc = rf.open(reads_fa, p->threads, err);
+    if (rc == SD_OK) rc = mf.open(monomers_fa, p->threads, err);
+    if (rc == SD_OK) rc = mf.validate(0, mf.recs.size(), p->threads, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    std::vector<sd::Seq> monos;
+    for (const auto& r : mf.recs) monos.push_back(sd::Seq{std::string(r.name, r.name_len), std::string(r.seq, (size_t)r.len)});
+    if (monos.empty()) { set_err(errbuf, errlen, "no monomers"); return SD_ERR_PARAM; }
+    std::vector<ReadView> reads;
+    reads.reserve(rf.recs.size());
+    for (const auto& r : rf.recs) {
+        if (r.len <= 0) { set_err(errbuf, errlen, "ERROR: Sequence " + std::string(r.name, r.name_len) + " is empty"); return SD_ERR_EMPTY; }
+        reads.push_back(ReadView{r.name, r.name_len, r.seq, r.len});
+    }
+    TemplateSet ts(monos);
+    std::vector<CRef> table;
+    std::vector<int32_t> nch;
+    build_chunk_table(reads, p, table, nch);
+    const int64_t n = (int64_t)table.size();
+    const int64_t base = n / world, extra = n % world;
+    const int64_t lo = rank * base + std::min<int64_t>(rank, extra);
+    const int64_t hi = lo + base + (rank < extra ? 1 : 0);
+    if (chunk_lo) *chunk_lo = lo;
+    if (chunk_hi) *chunk_hi = hi;
+    if (n_chunks_total) *n_chunks_total = n;
+    if (hi > lo) {
+        rc = rf.validate((size_t)table[(size_t)lo].read, (size_t)table[(size_t)hi - 1].read + 1, p->threads, err);
+        if (rc) { set_err(errbuf, errlen, err); return rc; }
+    }
+    std::vector<sd_rec> all;
+    std::vector<int64_t> offs(1, 0);
+    rc = run_chunk_batches(reads, table, (size_t)lo, (size_t)hi, ts, p, err,
+                           [&](size_t c0, size_t c1, const sd_rec* r, const int64_t* ro) {
+                               const int64_t b0 = (int64_t)all.size();
+                               all.insert(all.end(), r, r + ro[c1 - c0]);
+                               for (size_t c = 1; c <= c1 - c0; ++c) offs.push_back(b0 + ro[c]);
+                           });
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    sd_rec* o = static_cast<sd_rec*>(std::malloc(sizeof(sd_rec) * std::max<size_t>(all.size(), 1)));
+    if (!all.empty()) std::memcpy(o, all.data(), sizeof(sd_rec) * all.size());
+    int64_t* ro = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * offs.size()));
+    std::memcpy(ro, offs.data(), sizeof(int64_t) * offs.size());
+    *recs = o;
+    *rec_off = ro;
+    return SD_OK;
+}
+
+// Rank 0 of a sharded job: the records of all chunks in table order -> raw TSV file (names and lengths come
+// from the FASTA index; host only).
+int sd_assemble_files_tsv(const char* reads_fa, const char* monomers_fa, const sd_params* p, const sd_rec* recs,
+                          const int64_t* rec_off, int64_t n_chunks, const char* raw_tsv_out, char* errbuf, size_t errlen) {
+    if (!reads_fa || !monomers_fa || !rec_off || !raw_tsv_out || (!recs && rec_off[n_chunks] > 0)) return SD_ERR_PARAM;
+    std::string err;
+    int rc = validate_params(p, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    sd::FastaFile rf, mf;
+    rc = rf.open(reads_fa, p->threads, err);
+    if (rc == SD_OK) rc = mf.open(monomers_fa, p->threads, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    std::vector<std::string> rnames, mnames;
+    std::vector<const char*> rn, mn;
+    std::vector<int64_t> rl;
+    for (const auto& r : rf.recs) { rnames.emplace_back(r.name, r.name_len); rl.push_back(r.len); }
+    for (const auto& r : mf.recs) mnames.emplace_back(r.name, r.name_len);
+    for (const std::string& x : rnames) rn.push_back(x.c_str());
+    for (const std::string& x : mnames) mn.push_back(x.c_str());
+    char* tsv = nullptr;
+    size_t len = 0;
+    rc = sd_assemble_tsv(rn.data(), rl.data(), (int32_t)rn.size(), mn.data(), (int32_t)mn.size(), p, recs, rec_off, n_chunks,
+                         &tsv, &len, errbuf, errlen);
+    if (rc) return rc;
+    FILE* fp = std::fopen(raw_tsv_out, "wb");
+    if (!fp) { std::free(tsv); set_err(errbuf, errlen, std::string("cannot write ") + raw_tsv_out); return SD_ERR_IO; }
+    const size_t w = std::fwrite(tsv, 1, len, fp);
+    std::free(tsv);
+    if (std::fclose(fp) != 0 || w != len) { set_err(errbuf, errlen, std::string("short write to ") + raw_tsv_out); return SD_ERR_IO; }
     return SD_OK;
 }
 
@@ -1558,6 +1655,146 @@ int32_t sd_pack_bases(const char* seq, int64_t n, uint32_t* words, uint32_t* nma
 }
 
 // -------------------------------------------------------------------------------------------
+// whole CLI job as one native call: FASTA files -> raw TSV + final TSV + _alt TSV, streamed per
+// device batch (main.py:186-197 run + :168-184 convert_tsv without the round trip through the raw file)
+// -------------------------------------------------------------------------------------------
+int sd_run_files(const char* reads_fa, const char* monomers_fa, const sd_params* p, const char* raw_tsv_out,
+                 const char* final_tsv_out, const char* alt_tsv_out, int32_t min_identity, int32_t second_best,
+                 const double* lr_coef, char* errbuf, size_t errlen) {
+    std::string err;
+    int rc = validate_params(p, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    if (!reads_fa || !monomers_fa || !raw_tsv_out || !final_tsv_out || !alt_tsv_out || !lr_coef) return SD_ERR_PARAM;
+    const bool timing = getenv("SD_TIMING") != nullptr;
+    const double t_begin = now_s();
+    double t_prev = t_begin;
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const double t = now_s();
+        std::fprintf(stderr, "[sd timing] %-34s %9.2f ms\n", what, (t - t_prev) * 1e3);
+        t_prev = t;
+    };
+    sd::FastaFile rf, mf;
+    rc = rf.open(reads_fa, p->threads, err);                                  // main.cpp:394
+    if (rc == SD_OK) rc = rf.validate(0, rf.recs.size(), p->threads, err);
+    if (rc == SD_OK) rc = mf.open(monomers_fa, p->threads, err);              // main.cpp:395
+    if (rc == SD_OK) rc = mf.validate(0, mf.recs.size(), p->threads, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    lap("FASTA index + alphabet check");
+    std::vector<sd::Seq> monos;
+    for (const auto& r : mf.recs) monos.push_back(sd::Seq{std::string(r.name, r.name_len), std::string(r.seq, (size_t)r.len)});
+    if (monos.empty()) { set_err(errbuf, errlen, "no monomers"); return SD_ERR_PARAM; }
+    std::vector<ReadView> reads;
+    reads.reserve(rf.recs.size());
+    for (const auto& r : rf.recs) {
+        if (r.len <= 0) { set_err(errbuf, errlen, "ERROR: Sequence " + std::string(r.name, r.name_len) + " is empty"); return SD_ERR_EMPTY; }
+        reads.push_back(ReadView{r.name, r.name_len, r.seq, r.len});
+    }
+    {
+        // SeqIO.to_dict (main.py:65) refuses repeated read ids
+        std::vector<std::pair<std::string, size_t>> nm;
+        nm.reserve(reads.size());
+        for (size_t r = 0; r < reads.size(); ++r) nm.emplace_back(std::string(reads[r].name, reads[r].name_len), r);
+        std::sort(nm.begin(), nm.end());
+        for (size_t i = 1; i < nm.size(); ++i)
+            if (nm[i].first == nm[i - 1].first) { set_err(errbuf, errlen, "Duplicate key '" + nm[i].first + "'"); return SD_ERR_FORMAT; }
+    }
+    TemplateSet ts(monos);
+    sd::PostProcessor pp;
+    rc = pp.init(monos, min_identity, second_best != 0, lr_coef, p->device, p->threads, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    FILE* fr = std::fopen(raw_tsv_out, "wb");
+    FILE* ff = fr ? std::fopen(final_tsv_out, "wb") : nullptr;
+    FILE* fa = ff ? std::fopen(alt_tsv_out, "wb") : nullptr;
+    if (!fr || !ff || !fa) {
+        for (FILE* f : {fr, ff, fa}) if (f) std::fclose(f);
+        set_err(errbuf, errlen, std::string("cannot write ") + raw_tsv_out);
+        return SD_ERR_IO;
+    }
+    RowJob job;
+    job.n_reads = (int32_t)reads.size();
+    job.threads = p->threads;
+    build_chunk_table(reads, p, job.table, job.nch);
+    job.row_off = static_cast<int64_t*>(std::calloc(reads.size() + 1, sizeof(int64_t)));
+    Pipeline pipe;
+    rc = pipe.create(p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size());
+    if (rc) err = pipe.eb;
+    std::vector<std::pair<size_t, size_t>> batches;
+    if (rc == SD_OK) plan_batches(job.table, 0, job.table.size(), pipe.row_budget(), 1, batches);
+    lap("chunk table, engine");
+    int sink_rc = SD_OK;
+    double t_fmt = 0, t_post = 0, t_io = 0;
+    std::string raw, fin, alt;
+    std::vector<sd::PostRead> preads;
+    auto sink = [&](size_t c0, size_t c1, const sd_rec* recs, const int64_t* roff) {
+        if (sink_rc) return;
+        const size_t r0 = job.next_read;
+        job.n_rows = 0;
+        job.row_off[r0] = 0;
+        job.add(c0, c1, recs, roff);
+        if (job.oom) { sink_rc = SD_ERR_INTERNAL; err = "out of host memory"; return; }
+        const size_t r1 = job.next_read;
+        if (r1 == r0) return;
+        double t0 = now_s();
+        // raw TSV (SaveBatch, main.cpp:272-285): slices of <= 32 k rows, so that a chromosome-sized read is
+        // formatted by all threads; a slice needs the end of the row before it
+        struct Slice { size_t r; int64_t a, b; };
+        std::vector<Slice> slices;
+        for (size_t r = r0; r < r1; ++r)
+            for (int64_t a = job.row_off[r]; a < job.row_off[r + 1]; a += 32768)
+                slices.push_back(Slice{r, a, std::min<int64_t>(job.row_off[r + 1], a + 32768)});
+        std::vector<std::string> parts(slices.size());
+        sd::parallel_for((int64_t)slices.size(), p->threads, 1, [&](int64_t x) {
+            const Slice& sl = slices[(size_t)x];
+            sd::format_rows(parts[(size_t)x], reads[sl.r].name, reads[sl.r].name_len, ts.tnames, job.rows + sl.a,
+                            (size_t)(sl.b - sl.a), sl.a > job.row_off[sl.r] ? job.rows[sl.a - 1].end : 0);
+        });
+        raw.clear();
+        for (const std::string& q : parts) raw += q;
+        t_fmt += now_s() - t0;
+        t0 = now_s();
+        preads.clear();
+        for (size_t r = r0; r < r1; ++r) preads.push_back(sd::PostRead{reads[r].name, reads[r].name_len, reads[r].seq, reads[r].len});
+        fin.clear();
+        alt.clear();
+        const int r2 = pp.process(preads.data(), preads.size(), job.rows, job.row_off + r0, fin, alt, err);
+        t_post += now_s() - t0;
+        if (r2) { sink_rc = r2; return; }
+        t0 = now_s();
+        if (std::fwrite(raw.data(), 1, raw.size(), fr) != raw.size() || std::fwrite(fin.data(), 1, fin.size(), ff) != fin.size() ||
+            std::fwrite(alt.data(), 1, alt.size(), fa) != alt.size()) {
+            sink_rc = SD_ERR_IO;
+            err = std::string("short write to ") + raw_tsv_out;
+        }
+        t_io += now_s() - t0;
+    };
+    std::vector<const char*> cptr;
+    std::vector<int32_t> clen;
+    for (size_t b = 0; b < batches.size() && rc == SD_OK && sink_rc == SD_OK; ++b) {
+        const size_t c0 = batches[b].first, c1 = batches[b].second;
+        cptr.clear();
+        clen.clear();
+        for (size_t c = c0; c < c1; ++c) {
+            cptr.push_back(reads[(size_t)job.table[c].read].seq + job.table[c].off);
+            clen.push_back(job.table[c].len);
+        }
+        rc = pipe.push(cptr, clen, [&sink, c0, c1](const sd_rec* r, const int64_t* ro, size_t) { sink(c0, c1, r, ro); });
+        if (rc) err = pipe.eb;
+    }
+    const int rc2 = pipe.drain();
+    if (rc == SD_OK && rc2) { rc = rc2; err = pipe.eb; }
+    if (rc == SD_OK) rc = sink_rc;
+    const bool w1 = std::fclose(fr) == 0, w2 = std::fclose(ff) == 0, w3 = std::fclose(fa) == 0;
+    if (rc == SD_OK && !(w1 && w2 && w3)) { rc = SD_ERR_IO; err = std::string("short write to ") + raw_tsv_out; }
+    if (timing)
+        std::fprintf(stderr, "[sd timing] %zu batches: pack+enqueue %.1f ms, wait %.1f ms, raw text %.1f ms, post-processing %.1f ms, "
+                     "file writes %.1f ms, total %.1f ms\n", batches.size(), pipe.pack_s * 1e3, pipe.wait_s * 1e3, t_fmt * 1e3,
+                     t_post * 1e3, t_io * 1e3, (now_s() - t_begin) * 1e3);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    return SD_OK;
+}
+
+// -------------------------------------------------------------------------------------------
 // host-only helpers (CPU tests)
 // -------------------------------------------------------------------------------------------
 int32_t sd_chunk_plan(int64_t read_len, int32_t part_size, int32_t overlap, int64_t* off,
@@ -1594,24 +1831,29 @@ int sd_format_rows(const char* read_name, const char* const* tmpl_names, const s
 }
 
 int sd_fasta_load(const char* path, sd_fasta* out, char* errbuf, size_t errlen) {
-    if (!out) return SD_ERR_PARAM;
+    if (!out || !path) return SD_ERR_PARAM;
     std::memset(out, 0, sizeof *out);
-    std::vector<sd::Seq> v;
-    bool hn = false;
+    sd::FastaFile ff;
     std::string err;
-    int rc = sd::load_fasta(path, v, hn, err);
+    const int threads = std::max(1, std::min(32, (int)std::thread::hardware_concurrency()));
+    int rc = ff.open(path, threads, err);
+    if (rc == SD_OK) rc = ff.validate(0, ff.recs.size(), threads, err);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
-    out->n = (int32_t)v.size();
-    out->has_n = hn ? 1 : 0;
-    out->names = static_cast<char**>(std::malloc(sizeof(char*) * std::max<size_t>(v.size(), 1)));
-    out->seqs = static_cast<char**>(std::malloc(sizeof(char*) * std::max<size_t>(v.size(), 1)));
-    out->lens = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * std::max<size_t>(v.size(), 1)));
-    for (size_t i = 0; i < v.size(); ++i) {
-        out->names[i] = strdup(v[i].name.c_str());
-        out->seqs[i] = static_cast<char*>(std::malloc(v[i].seq.size() + 1));
-        std::memcpy(out->seqs[i], v[i].seq.data(), v[i].seq.size());
-        out->seqs[i][v[i].seq.size()] = 0;
-        out->lens[i] = (int64_t)v[i].seq.size();
+    const size_t n = ff.recs.size();
+    out->n = (int32_t)n;
+    out->has_n = ff.has_n ? 1 : 0;
+    out->names = static_cast<char**>(std::malloc(sizeof(char*) * std::max<size_t>(n, 1)));
+    out->seqs = static_cast<char**>(std::malloc(sizeof(char*) * std::max<size_t>(n, 1)));
+    out->lens = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * std::max<size_t>(n, 1)));
+    for (size_t i = 0; i < n; ++i) {
+        const sd::FastaFile::Rec& r = ff.recs[i];
+        out->names[i] = static_cast<char*>(std::malloc(r.name_len + 1));
+        std::memcpy(out->names[i], r.name, r.name_len);
+        out->names[i][r.name_len] = 0;
+        out->seqs[i] = static_cast<char*>(std::malloc((size_t)r.len + 1));
+        std::memcpy(out->seqs[i], r.seq, (size_t)r.len);
+        out->seqs[i][r.len] = 0;
+        out->lens[i] = r.len;
     }
     return SD_OK;
 }

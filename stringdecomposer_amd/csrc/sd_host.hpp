@@ -17,6 +17,11 @@
 #include <utility>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "../../include/sd_hip.h"
 
 namespace sd {
@@ -27,51 +32,6 @@ struct Seq {
 };
 
 inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n'; }
-
-// load_fasta (main.cpp:314-346): record name = first whitespace token of the header, sequence
-// lines appended verbatim (no upper-casing, '\r' kept), alphabet {A,C,G,T,N} enforced afterwards.
-inline int load_fasta(const std::string& path, std::vector<Seq>& out, bool& has_n, std::string& err) {
-    out.clear();
-    has_n = false;
-    FILE* fp = std::fopen(path.c_str(), "rb");
-    if (!fp) { err = "cannot open " + path; return SD_ERR_IO; }
-    std::string data;
-    {
-        char buf[1 << 16];
-        size_t got;
-        while ((got = std::fread(buf, 1, sizeof buf, fp)) > 0) data.append(buf, got);
-    }
-    std::fclose(fp);
-    size_t pos = 0;
-    const size_t N = data.size();
-    while (pos < N) {
-        size_t eol = data.find('\n', pos);
-        if (eol == std::string::npos) eol = N;
-        const char* ln = data.data() + pos;
-        const size_t L = eol - pos;
-        if (L > 0 && ln[0] == '>') {
-            size_t a = 1;
-            while (a < L && is_ws(ln[a])) ++a;
-            size_t b = a;
-            while (b < L && !is_ws(ln[b])) ++b;
-            if (a == b) { err = "FASTA header without a name"; return SD_ERR_FORMAT; }
-            out.push_back(Seq{std::string(ln + a, b - a), std::string()});
-        } else if (L > 0) {
-            if (out.empty()) { err = "FASTA does not start with a header"; return SD_ERR_FORMAT; }
-            out.back().seq.append(ln, L);
-        }
-        pos = eol + 1;
-    }
-    for (const Seq& s : out) {
-        for (char c : s.seq) {
-            if (c == 'A' || c == 'C' || c == 'G' || c == 'T') continue;
-            if (c == 'N') { has_n = true; continue; }
-            err = "ERROR: Sequence " + s.name + " contains undefined symbol (not ACGT): " + c;
-            return SD_ERR_SYMBOL;
-        }
-    }
-    return SD_OK;
-}
 
 // alphabet check for in-memory sequences (same rule and message as load_fasta)
 inline int check_alphabet(const char* name, const char* s, int64_t n, std::string& err) {
@@ -313,5 +273,192 @@ inline bool pack_chunk(const char* s, int32_t l, uint32_t* out) {
     }
     return has_n;
 }
+
+// ---------------------------------------------------------------------------------------------
+// FastaFile: load_fasta (main.cpp:314-346) for files of any size.  The file is mapped, record starts
+// ('>' at the beginning of a line) are found by all host threads, and every record is then parsed on
+// its own: name = first whitespace token of the header, sequence = the following lines appended
+// verbatim.  A sequence that sits on ONE line is used where it lies in the mapping (no copy); a
+// multi-line sequence is concatenated into a buffer of its own.  The alphabet {A,C,G,T,N} is enforced
+// per record (validate()); the first offending record in file order is reported with the reference's
+// text.  For a job sharded over ranks only the records a rank's chunk range touches need validating.
+// ---------------------------------------------------------------------------------------------
+class FastaFile {
+  public:
+    struct Rec {
+        const char* name; size_t name_len;
+        const char* seq; int64_t len;     // into the mapping or into `owned`
+    };
+    std::vector<Rec> recs;
+    bool has_n = false;
+
+    FastaFile() = default;
+    FastaFile(const FastaFile&) = delete;
+    FastaFile& operator=(const FastaFile&) = delete;
+    ~FastaFile() { close_(); }
+
+    int open(const std::string& path, int threads, std::string& err) {
+        close_();
+        fd_ = ::open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) { err = "cannot open " + path; return SD_ERR_IO; }
+        struct stat sb;
+        if (fstat(fd_, &sb) != 0) { err = "cannot open " + path; return SD_ERR_IO; }
+        size_ = (size_t)sb.st_size;
+        if (size_ == 0) return SD_OK;
+        void* m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+        if (m == MAP_FAILED) {  // not mappable (a pipe, a special file): read it
+            map_ = nullptr;
+            fallback_.resize(size_);
+            size_t got = 0;
+            while (got < size_) {
+                const ssize_t r = ::pread(fd_, &fallback_[got], size_ - got, (off_t)got);
+                if (r <= 0) { err = "cannot read " + path; return SD_ERR_IO; }
+                got += (size_t)r;
+            }
+            data_ = fallback_.data();
+        } else {
+            map_ = m;
+            data_ = static_cast<const char*>(m);
+            (void)madvise(m, size_, MADV_SEQUENTIAL);
+        }
+        return index(threads, err);
+    }
+    // alphabet check of records [r0, r1) (main.cpp:329-344); sets has_n
+    int validate(size_t r0, size_t r1, int threads, std::string& err) {
+        r1 = std::min(r1, recs.size());
+        if (r0 >= r1) return SD_OK;
+        // pieces of <= 4 MB so that one long sequence is checked by all threads
+        struct Piece { size_t rec; int64_t off, len; };
+        std::vector<Piece> pieces;
+        for (size_t r = r0; r < r1; ++r)
+            for (int64_t o = 0; o < recs[r].len; o += (4 << 20))
+                pieces.push_back(Piece{r, o, std::min<int64_t>(4 << 20, recs[r].len - o)});
+        std::vector<int64_t> bad(pieces.size(), -1);
+        std::vector<uint8_t> hn(pieces.size(), 0);
+        parallel_for((int64_t)pieces.size(), threads, 1, [&](int64_t x) {
+            const Piece& pc = pieces[(size_t)x];
+            const char* q = recs[pc.rec].seq + pc.off;
+            uint8_t n = 0;
+            for (int64_t i = 0; i < pc.len; ++i) {
+                const char c = q[i];
+                if (c == 'A' || c == 'C' || c == 'G' || c == 'T') continue;
+                if (c == 'N') { n = 1; continue; }
+                bad[(size_t)x] = i;
+                break;
+            }
+            hn[(size_t)x] = n;
+        });
+        for (size_t x = 0; x < pieces.size(); ++x) {
+            if (bad[x] >= 0) {
+                const Rec& rc = recs[pieces[x].rec];
+                err = "ERROR: Sequence " + std::string(rc.name, rc.name_len) + " contains undefined symbol (not ACGT): " +
+                      rc.seq[pieces[x].off + bad[x]];
+                return SD_ERR_SYMBOL;
+            }
+            if (hn[x]) has_n = true;
+        }
+        return SD_OK;
+    }
+
+  private:
+    int fd_ = -1;
+    void* map_ = nullptr;
+    const char* data_ = nullptr;
+    size_t size_ = 0;
+    std::string fallback_;
+    std::vector<std::string> owned_;   // concatenated multi-line sequences
+
+    void close_() {
+        if (map_) munmap(map_, size_);
+        if (fd_ >= 0) ::close(fd_);
+        map_ = nullptr;
+        fd_ = -1;
+        data_ = nullptr;
+        size_ = 0;
+        recs.clear();
+        owned_.clear();
+        fallback_.clear();
+    }
+    int index(int threads, std::string& err) {
+        const char* d = data_;
+        const size_t N = size_;
+        // (1) record starts: '>' at offset 0 or right after a newline
+        const size_t slab = (size_t)8 << 20;
+        const int64_t n_slabs = (int64_t)((N + slab - 1) / slab);
+        std::vector<std::vector<size_t>> found((size_t)n_slabs);
+        parallel_for(n_slabs, threads, 1, [&](int64_t sl) {
+            const size_t b = (size_t)sl * slab, e = std::min(N, b + slab);
+            std::vector<size_t>& out = found[(size_t)sl];
+            const char* p = d + b;
+            const char* end = d + e;
+            while (p < end) {
+                p = static_cast<const char*>(std::memchr(p, '>', (size_t)(end - p)));
+                if (!p) break;
+                const size_t pos = (size_t)(p - d);
+                if (pos == 0 || d[pos - 1] == '\n') out.push_back(pos);
+                ++p;
+            }
+        });
+        std::vector<size_t> starts;
+        for (auto& v : found) starts.insert(starts.end(), v.begin(), v.end());
+        {
+            // anything before the first header must be blank lines (the reference would append it to a
+            // record that does not exist, main.cpp:327)
+            const size_t first = starts.empty() ? N : starts[0];
+            for (size_t i = 0; i < first; ++i)
+                if (d[i] != '\n') { err = "FASTA does not start with a header"; return SD_ERR_FORMAT; }
+        }
+        const size_t R = starts.size();
+        recs.assign(R, Rec{nullptr, 0, nullptr, 0});
+        owned_.assign(R, std::string());
+        std::vector<uint8_t> bad(R, 0);
+        // (2) every record on its own
+        parallel_for((int64_t)R, threads, 4, [&](int64_t r) {
+            const size_t b = starts[(size_t)r], e = (size_t)r + 1 < R ? starts[(size_t)r + 1] : N;
+            const char* nl = static_cast<const char*>(std::memchr(d + b, '\n', e - b));
+            const size_t hdr_end = nl ? (size_t)(nl - d) : e;
+            size_t a = b + 1;
+            while (a < hdr_end && is_ws(d[a])) ++a;
+            size_t z = a;
+            while (z < hdr_end && !is_ws(d[z])) ++z;
+            if (a == z) { bad[(size_t)r] = 1; return; }
+            Rec& rc = recs[(size_t)r];
+            rc.name = d + a;
+            rc.name_len = z - a;
+            size_t pos = hdr_end < e ? hdr_end + 1 : e;
+            // sequence lines: [pos, e)
+            // fast path: exactly one non-empty line
+            size_t lines = 0, total = 0, first_b = 0, first_l = 0;
+            for (size_t q = pos; q < e;) {
+                const char* n2 = static_cast<const char*>(std::memchr(d + q, '\n', e - q));
+                const size_t le = n2 ? (size_t)(n2 - d) : e;
+                if (le > q) {
+                    if (lines == 0) { first_b = q; first_l = le - q; }
+                    ++lines;
+                    total += le - q;
+                }
+                q = le + 1;
+            }
+            if (lines <= 1) {
+                rc.seq = d + first_b;
+                rc.len = (int64_t)first_l;
+            } else {
+                std::string& o = owned_[(size_t)r];
+                o.reserve(total);
+                for (size_t q = pos; q < e;) {
+                    const char* n2 = static_cast<const char*>(std::memchr(d + q, '\n', e - q));
+                    const size_t le = n2 ? (size_t)(n2 - d) : e;
+                    if (le > q) o.append(d + q, le - q);
+                    q = le + 1;
+                }
+                rc.seq = o.data();
+                rc.len = (int64_t)o.size();
+            }
+        });
+        for (size_t r = 0; r < R; ++r)
+            if (bad[r]) { err = "FASTA header without a name"; return SD_ERR_FORMAT; }
+        return SD_OK;
+    }
+};
 
 }  // namespace sd

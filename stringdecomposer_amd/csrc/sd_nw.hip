@@ -169,7 +169,12 @@ struct NwCtx {
     std::mutex m;
     int dev = -1;
     NwBuf seq, starts, lens, pair, peq, tlen, hist, dist, matches;
+    char* stage = nullptr;      // pinned staging of the text
+    size_t stage_cap = 0;
     void release() {
+        if (stage) (void)hipHostFree(stage);
+        stage = nullptr;
+        stage_cap = 0;
         for (NwBuf* b : {&seq, &starts, &lens, &pair, &peq, &tlen, &hist, &dist, &matches}) {
             if (b->p) (void)hipFree(b->p);
             b->p = nullptr;
@@ -196,12 +201,16 @@ extern "C" void sd_nw_release_cache(void) {
     if (g_nw.dev >= 0) { (void)hipSetDevice(g_nw.dev); g_nw.release(); }
 }
 
-extern "C" int sd_identity_segments_dev(const char* seq, int64_t seqlen, const int64_t* starts, const int64_t* ends,
-                                        int64_t n_seg, const char* const* tmpl, const int32_t* tlen, int32_t T,
-                                        const int32_t* pair_tmpl, int32_t homo, int32_t device, int32_t threads,
-                                        int32_t* dist, int32_t* matches, int32_t* columns) {
-    if (n_seg < 0 || T < 0 || !seq || (n_seg && (!starts || !ends)) || (T && (!tmpl || !tlen)) || !matches || !columns)
-        return SD_ERR_PARAM;
+namespace sd {
+// Core of the device identity: the text is the concatenation of `spans` (pointer, length); segment s is
+// text[seg_start[s] .. seg_start[s] + seg_len[s]).  Templates as given (the caller compresses them for the
+// homopolymer form).  Outputs per pair (all-vs-all: s * T + t; pair_tmpl: s).  SD_ERR_UNSUPPORTED for input
+// the kernel does not take; nothing is written then.
+int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans, const int64_t* seg_start,
+                       const int32_t* seg_len, int64_t n_seg, const std::vector<std::string>& tmpl,
+                       const int32_t* pair_tmpl, bool homo, int device, int threads, int32_t* dist,
+                       int32_t* matches) {
+    const int T = (int)tmpl.size();
     const int64_t n_pairs = pair_tmpl ? n_seg : n_seg * (int64_t)T;
     if (n_pairs == 0) return SD_OK;
     int ndev = 0;
@@ -211,11 +220,11 @@ extern "C" int sd_identity_segments_dev(const char* seq, int64_t seqlen, const i
     std::vector<std::string> ts((size_t)T);
     int tmax = 1;
     for (int t = 0; t < T; ++t) {
-        if (tlen[t] < 0) return SD_ERR_PARAM;
+        const std::string& in = tmpl[(size_t)t];
         std::string& o = ts[(size_t)t];
-        for (int32_t i = 0; i < tlen[t]; ++i) {
-            if (nw_code(tmpl[t][i]) < 0) return SD_ERR_UNSUPPORTED;   // outside ACGTN: the host path handles it
-            if (!homo || i == 0 || tmpl[t][i] != tmpl[t][i - 1]) o.push_back(tmpl[t][i]);
+        for (size_t i = 0; i < in.size(); ++i) {
+            if (nw_code(in[i]) < 0) return SD_ERR_UNSUPPORTED;   // outside ACGTN: the host path handles it
+            if (!homo || i == 0 || in[i] != in[i - 1]) o.push_back(in[i]);
         }
         tmax = std::max(tmax, (int)o.size());
     }
@@ -230,38 +239,55 @@ extern "C" int sd_identity_segments_dev(const char* seq, int64_t seqlen, const i
         for (size_t k = 0; k < ts[(size_t)t].size(); ++k)
             peq[((size_t)t * 5 + (size_t)nw_code(ts[(size_t)t][k])) * K + (k >> 6)] |= 1ull << (k & 63);
     }
-    // segments: lengths, the text range they span, alphabet
-    std::vector<int64_t> st((size_t)n_seg);
-    std::vector<int32_t> ln((size_t)n_seg);
-    int64_t lo = seqlen, hi = 0;
+    int64_t text = 0;
+    std::vector<int64_t> span_off(spans.size() + 1, 0);
+    for (size_t i = 0; i < spans.size(); ++i) { span_off[i] = text; text += spans[i].second; }
+    span_off[spans.size()] = text;
     int qmax = 1;
     for (int64_t s = 0; s < n_seg; ++s) {
-        if (starts[s] < 0 || ends[s] >= seqlen) return SD_ERR_PARAM;
-        const int64_t l = std::max<int64_t>(0, ends[s] - starts[s] + 1);
-        if (l > 65000) return SD_ERR_UNSUPPORTED;
-        ln[(size_t)s] = (int32_t)l;
-        if (l > 0) { lo = std::min(lo, starts[s]); hi = std::max(hi, ends[s] + 1); }
-        qmax = std::max(qmax, (int)l);
+        if (seg_len[s] < 0 || seg_start[s] < 0 || seg_start[s] + seg_len[s] > text) return SD_ERR_PARAM;
+        if (seg_len[s] > 65000) return SD_ERR_UNSUPPORTED;
+        qmax = std::max(qmax, (int)seg_len[s]);
     }
     if (pair_tmpl)
         for (int64_t s = 0; s < n_seg; ++s)
             if (pair_tmpl[s] < 0 || pair_tmpl[s] >= T) return SD_ERR_PARAM;
-    if (hi < lo) { lo = 0; hi = 0; }
-    {
-        std::vector<uint8_t> bad((size_t)n_seg, 0);
-        sd::parallel_for(n_seg, threads, 256, [&](int64_t s) {
-            const char* q = seq + starts[s];
-            for (int32_t i = 0; i < ln[(size_t)s]; ++i)
-                if (nw_code(q[i]) < 0) { bad[(size_t)s] = 1; break; }
-        });
-        for (uint8_t b : bad)
-            if (b) return SD_ERR_UNSUPPORTED;
-    }
-    for (int64_t s = 0; s < n_seg; ++s) st[(size_t)s] = starts[s] - lo;
 
     std::lock_guard<std::mutex> g(g_nw.m);
     if (hipSetDevice(device) != hipSuccess) return SD_ERR_HIP;
     if (g_nw.dev != device) { if (g_nw.dev >= 0) g_nw.release(); g_nw.dev = device; }
+    // text -> pinned staging (alphabet checked on the way) -> device
+    if ((size_t)text + 8 > g_nw.stage_cap) {
+        if (g_nw.stage) (void)hipHostFree(g_nw.stage);
+        g_nw.stage = nullptr;
+        g_nw.stage_cap = 0;
+        const size_t want = (size_t)text + (size_t)text / 4 + 4096;
+        if (hipHostMalloc(reinterpret_cast<void**>(&g_nw.stage), want, hipHostMallocDefault) != hipSuccess) return SD_ERR_HIP;
+        g_nw.stage_cap = want;
+    }
+    {
+        // pieces of <= 1 MB so that one long sequence is copied by all threads as well
+        struct Piece { size_t span; int64_t off, len; };
+        std::vector<Piece> pieces;
+        for (size_t i = 0; i < spans.size(); ++i)
+            for (int64_t o = 0; o < spans[i].second; o += (1 << 20))
+                pieces.push_back(Piece{i, o, std::min<int64_t>(1 << 20, spans[i].second - o)});
+        std::vector<uint8_t> bad(pieces.size(), 0);
+        sd::parallel_for((int64_t)pieces.size(), threads, 1, [&](int64_t x) {
+            const Piece& pc = pieces[(size_t)x];
+            const char* src = spans[pc.span].first + pc.off;
+            char* dst = g_nw.stage + span_off[pc.span] + pc.off;
+            uint8_t b = 0;
+            for (int64_t i = 0; i < pc.len; ++i) {
+                const char ch = src[i];
+                b |= (uint8_t)!(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'N');
+                dst[i] = ch;
+            }
+            bad[(size_t)x] = b;
+        });
+        for (uint8_t b : bad)
+            if (b) return SD_ERR_UNSUPPORTED;
+    }
     // resident lanes: up to 32 waves per CU, within a history budget of 8 GB (and a third of the free HBM)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SD_ERR_HIP;
@@ -274,16 +300,15 @@ extern "C" int sd_identity_segments_dev(const char* seq, int64_t seqlen, const i
     lanes = std::min<int64_t>(lanes, (int64_t)(budget / per_lane) / 256 * 256);
     if (lanes < 256) lanes = 256;
     const int grid = (int)(lanes / 256);
-    const size_t text = (size_t)(hi - lo);
-    bool ok = g_nw.seq.need(text + 8) && g_nw.starts.need(sizeof(int64_t) * (size_t)n_seg) &&
+    bool ok = g_nw.seq.need((size_t)text + 8) && g_nw.starts.need(sizeof(int64_t) * (size_t)n_seg) &&
               g_nw.lens.need(sizeof(int32_t) * (size_t)n_seg) && g_nw.peq.need(sizeof(unsigned long long) * peq.size()) &&
               g_nw.tlen.need(sizeof(int32_t) * (size_t)std::max(T, 1)) && g_nw.hist.need((size_t)lanes * per_lane) &&
               g_nw.dist.need(sizeof(int32_t) * (size_t)n_pairs) && g_nw.matches.need(sizeof(int32_t) * (size_t)n_pairs) &&
               (!pair_tmpl || g_nw.pair.need(sizeof(int32_t) * (size_t)n_seg));
     if (!ok) return SD_ERR_HIP;
     auto up = [](void* d, const void* h, size_t n) { return n == 0 || hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; };
-    ok = up(g_nw.seq.p, seq + lo, text) && up(g_nw.starts.p, st.data(), sizeof(int64_t) * (size_t)n_seg) &&
-         up(g_nw.lens.p, ln.data(), sizeof(int32_t) * (size_t)n_seg) &&
+    ok = up(g_nw.seq.p, g_nw.stage, (size_t)text) && up(g_nw.starts.p, seg_start, sizeof(int64_t) * (size_t)n_seg) &&
+         up(g_nw.lens.p, seg_len, sizeof(int32_t) * (size_t)n_seg) &&
          up(g_nw.peq.p, peq.data(), sizeof(unsigned long long) * peq.size()) &&
          up(g_nw.tlen.p, tl.data(), sizeof(int32_t) * (size_t)T) &&
          (!pair_tmpl || up(g_nw.pair.p, pair_tmpl, sizeof(int32_t) * (size_t)n_seg));
@@ -295,12 +320,45 @@ extern "C" int sd_identity_segments_dev(const char* seq, int64_t seqlen, const i
                         homo ? 1 : 0, qmax, g_nw.hist.p, static_cast<int32_t*>(g_nw.dist.p),
                         static_cast<int32_t*>(g_nw.matches.p));
     if (hipGetLastError() != hipSuccess) return SD_ERR_HIP;
+    if (hipMemcpy(dist, g_nw.dist.p, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(matches, g_nw.matches.p, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost) != hipSuccess)
+        return SD_ERR_HIP;
+    return SD_OK;
+}
+}  // namespace sd
+
+extern "C" int sd_identity_segments_dev(const char* seq, int64_t seqlen, const int64_t* starts, const int64_t* ends,
+                                        int64_t n_seg, const char* const* tmpl, const int32_t* tlen, int32_t T,
+                                        const int32_t* pair_tmpl, int32_t homo, int32_t device, int32_t threads,
+                                        int32_t* dist, int32_t* matches, int32_t* columns) {
+    if (n_seg < 0 || T < 0 || !seq || (n_seg && (!starts || !ends)) || (T && (!tmpl || !tlen)) || !matches || !columns)
+        return SD_ERR_PARAM;
+    const int64_t n_pairs = pair_tmpl ? n_seg : n_seg * (int64_t)T;
+    if (n_pairs == 0) return SD_OK;
+    std::vector<std::string> ts((size_t)T);
+    for (int t = 0; t < T; ++t) {
+        if (tlen[t] < 0) return SD_ERR_PARAM;
+        ts[(size_t)t].assign(tmpl[t], (size_t)tlen[t]);
+    }
+    // only the text the segments span travels to the device
+    std::vector<int64_t> st((size_t)n_seg);
+    std::vector<int32_t> ln((size_t)n_seg);
+    int64_t lo = seqlen, hi = 0;
+    for (int64_t s = 0; s < n_seg; ++s) {
+        if (starts[s] < 0 || ends[s] >= seqlen) return SD_ERR_PARAM;
+        const int64_t l = std::max<int64_t>(0, ends[s] - starts[s] + 1);
+        if (l > 65000) return SD_ERR_UNSUPPORTED;
+        ln[(size_t)s] = (int32_t)l;
+        if (l > 0) { lo = std::min(lo, starts[s]); hi = std::max(hi, ends[s] + 1); }
+    }
+    if (hi < lo) { lo = 0; hi = 0; }
+    for (int64_t s = 0; s < n_seg; ++s) st[(size_t)s] = ln[(size_t)s] > 0 ? starts[s] - lo : 0;
     std::vector<int32_t> dtmp;
     int32_t* dh = dist;
     if (!dh) { dtmp.resize((size_t)n_pairs); dh = dtmp.data(); }
-    if (hipMemcpy(dh, g_nw.dist.p, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(matches, g_nw.matches.p, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost) != hipSuccess)
-        return SD_ERR_HIP;
+    std::vector<std::pair<const char*, int64_t>> spans(1, std::make_pair(seq + lo, hi - lo));
+    const int rc = sd::nw_identity_device(spans, st.data(), ln.data(), n_seg, ts, pair_tmpl, homo != 0, device, threads, dh, matches);
+    if (rc) return rc;
     sd::parallel_for((n_pairs + 65535) / 65536, threads, 1, [&](int64_t blk) {
         const int64_t e = std::min<int64_t>(n_pairs, (blk + 1) * 65536);
         for (int64_t p = blk * 65536; p < e; ++p) columns[p] = dh[p] < 0 ? 0 : dh[p] + matches[p];

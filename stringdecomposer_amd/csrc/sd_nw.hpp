@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
 
 namespace sd {
 
@@ -13,5 +16,12 @@ void launch_nw_pairs(int K, hipStream_t st, int grid, const uint8_t* seq, const 
                      const int32_t* seg_len, int64_t n_seg, int T, const int32_t* pair_tmpl,
                      const unsigned long long* peq, const int32_t* tlen, int homo, int qmax, void* hist,
                      int32_t* dist, int32_t* matches);
+
+// Host driver (sd_nw.hip): identity of segments of a text (the concatenation of `spans`) against templates on
+// the device; see the definition.
+int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans, const int64_t* seg_start,
+                       const int32_t* seg_len, int64_t n_seg, const std::vector<std::string>& tmpl,
+                       const int32_t* pair_tmpl, bool homo, int device, int threads, int32_t* dist,
+                       int32_t* matches);
 
 }  // namespace sd

@@ -33,6 +33,7 @@ EXPORTS = [
     "sd_decompose_chunk_range", "sd_assemble_tsv", "sd_release_cache", "sd_format_alt_rows",
     "sd_stream_create", "sd_stream_destroy", "sd_stream_submit", "sd_stream_collect", "sd_stream_stats",
     "sd_stream_info", "sd_pack_bases", "sd_identity_segments_dev", "sd_nw_release_cache",
+    "sd_run_files", "sd_convert_raw_tsv", "sd_decompose_files_range", "sd_assemble_files_tsv",
 ]
 
 
@@ -109,6 +110,15 @@ def load():
     L.sd_identity_segments_dev.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                            P(C.c_char_p), P(C.c_int32), C.c_int32, C.c_void_p, C.c_int32,
                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sd_run_files.argtypes = [C.c_char_p, C.c_char_p, P(Params), C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32,
+                               C.c_int32, P(C.c_double), C.c_char_p, C.c_size_t]
+    L.sd_convert_raw_tsv.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32,
+                                     P(C.c_double), C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]
+    L.sd_decompose_files_range.argtypes = [C.c_char_p, C.c_char_p, P(Params), C.c_int32, C.c_int32, P(P(Rec)),
+                                           P(P(C.c_int64)), P(C.c_int64), P(C.c_int64), P(C.c_int64), C.c_char_p,
+                                           C.c_size_t]
+    L.sd_assemble_files_tsv.argtypes = [C.c_char_p, C.c_char_p, P(Params), C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_char_p, C.c_char_p, C.c_size_t]
     L.sd_format_alt_rows.argtypes = [P(C.c_char_p), C.c_int32, C.c_void_p, P(C.c_char_p), C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, P(C.c_void_p),
                                      P(C.c_size_t)]
@@ -172,6 +182,33 @@ def decompose_files(reads_fa, monomers_fa, raw_tsv_out, **kw):
     err = C.create_string_buffer(4096)
     rc = L.sd_decompose_files(os.fsencode(reads_fa), os.fsencode(monomers_fa), C.byref(p),
                               os.fsencode(raw_tsv_out), err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+
+
+def run_files(reads_fa, monomers_fa, raw_tsv_out, final_tsv_out, alt_tsv_out, min_identity=0, second_best=False,
+              lr_coef=(-31.48494996, 0.41784018, 0.69186882), **kw):
+    """The whole CLI job natively (sd_run_files): raw, final and _alt TSV files from the two FASTA files."""
+    L = load()
+    p = make_params(**kw)
+    err = C.create_string_buffer(4096)
+    coef = (C.c_double * 3)(*[float(x) for x in lr_coef])
+    rc = L.sd_run_files(os.fsencode(reads_fa), os.fsencode(monomers_fa), C.byref(p), os.fsencode(raw_tsv_out),
+                        os.fsencode(final_tsv_out), os.fsencode(alt_tsv_out), int(min_identity), 1 if second_best else 0,
+                        coef, err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+
+
+def convert_raw_tsv(raw_tsv, reads_fa, monomers_fa, final_tsv_out, alt_tsv_out, min_identity=0, second_best=False,
+                    lr_coef=(-31.48494996, 0.41784018, 0.69186882), device=-1, threads=1):
+    """convert_tsv (main.py:168-184) natively; device=-1: host identities, else the HIP kernel."""
+    L = load()
+    err = C.create_string_buffer(4096)
+    coef = (C.c_double * 3)(*[float(x) for x in lr_coef])
+    rc = L.sd_convert_raw_tsv(os.fsencode(raw_tsv), os.fsencode(reads_fa), os.fsencode(monomers_fa),
+                              os.fsencode(final_tsv_out), os.fsencode(alt_tsv_out), int(min_identity),
+                              1 if second_best else 0, coef, int(device), int(threads), err, 4096)
     if rc != SD_OK:
         raise SdError(rc, err.value.decode(errors="replace"))
 
@@ -535,6 +572,44 @@ def decompose_chunk_range(read_seqs, mono_seqs, chunk_lo, chunk_hi, **kw):
     L.sd_free(recs)
     L.sd_free(off)
     return r, o
+
+
+def decompose_files_range(reads_fa, monomers_fa, rank, world, **kw):
+    """A rank's share of a sharded job straight from the FASTA files (mapped, not copied):
+    (recs, rec_off, chunk_lo, chunk_hi, n_chunks_total)."""
+    import numpy as np
+    L = load()
+    p = make_params(**kw)
+    recs = C.POINTER(Rec)()
+    off = C.POINTER(C.c_int64)()
+    lo, hi, tot = C.c_int64(), C.c_int64(), C.c_int64()
+    err = C.create_string_buffer(4096)
+    rc = L.sd_decompose_files_range(os.fsencode(reads_fa), os.fsencode(monomers_fa), C.byref(p), rank, world,
+                                    C.byref(recs), C.byref(off), C.byref(lo), C.byref(hi), C.byref(tot), err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+    n = hi.value - lo.value
+    o = np.ctypeslib.as_array(off, shape=(n + 1,)).copy()
+    nrec = int(o[n])
+    r = (np.frombuffer(C.string_at(recs, nrec * C.sizeof(Rec)), dtype=_rec_dtype()).copy() if nrec
+         else np.zeros(0, dtype=_rec_dtype()))
+    L.sd_free(recs)
+    L.sd_free(off)
+    return r, o, lo.value, hi.value, tot.value
+
+
+def assemble_files_tsv(reads_fa, monomers_fa, recs, rec_off, raw_tsv_out, **kw):
+    """Rank 0: gathered records of all chunks -> raw TSV file (names / lengths from the FASTA index)."""
+    import numpy as np
+    L = load()
+    p = make_params(**kw)
+    r = np.ascontiguousarray(recs, dtype=_rec_dtype())
+    o = np.ascontiguousarray(rec_off, dtype=np.int64)
+    err = C.create_string_buffer(4096)
+    rc = L.sd_assemble_files_tsv(os.fsencode(reads_fa), os.fsencode(monomers_fa), C.byref(p), r.ctypes.data,
+                                 o.ctypes.data, len(o) - 1, os.fsencode(raw_tsv_out), err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
 
 
 def assemble_tsv(read_names, read_lens, mono_names, recs, rec_off, **kw):

@@ -11,6 +11,11 @@ Documented difference: the reference CLI silently ignores -s/--scoring (it alway
 binary with 10 arguments, and main.cpp:381 parses scores only when argc == 10, i.e. 9 arguments).
 Here -s is honoured (the documented intent, README / main.py:210); pass --ref-compat to reproduce
 the reference CLI's effective behaviour (default scores whatever -s says).
+
+The command line runs natively end to end (lib.run_files -> sd_run_files): FASTA ingest, DP, raw TSV,
+identities (device kernel) and the final / _alt TSVs are produced batch by batch inside the library.
+convert_read / print_read / convert_tsv below are the same post-processing written on numpy arrays:
+the module-level API of the reference, kept importable and used by the tests as a second implementation.
 """
 import argparse
 import logging
@@ -337,8 +342,12 @@ def convert_tsv(decomposition, reads, monomers, outfile, identity_th, light, thr
 
 
 def run(sequences, monomers, num_threads, scoring, batch_size, raw_file, ed_thr, overlap, logger,
-        ref_compat=False, device=0, kernel=0):
-    """main.py:186-197 with the subprocess replaced by libsd_hip.so."""
+        ref_compat=False, device=0, kernel=0, final_file=None, min_identity=0, second_best=False):
+    """main.py:186-197 with the subprocess replaced by libsd_hip.so.
+
+    Single process with final_file given: ONE native call (sd_run_files) streams the job through the
+    device and writes the raw, final and _alt TSVs batch by batch -- nothing is re-read, returns True.
+    Otherwise (a multi-GPU launch, or no final_file): writes the raw TSV and returns its text (rank 0)."""
     ins, dels, mm, match = [int(x) for x in scoring.split(",")]
     if ref_compat:
         ins, dels, mm, match = -1, -1, -1, 1  # what the reference binary does with 10 argv (main.cpp:381)
@@ -355,19 +364,21 @@ def run(sequences, monomers, num_threads, scoring, batch_size, raw_file, ed_thr,
         # one process per GPU, each takes a contiguous range of the global chunk table (shard.py);
         # the records meet on rank 0 through a host-side (gloo) gather -- no device collective.
         dist = shard.init_process_group("gloo")
-        names, seqs, _ = lib.fasta_load(sequences)
-        mnames, mseqs, _ = lib.fasta_load(monomers)
-        raw = shard.decompose_sharded(names, seqs, mnames, mseqs, dist=dist, scoring=(ins, dels, mm, match),
-                                      part_size=int(batch_size), overlap=int(overlap), ed_thr=int(ed_thr),
-                                      threads=int(num_threads), kernel=kernel,
-                                      device=local_rank % max(lib.device_count(), 1))
-        shard.barrier(dist)
-        dist.destroy_process_group()
-        if rank != 0:
-            return None
-        with open(raw_file, "wb") as f:
-            f.write(raw)
-        return raw.decode()
+        try:
+            ok = shard.decompose_files_sharded(sequences, monomers, raw_file, dist, scoring=(ins, dels, mm, match),
+                                               part_size=int(batch_size), overlap=int(overlap), ed_thr=int(ed_thr),
+                                               threads=int(num_threads), kernel=kernel,
+                                               device=local_rank % max(lib.device_count(), 1))
+        finally:
+            shard.barrier(dist)
+            dist.destroy_process_group()
+        return "raw file written" if ok else None
+    if final_file is not None:
+        lib.run_files(sequences, monomers, raw_file, final_file, final_file[:-len(".tsv")] + "_alt.tsv",
+                      min_identity=min_identity, second_best=second_best, lr_coef=_lr_coef(),
+                      scoring=(ins, dels, mm, match), part_size=int(batch_size), overlap=int(overlap),
+                      ed_thr=int(ed_thr), threads=int(num_threads), device=device, kernel=kernel)
+        return True
     lib.decompose_files(sequences, monomers, raw_file, scoring=(ins, dels, mm, match),
                         part_size=int(batch_size), overlap=int(overlap), ed_thr=int(ed_thr),
                         threads=int(num_threads), device=device, kernel=kernel)
@@ -418,11 +429,14 @@ def main(argv=None):
     logger.info(f"cmd: {sys.argv}")
 
     raw_decomp_fn = os.path.join(args.out_dir, args.out_file + "_raw.tsv")
+    convert_tsv_fn = os.path.join(args.out_dir, args.out_file + ".tsv")
     kernel = {"auto": 0, "generic": 1, "fast": 2}[args.kernel]
     try:
         raw_decomposition = run(args.sequences, args.monomers, args.threads, args.scoring, args.batch_size,
                                 raw_decomp_fn, args.ed_thr, args.overlap, logger,
-                                ref_compat=args.ref_compat, device=args.device, kernel=kernel)
+                                ref_compat=args.ref_compat, device=args.device, kernel=kernel,
+                                final_file=convert_tsv_fn, min_identity=int(args.min_identity),
+                                second_best=args.second_best)
     except lib.SdError as e:
         # the reference dies with CalledProcessError after the binary printed its message on stderr
         sys.stderr.write(e.msg + "\n")
@@ -431,22 +445,19 @@ def main(argv=None):
     if raw_decomposition is None:
         return  # not rank 0
     logger.info("Saved raw decomposition to " + raw_decomp_fn)
-
-    reads = load_fasta(args.sequences, "map")
-    monomers = load_fasta(args.monomers)
-    monomers = add_rc_monomers(monomers)
     logger.info("Transforming raw alignments...")
-
-    convert_tsv_fn = os.path.join(args.out_dir, args.out_file + ".tsv")
-    try:
-        convert_tsv(raw_decomposition, reads, monomers, convert_tsv_fn, int(args.min_identity),
-                    not args.second_best, threads=max(1, int(args.threads)))
-    except lib.SdError as e:
-        # e.g. a block longer than the identity kernel accepts (-b >= 65000 with a degenerate scoring):
-        # the raw decomposition is already on disk; end with a message, not a traceback
-        sys.stderr.write("post-processing failed: " + e.msg + "\n")
-        logger.info("Transformation failed (%s); the raw decomposition is in %s" % (e.msg, raw_decomp_fn))
-        sys.exit(e.code if 0 < e.code < 256 else 1)
+    if raw_decomposition is not True:
+        # multi-GPU launch: rank 0 holds the raw TSV of the whole job; convert_tsv (main.py:168-184) natively,
+        # identities on this rank's GPU
+        try:
+            lib.convert_raw_tsv(raw_decomp_fn, args.sequences, args.monomers, convert_tsv_fn,
+                                convert_tsv_fn[:-len(".tsv")] + "_alt.tsv", int(args.min_identity), args.second_best,
+                                _lr_coef(), device=shard.world()[1] % max(lib.device_count(), 1),
+                                threads=max(1, int(args.threads)))
+        except lib.SdError as e:
+            sys.stderr.write("post-processing failed: " + e.msg + "\n")
+            logger.info("Transformation failed (%s); the raw decomposition is in %s" % (e.msg, raw_decomp_fn))
+            sys.exit(e.code if 0 < e.code < 256 else 1)
     logger.info("Transformation finished. Results can be found in " + convert_tsv_fn)
 
     logger.info("Thank you for using StringDecomposer!")

@@ -144,3 +144,42 @@ def decompose_sharded(read_names, read_seqs, mono_names, mono_seqs, dist=None, r
     assert len(all_off) == n_chunks + 1
     keep = {k: v for k, v in params.items() if k in ("scoring", "part_size", "overlap", "threads")}
     return lib.assemble_tsv(read_names, read_lens, mono_names, all_recs, all_off, **keep)
+
+
+def decompose_files_sharded(reads_fa, monomers_fa, raw_tsv_out, dist, range_fn=None, **params):
+    """The multi-process command line: every rank maps the FASTA files itself (sequences never enter Python),
+    runs its contiguous share of the global chunk table on its GPU and sends the compact records to rank 0,
+    which writes the raw TSV file.  Returns True on rank 0, None elsewhere.  A failure on any rank (an
+    undefined symbol in its share, a device error) is raised on EVERY rank: the lowest failing rank's, i.e.
+    the first offending read in file order, as the reference would report it."""
+    import numpy as np
+    from . import lib
+    rank, local_rank, ws = world()
+    params = dict(params, device=params.get("device", local_rank))
+    fn = range_fn or lib.decompose_files_range
+    failure, res = None, None
+    try:
+        res = fn(reads_fa, monomers_fa, rank, ws, **params)
+    except lib.SdError as e:
+        failure = (e.code, e.msg)
+    status = [None] * ws
+    dist.all_gather_object(status, failure)
+    failure = next((s for s in status if s is not None), None)
+    if failure is not None:
+        raise lib.SdError(*failure)
+    recs, off, lo, hi, n_chunks = res
+    box = [None] * ws if rank == 0 else None
+    dist.gather_object((lo, recs, off), box, dst=0)
+    if rank != 0:
+        return None
+    parts = sorted(box, key=lambda t: t[0])
+    all_recs = np.concatenate([p[1] for p in parts])
+    offs, base = [np.zeros(1, dtype=np.int64)], 0
+    for _, r, o in parts:
+        offs.append(o[1:] + base)
+        base += len(r)
+    all_off = np.concatenate(offs)
+    assert len(all_off) == n_chunks + 1
+    keep = {k: v for k, v in params.items() if k in ("scoring", "part_size", "overlap", "threads")}
+    lib.assemble_files_tsv(reads_fa, monomers_fa, all_recs, all_off, raw_tsv_out, **keep)
+    return True

@@ -309,3 +309,88 @@ def test_host_pool_parallel_loops_are_exact():
 
     with ThreadPoolExecutor(4) as ex:
         assert all(x == exp for x in ex.map(one, range(40)))
+
+
+def test_native_convert_raw_tsv_reproduces_reference_golden(tmp_path):
+    """sd_convert_raw_tsv = convert_tsv (main.py:168-184) as one native call (host identities here): the
+    reference's golden final TSV, the _alt file of the Python implementation, the light-mode sha of the
+    unmodified reference CLI, -i filtering, and a monomer file with a repeated name."""
+    c = load_case("td_default")
+    td = os.path.join(GOLDEN, "test_data")
+    rfa, mfa = os.path.join(td, "read.fa"), os.path.join(td, "DXZ1_star_monomers.fa")
+    raw = str(tmp_path / "raw.tsv")
+    with open(raw, "wb") as f:
+        f.write(c["raw"])
+    fin, alt = str(tmp_path / "n.tsv"), str(tmp_path / "n_alt.tsv")
+    lib.convert_raw_tsv(raw, rfa, mfa, fin, alt, 0, True, device=-1, threads=4)
+    with open(fin, "rb") as f, open(os.path.join(td, "final_decomposition_fc89af8.tsv"), "rb") as g:
+        assert f.read() == g.read()
+    reads = sdmain.load_fasta(rfa, "map")
+    mons = sdmain.add_rc_monomers(sdmain.load_fasta(mfa))
+    pout = str(tmp_path / "p.tsv")
+    sdmain.convert_tsv(c["raw"].decode(), reads, mons, pout, 0, False, threads=4)
+    with open(alt, "rb") as f, open(pout[:-4] + "_alt.tsv", "rb") as g:
+        assert f.read() == g.read()
+    lib.convert_raw_tsv(raw, rfa, mfa, fin, alt, 0, False, device=-1, threads=3)
+    with open(fin, "rb") as f:
+        assert hashlib.sha256(f.read()).hexdigest() == "de9d4cc554051d842022f0a75db18a7d4ce7b3aa97af9cadc6ef960c7ea8ee85"
+    assert os.path.getsize(alt) == 0
+    for th in (85, 95):
+        lib.convert_raw_tsv(raw, rfa, mfa, fin, alt, th, True, device=-1, threads=2)
+        sdmain.convert_tsv(c["raw"].decode(), reads, mons, pout, th, False, threads=2)
+        for a, b in ((fin, pout), (alt, pout[:-4] + "_alt.tsv")):
+            with open(a, "rb") as f, open(b, "rb") as g:
+                assert f.read() == g.read()
+    # repeated monomer name + several reads + a read that comes back later in the raw file
+    st = synth.Stream(6, 66)
+    base = synth._ACGT[st.below(80, 4)].tobytes()
+    mseqs = [base, base[:40] + synth._ACGT[st.below(40, 4)].tobytes(), base[::-1], base[5:] + b"ACGTA"]
+    mfa2, rfa2 = str(tmp_path / "m2.fa"), str(tmp_path / "r2.fa")
+    synth.write_fasta(mfa2, ["a", "b", "a", "c"], mseqs)
+    rseqs = [base * 3 + mseqs[1] * 2, mseqs[2] * 4, mseqs[3] + base]
+    synth.write_fasta(rfa2, ["r0", "r1", "r2"], rseqs, width=50)
+    lines = []
+    for rn, n, mn in (("r0", 5, ["a", "a", "b'", "b", "c"]), ("r1", 4, ["a'", "a", "c'", "b"]), ("r0", 2, ["c", "a"]),
+                      ("r2", 2, ["c", "a"])):
+        for i in range(n):
+            lines.append("%s\t%s\t%d\t%d\t10.000000\t0\t79\n" % (rn, mn[i], 80 * i, 80 * i + 79))
+    raw2 = str(tmp_path / "raw2.tsv")
+    with open(raw2, "w") as f:
+        f.write("".join(lines))
+    for sb in (True, False):
+        lib.convert_raw_tsv(raw2, rfa2, mfa2, fin, alt, 0, sb, device=-1, threads=2)
+        sdmain.convert_tsv("".join(lines), sdmain.load_fasta(rfa2, "map"), sdmain.add_rc_monomers(sdmain.load_fasta(mfa2)),
+                           pout, 0, not sb, threads=2)
+        for a, b in ((fin, pout), (alt, pout[:-4] + "_alt.tsv")):
+            with open(a, "rb") as f, open(b, "rb") as g:
+                assert f.read() == g.read(), (sb, a)
+    with pytest.raises(lib.SdError):
+        lib.convert_raw_tsv(raw2, rfa, mfa2, fin, alt, 0, True, device=-1)     # reads of the raw file missing
+
+
+def test_fasta_file_mapped_loader_semantics(tmp_path):
+    """sd::FastaFile (mmap + parallel index) behind sd_fasta_load: same records as the line-by-line loader
+    semantics of main.cpp:314-346 for single-line, multi-line, blank-line and header-description input."""
+    p = tmp_path / "a.fa"
+    p.write_bytes(b"\n>r1 some description\nACGT\n\nNNAC\n>r2\tx\nGG\n>r3\nA\n>r4\nACGTACGT")
+    names, seqs, has_n = lib.fasta_load(str(p))
+    assert names == ["r1", "r2", "r3", "r4"] and seqs == [b"ACGTNNAC", b"GG", b"A", b"ACGTACGT"] and has_n
+    big = tmp_path / "big.fa"
+    mn, ms = synth.make_monomers(12, seed=2)
+    rn, rs = synth.make_reads(ms, 40, read_len=30000, seed=2)
+    synth.write_fasta(str(big), rn, rs, width=0)
+    n2, s2, hn = lib.fasta_load(str(big))
+    assert n2 == rn and s2 == rs and not hn
+    synth.write_fasta(str(big), rn, rs, width=61)
+    n2, s2, hn = lib.fasta_load(str(big))
+    assert n2 == rn and s2 == rs
+    bad = tmp_path / "bad.fa"
+    bad.write_bytes(b">x\nACGT\n>y\nACGu\nAC\n>z\nAXC\n")
+    with pytest.raises(lib.SdError) as e:
+        lib.fasta_load(str(bad))
+    assert e.value.code == lib.SD_ERR_SYMBOL and e.value.msg == "ERROR: Sequence y contains undefined symbol (not ACGT): u"
+    for content in (b"ACGT\n>x\nAC\n", b">\nACGT\n"):
+        bad.write_bytes(content)
+        with pytest.raises(lib.SdError) as e:
+            lib.fasta_load(str(bad))
+        assert e.value.code == lib.SD_ERR_FORMAT

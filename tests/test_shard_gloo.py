@@ -131,3 +131,72 @@ def test_one_job_sharded_by_chunk_range_world_size_2():
     one = shard.decompose_sharded(names, seqs, mn, ms, range_fn=_checker_range_fn,
                                   scoring=(-1, -2, -1, 1), part_size=500, overlap=100)
     assert one == exp
+
+
+# ---- the file form used by the multi-process command line --------------------------------------------
+def _checker_files_range_fn(reads_fa, monomers_fa, rank, ws, scoring=(-1, -1, -1, 1), part_size=5000, overlap=500, **_):
+    """lib.decompose_files_range with the CPU oracle standing in for the device (test infrastructure); a read
+    named 'bad...' makes the rank that owns one of its chunks fail like the alphabet check would."""
+    from stringdecomposer_amd import lib
+    names, seqs, _ = lib.fasta_load(reads_fa)
+    mnames, mseqs, _ = lib.fasta_load(monomers_fa)
+    n = lib.chunk_table_size([len(s) for s in seqs], part_size, overlap)
+    lo, hi = shard.block_range(n, rank, ws)
+    table = []
+    for nm, s in zip(names, seqs):
+        table += [nm] * len(lib.chunk_plan(len(s), part_size, overlap))
+    for nm in table[lo:hi]:
+        if nm.startswith("bad"):
+            raise lib.SdError(lib.SD_ERR_SYMBOL, "ERROR: Sequence %s contains undefined symbol (not ACGT): x" % nm)
+    recs, off = _checker_range_fn(seqs, mseqs, lo, hi, scoring=scoring, part_size=part_size, overlap=overlap)
+    return recs, off, lo, hi, n
+
+
+def _files_worker(rank, ws, port, q, d, bad):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ws),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from stringdecomposer_amd import lib
+    dist = shard.init_process_group("gloo")
+    out = os.path.join(d, "raw_%s.tsv" % ("bad" if bad else "ok"))
+    try:
+        ok = shard.decompose_files_sharded(os.path.join(d, "bad.fa" if bad else "r.fa"), os.path.join(d, "m.fa"), out, dist,
+                                           range_fn=_checker_files_range_fn, scoring=(-1, -2, -1, 1), part_size=500,
+                                           overlap=100, threads=2)
+        q.put((rank, "ok", ok))
+    except lib.SdError as e:
+        q.put((rank, "err", (e.code, e.msg)))
+    dist.destroy_process_group()
+
+
+def test_file_form_sharded_world_size_2_and_uniform_failure(tmp_path):
+    """decompose_files_sharded (what `torch.distributed.run ... bin/stringdecomposer` executes): rank 0 writes
+    the raw TSV of the whole job; a failure in ONE rank's share is raised by every rank (nobody is left
+    waiting in the gather) with that rank's message."""
+    from oracle import binding as oracle
+    mn, ms = synth.make_monomers(3, seed=2)
+    ms = [m[:60] for m in ms]
+    names, seqs = synth.make_reads(ms, 3, read_len=700, seed=2)
+    n2, s2 = synth.make_reads(ms, 1, read_len=2450, seed=3)
+    names, seqs = ["long"] + names, list(s2) + list(seqs)
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "r.fa"), names, seqs, width=70)
+    synth.write_fasta(os.path.join(d, "bad.fa"), names[:3] + ["bad1"], seqs)
+    synth.write_fasta(os.path.join(d, "m.fa"), mn, ms)
+    for bad in (False, True):
+        ws, port = 2, _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_files_worker, args=(r, ws, port, q, d, bad)) for r in range(ws)]
+        for p in ps:
+            p.start()
+        res = sorted(q.get(timeout=180) for _ in range(ws))
+        for p in ps:
+            p.join(60)
+            assert p.exitcode == 0
+        if not bad:
+            assert [r[1:] for r in res] == [("ok", True), ("ok", None)]
+            with open(os.path.join(d, "raw_ok.tsv"), "rb") as f:
+                assert f.read() == oracle.decompose(names, seqs, mn, ms, sc=(-1, -2, -1, 1), part=500, overlap=100)
+        else:
+            msg = "ERROR: Sequence bad1 contains undefined symbol (not ACGT): x"
+            assert [r[1:] for r in res] == [("err", (255, msg)), ("err", (255, msg))]
