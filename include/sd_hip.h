@@ -214,6 +214,11 @@ int sd_format_rows(const char* read_name, const char* const* tmpl_names, const s
  * = 0..3, N = 0 + a set bit in the optional 1-bit mask); returns 1 if the chunk holds an N, -1 on bad
  * arguments.  words: (n+15)/16 dwords, nmask (may be NULL): (n+31)/32 dwords. */
 int32_t sd_pack_bases(const char* seq, int64_t n, uint32_t* words, uint32_t* nmask);
+/* Rates of the host stages alone (no device): out[0] = chunk table + 2-bit packing, bp/s; out[1] = per-read
+ * assembly (chunk offsets, seam merge) + raw TSV text of one synthetic record per 171 bases, bp/s; out[2] =
+ * TSV rows/s; out[3] = bytes of text per pass.  p->threads host threads, `iters` passes over the reads. */
+int sd_host_stage_rates(const char* const* read_seqs, const int64_t* read_lens, int32_t n_reads,
+                        const sd_params* p, int32_t iters, double out[4]);
 /* FASTA validation + load with the reference's semantics (main.cpp:314-346).  Arrays malloc'ed,
  * free with sd_fasta_free. */
 typedef struct sd_fasta {

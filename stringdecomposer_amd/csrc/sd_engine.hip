@@ -1643,6 +1643,63 @@ int sd_stream_info(sd_stream* s, int64_t info[8]) {
     return sd_engine_info(s->pipe.eng[0], info);
 }
 
+// Host stages of the path alone, no device (for sizing the host side of a multi-GPU node: SURVEY 8(e) wants
+// the host to feed >= 7x one GPU): (a) chunk table + 2-bit packing of the reads into a host buffer, as
+// load_chunks_impl does, (b) per-read assembly + raw TSV text of one synthetic record per 171 bases per
+// chunk (offsets, seam merge, SaveBatch formatting), as sd_decompose's sink does.
+int sd_host_stage_rates(const char* const* read_seqs, const int64_t* read_lens, int32_t n_reads, const sd_params* p,
+                        int32_t iters, double out[4]) {
+    std::string err;
+    if (validate_params(p, err) || !out || n_reads < 0 || (n_reads && (!read_seqs || !read_lens)) || iters < 1) return SD_ERR_PARAM;
+    std::vector<ReadView> reads((size_t)n_reads);
+    int64_t bp = 0;
+    for (int32_t r = 0; r < n_reads; ++r) { reads[(size_t)r] = ReadView{"read", 4, read_seqs[r], read_lens[r]}; bp += read_lens[r]; }
+    std::vector<CRef> table;
+    std::vector<int32_t> nch;
+    build_chunk_table(reads, p, table, nch);
+    const size_t C = table.size();
+    std::vector<uint32_t> woff(C + 1, 0);
+    for (size_t c = 0; c < C; ++c) woff[c + 1] = woff[c] + (uint32_t)((table[c].len + 15) / 16);
+    std::vector<uint32_t> words(woff[C] + 1);
+    double t0 = now_s();
+    for (int it = 0; it < iters; ++it)
+        sd::parallel_for((int64_t)C, p->threads, 16, [&](int64_t c) {
+            (void)sd::pack_chunk(reads[(size_t)table[(size_t)c].read].seq + table[(size_t)c].off, table[(size_t)c].len,
+                                 words.data() + woff[(size_t)c]);
+        });
+    out[0] = (double)bp * iters / std::max(now_s() - t0, 1e-9);
+    // synthetic records: one per 171 bases, chunk-local coordinates
+    std::vector<sd_rec> recs;
+    std::vector<int64_t> roff(C + 1, 0);
+    for (size_t c = 0; c < C; ++c) {
+        for (int32_t a = 0; a < table[c].len; a += 171)
+            recs.push_back(sd_rec{(int32_t)((a / 171) % 24), a, std::min(a + 170, table[c].len - 1), 100});
+        roff[c + 1] = (int64_t)recs.size();
+    }
+    std::vector<std::string> tnames;
+    for (int j = 0; j < 24; ++j) tnames.push_back("M" + std::to_string(j % 12) + (j >= 12 ? "'" : ""));
+    size_t text = 0, rows = 0;
+    t0 = now_s();
+    for (int it = 0; it < iters; ++it) {
+        std::string tsv;
+        ReadAssembler as(reads, table, nch, tnames, p->threads, tsv);
+        const size_t step = 4096;
+        for (size_t c0 = 0; c0 < C; c0 += step) {
+            const size_t c1 = std::min(C, c0 + step);
+            std::vector<int64_t> ro(c1 - c0 + 1);
+            for (size_t c = c0; c <= c1; ++c) ro[c - c0] = roff[c] - roff[c0];
+            as.add(c0, c1, recs.data() + roff[c0], ro.data());
+        }
+        text = tsv.size();
+        rows = (size_t)std::count(tsv.begin(), tsv.end(), '\n');
+    }
+    const double dt = std::max(now_s() - t0, 1e-9);
+    out[1] = (double)bp * iters / dt;
+    out[2] = (double)rows * iters / dt;
+    out[3] = (double)text;
+    return SD_OK;
+}
+
 int32_t sd_pack_bases(const char* seq, int64_t n, uint32_t* words, uint32_t* nmask) {
     if (!seq || n < 0 || n > 0x7fffffff || !words) return -1;
     const bool hn = sd::pack_chunk(seq, (int32_t)n, words);

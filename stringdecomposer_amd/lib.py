@@ -34,6 +34,7 @@ EXPORTS = [
     "sd_stream_create", "sd_stream_destroy", "sd_stream_submit", "sd_stream_collect", "sd_stream_stats",
     "sd_stream_info", "sd_pack_bases", "sd_identity_segments_dev", "sd_nw_release_cache",
     "sd_run_files", "sd_convert_raw_tsv", "sd_decompose_files_range", "sd_assemble_files_tsv",
+    "sd_host_stage_rates",
 ]
 
 
@@ -119,6 +120,7 @@ def load():
                                            C.c_size_t]
     L.sd_assemble_files_tsv.argtypes = [C.c_char_p, C.c_char_p, P(Params), C.c_void_p, C.c_void_p, C.c_int64,
                                         C.c_char_p, C.c_char_p, C.c_size_t]
+    L.sd_host_stage_rates.argtypes = [P(C.c_char_p), P(C.c_int64), C.c_int32, P(Params), C.c_int32, P(C.c_double)]
     L.sd_format_alt_rows.argtypes = [P(C.c_char_p), C.c_int32, C.c_void_p, P(C.c_char_p), C.c_int32, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, P(C.c_void_p),
                                      P(C.c_size_t)]
@@ -415,6 +417,18 @@ class Stream:
         v = (C.c_int64 * 8)()
         self.L.sd_stream_info(self.h, v)
         return _info_dict(v)
+
+
+def host_stage_rates(reads, iters=3, **kw):
+    """{"pack_bp_per_s", "assemble_format_bp_per_s", "rows_per_s", "text_bytes"} of the host stages alone."""
+    L = load()
+    rs = reads if isinstance(reads, ReadSet) else ReadSet(reads)
+    p = make_params(**kw)
+    out = (C.c_double * 4)()
+    rc = L.sd_host_stage_rates(rs.ptrs, rs.lens, rs.n, C.byref(p), int(iters), out)
+    if rc != SD_OK:
+        raise SdError(rc, "sd_host_stage_rates")
+    return {"pack_bp_per_s": out[0], "assemble_format_bp_per_s": out[1], "rows_per_s": out[2], "text_bytes": out[3]}
 
 
 def pack_bases(seq):
