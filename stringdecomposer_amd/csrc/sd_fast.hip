@@ -395,12 +395,19 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
                 cl.code[q] = kk < Lj ? (int)tcodes[x0 + kk] : 7;
                 cl.slot[q] = kk < Lj ? (int)slot_of[x0 + kk] : 0;
 #pragma unroll
-                for (int b = 0; b < 5; ++b) mt[b][lane][q] = (int16_t)(cl.code[q] == b ? mD : xD);
+                for (int b = 0; b < 5; ++b) mt[b][lane][q] = (int16_t)(4 * (cl.code[q] == b ? mD : xD) - 2);
             }
             return cl;
         };
         // one block of rows [a, i]: recompute, derive the moves, walk; returns true when the instance
         // start (START move) was reached
+        // Cells are kept as T = 4*E + 3, and every candidate of the cell update carries the reference's
+        // traceback priority in its two low bits -- DEL 3 > INS 2 > DIAG 1 > START 0 (main.cpp:242-253) -- so
+        // that ONE maximum yields both the value and, among equal values, the move the reference's equality
+        // tests would pick first; no compares.  With Bd2 = 4*(B_i + del) + 2 and mm4 = 4*(mm - del) - 2:
+        //     diag / start:  max(T[k-1], Bd2) + mm4   -> 4*(E[k-1] + mm - del) + 1  or  4*(B_i + mm) + 0
+        //     insertion:     T[k] + (4*ins - 1)       -> 4*(E[k] + ins) + 2
+        //     deletion:      (left cell's result) | 3
         auto block = [&](auto qq_c, const Cells cl, const int i_in, const int k_in) -> Pos {
             constexpr int QQ = decltype(qq_c)::value;
             constexpr int QQP = QQ <= 4 ? 4 : 8;
@@ -408,10 +415,10 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
             const int* code = cl.code;
             const int* slot = cl.slot;
             const int a = i & ~(FAST_R - 1);  // first row of the block
-            int32_t E[QQ];
+            int32_t T[QQ];
             int rstart;
             if (a == 0) {
-                // row 0, main.cpp:171-182
+                // row 0, main.cpp:171-182 (moves: DEL where the cell equals its left neighbour, else stop)
                 const int r = rc.code(0);
                 int32_t run = NEG_INF32;
                 int32_t loc[QQ];
@@ -429,10 +436,10 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
 #pragma unroll
                 for (int q = 0; q < QQ; ++q) {
                     const int32_t Ef = max(loc[q], X);
-                    const int pc = Ef == left ? 0 : 3;  // k == 0: left = -inf
-                    bits |= (uint32_t)pc << (2 * q);
+                    const int tg = Ef == left ? 3 : 0;  // k == 0: left = -inf
+                    bits |= (uint32_t)tg << (2 * q);
                     left = Ef;
-                    E[q] = Ef;
+                    T[q] = 4 * Ef + 3;
                 }
                 pt[0][lane] = (pt_t)bits;
                 rstart = 1;
@@ -445,22 +452,24 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
                     const int v = slot[q] & 127, s = slot[q] >> 7;
                     const uint32_t wv = ckq[s * 64 + (v & 63)];
                     const uint32_t hw = (v >> 6) ? (wv >> 16) : (wv & 0xffffu);
-                    E[q] = cb + (ckf16 ? (int)(float)__builtin_bit_cast(_Float16, (unsigned short)hw)
-                                       : (int)(short)hw);
+                    const int32_t Ev = cb + (ckf16 ? (int)(float)__builtin_bit_cast(_Float16, (unsigned short)hw)
+                                                   : (int)(short)hw);
+                    T[q] = 4 * max(Ev, -0x08000000) + 3;  // padding cells hold the fill's "-inf": keep them far below, no overflow
                 }
                 rstart = a;
             }
             // per-row scalars of the block, one row per lane (read once, then v_readlane per row)
             const int rl = a + lane;
             const bool rvalid = rl >= 1 && rl <= i;
-            const int vBd = rvalid ? Bof(rl) + del : 0;
+            const int vBd = rvalid ? 4 * (Bof(rl) + del) + 2 : 0;
             const int vR = rvalid ? rc.code(rl) : 0;
+            const int ins4 = 4 * ins - 1;
             for (int r_i = rstart; r_i <= i; ++r_i) {
                 const int r = __builtin_amdgcn_readlane(vR, r_i - a);
-                const int32_t Bd = __builtin_amdgcn_readlane(vBd, r_i - a);
-                const int32_t pdEdge = lane_up_neg(E[QQ - 1]);
-                int32_t loc[QQ], w[QQ], dg[QQ];
-                int32_t run = NEG_INF32, pd = pdEdge;
+                const int32_t Bd2 = __builtin_amdgcn_readlane(vBd, r_i - a);
+                const int32_t pdEdge = lane_up_neg(T[QQ - 1]);
+                int32_t loc[QQ];
+                int32_t pd = pdEdge;
                 int32_t mm4[QQP];
 #pragma unroll
                 for (int h = 0; h < QQP / 4; ++h) {
@@ -470,37 +479,34 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
                 }
 #pragma unroll
                 for (int q = 0; q < QQ; ++q) {
-                    const int32_t mmd = mm4[q];
-                    const int32_t v = max(pd, Bd) + mmd;     // start / diag (lane 0: pd = -inf)
-                    dg[q] = pd + mmd;
-                    w[q] = E[q] + ins;
-                    int32_t cand = max(v, w[q]);
-                    if (q == 0) cand = lane == 0 ? v : cand;  // k == 0: start term only
-                    run = q == 0 ? cand : max(run, cand);
-                    loc[q] = run;
-                    pd = E[q];
+                    const int32_t v = max(pd, Bd2) + mm4[q];   // diag (tag 1) / start (tag 0); lane 0: pd = -inf
+                    const int32_t w = T[q] + ins4;             // insertion (tag 2)
+                    if (q == 0) {
+                        // k == 0 (lane 0): the fill never takes the insertion there, but the reference's
+                        // traceback tests it (main.cpp:245): the value stays v; the move is INS iff w == v
+                        const int32_t c = max(v, w);
+                        loc[0] = (lane == 0 && w > (v | 3)) ? v : c;
+                    } else {
+                        loc[q] = max(max(loc[q - 1] | 3, v), w);
+                    }
+                    pd = T[q];
                 }
-                const int32_t X = lane_up_neg(wave_prefix_max(run));
-                int32_t left = X;
+                const int32_t X = lane_up_neg(wave_prefix_max(loc[QQ - 1] | 3));
                 uint32_t bits = 0;
 #pragma unroll
                 for (int q = 0; q < QQ; ++q) {
                     const int32_t Ef = max(loc[q], X);
-                    int pc = Ef == dg[q] ? 2 : 3;   // DIAG  main.cpp:249 / START main.cpp:253
-                    pc = Ef == w[q] ? 1 : pc;       // INS   main.cpp:245 (tested at k == 0 too)
-                    pc = Ef == left ? 0 : pc;       // DEL   main.cpp:242 (k == 0: left = -inf)
-                    bits |= (uint32_t)pc << (2 * q);
-                    left = Ef;
-                    E[q] = Ef;
+                    bits = __builtin_amdgcn_alignbit((uint32_t)Ef, bits, 2);   // tag into the top, oldest cell lowest
+                    T[q] = Ef | 3;
                 }
-                pt[r_i - a][lane] = (pt_t)bits;
+                pt[r_i - a][lane] = (pt_t)(bits >> (32 - 2 * QQ));
             }
             // walk inside the block (wave-uniform)
             while (i >= a) {
-                const int pc = __builtin_amdgcn_readfirstlane((pt[i - a][k / QQ] >> (2 * (k % QQ))) & 3);
-                if (pc == 0) { --k; }
-                else if (pc == 1) { --i; }
-                else if (pc == 2) { --i; --k; }
+                const int tg = __builtin_amdgcn_readfirstlane((pt[i - a][k / QQ] >> (2 * (k % QQ))) & 3);
+                if (tg == 3) { --k; }
+                else if (tg == 2) { --i; }
+                else if (tg == 1) { --i; --k; }
                 else { return Pos{i, k, true}; }
             }
             return Pos{i, k, false};
