@@ -170,7 +170,9 @@ struct sd_engine {
     int family = 0;  // 1 generic, 2 fast
 
     // generic family
-    int Q = 0, threads = 0, rowBytes = 0;
+    int Q = 0, threads = 0, rowBytes = 0, n_tiles = 1;
+    DevBuf<int32_t> d_estate;        // tiled generic fill: previous row of every resident chunk
+    DevBuf<uint16_t> d_grank;        // --ed_thr, generic family: rank table [chunk][T]
     DevBuf<uint8_t> d_tmeta;
     DevBuf<int32_t> d_tend_kd, d_tend_j, d_toff, d_tlen;
     DevBuf<uint8_t> d_ptr;
@@ -232,7 +234,7 @@ struct sd_engine {
     }
 
     size_t workspace_bytes() const {
-        return d_tmeta.bytes() + d_tend_kd.bytes() + d_tend_j.bytes() + d_ptr.bytes() +
+        return d_tmeta.bytes() + d_tend_kd.bytes() + d_tend_j.bytes() + d_ptr.bytes() + d_estate.bytes() + d_grank.bytes() +
                d_ftable.bytes() + d_flane.bytes() + d_fslot.bytes() + d_ftcodes.bytes() + d_fckpt.bytes() +
                d_fckbase.bytes() + d_in.bytes() +
                d_B.bytes() + d_argB.bytes() + d_cnt.bytes() + d_recs.bytes() + d_dense.bytes() +
@@ -282,8 +284,13 @@ void build_generic_tables(sd_engine* e) {
     const int64_t need = (e->sumL + Q - 1) / Q;
     int threads = (int)((need + 63) / 64 * 64);
     if (threads < 64) threads = 64;
+    e->n_tiles = 1;
+    if (threads > 1024) {  // more than 32 768 cells: tiles of 1024 threads x 32 cells, processed in order
+        e->n_tiles = (int)((need + 1023) / 1024);
+        threads = 1024;
+    }
     e->threads = threads;
-    const int64_t cells = (int64_t)threads * Q;
+    const int64_t cells = (int64_t)e->n_tiles * threads * Q;
     e->rowBytes = (int)(cells / 4);
     std::vector<uint8_t> meta((size_t)cells, (uint8_t)(7 | sd::CELL_START));
     std::vector<int32_t> kd((size_t)cells, 0), tj((size_t)cells, 0);
@@ -389,19 +396,16 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
             return SD_ERR_UNSUPPORTED;
         }
         if (family != 1 && family != 2) { set_err(errbuf, errlen, "bad kernel family"); return SD_ERR_PARAM; }
-        if (p->ed_thr > -1 && family != 2) {
-            set_err(errbuf, errlen, "--ed_thr needs the fast kernel family, which is not applicable here: " + why);
+        if (p->ed_thr > -1 && e->Lmax > 512) {
+            set_err(errbuf, errlen, "--ed_thr supports templates of up to 512 bp");
             return SD_ERR_UNSUPPORTED;
         }
+        if (e->T > 65534) { set_err(errbuf, errlen, "more than 65534 templates"); return SD_ERR_UNSUPPORTED; }
         e->family = family;
         e->d_toff.upload(e->toff);
         e->d_tlen.upload(e->tlen);
         if (family == 1) {
             e->Q = sd::generic_pick_q(e->sumL);
-            if (e->Q < 0) {
-                set_err(errbuf, errlen, "template set too large for the generic kernel (> 32768 cells)");
-                return SD_ERR_UNSUPPORTED;
-            }
             build_generic_tables(e.get());
         } else {
             e->d_ftable.upload(e->fplan.table);
@@ -409,12 +413,14 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
             e->d_fslot.upload(e->fplan.slot_of);
             e->d_ftcodes.upload(e->fplan.tcodes);
             if (p->ed_thr > -1) {
-                std::vector<unsigned long long> peq;
-                sd::build_peq(e->tseq, peq);
-                e->d_peq.upload(peq);
                 e->d_endvl.upload(e->fplan.end_vlane);
                 e->d_endoff.upload(e->fplan.end_off);
             }
+        }
+        if (p->ed_thr > -1) {
+            std::vector<unsigned long long> peq;
+            sd::build_peq(e->tseq, peq);
+            e->d_peq.upload(peq);
         }
         SD_HIP(hipEventCreate(&e->ev_run0));
         SD_HIP(hipEventCreate(&e->ev_run1));
@@ -549,6 +555,15 @@ static int load_chunks_impl(sd_engine* e, const std::vector<const char*>& cptr,
             }
             if (C > 0) { e->subs.emplace_back(begin, (int)C); max_sub = std::max(max_sub, cur); }
             e->d_ptr.alloc(max_sub);
+            if (e->n_tiles > 1) {
+                size_t most = 0;
+                for (const auto& sb : e->subs) most = std::max(most, (size_t)(sb.second - sb.first));
+                e->d_estate.alloc(most * (size_t)e->n_tiles * 1024 * 32);
+            }
+            if (e->p.ed_thr > -1) {
+                e->d_dist.alloc(C * (size_t)e->T);
+                e->d_grank.alloc(C * (size_t)e->T);
+            }
             ensure_events(e->ev_fill, e->subs.size());
             ensure_events(e->ev_trace, e->subs.size());
         } else {
@@ -619,6 +634,11 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
         e->fill_launches = 0;
         if (C > 0) {
             if (e->family == 1) {
+                const bool ranked = e->p.ed_thr > -1;
+                if (ranked)  // main.cpp:91-93: per-chunk template prefilter -> rank table
+                    sd::launch_edthr_filter(st, e->dp_chunks, C, e->T, e->Lmax, e->p.ed_thr, e->dp_bases2, e->dp_nmask,
+                                            e->d_peq.p, e->d_tlen.p, nullptr, nullptr, e->d_dist.p, nullptr, nullptr,
+                                            e->d_grank.p);
                 for (size_t s = 0; s < e->subs.size(); ++s) {
                     const int b = e->subs[s].first, n_sub = e->subs[s].second - b;
                     const uint64_t row0_base = e->chunks[(size_t)b].row0;
@@ -626,7 +646,8 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                     sd::launch_generic_fill(e->Q, e->threads, n_sub, st, e->dp_chunks, b,
                                             e->dp_bases2, e->dp_nmask, e->d_tmeta.p,
                                             e->d_tend_kd.p, e->d_tend_j.p, e->sc, e->rowBytes,
-                                            e->d_ptr.p, row0_base, e->d_B.p, e->d_argB.p);
+                                            e->d_ptr.p, row0_base, e->d_B.p, e->d_argB.p,
+                                            ranked ? e->d_grank.p : nullptr, e->T, e->n_tiles, e->d_estate.p);
                     SD_HIP(hipEventRecord(e->ev_fill[2 * s + 1], st));
                     SD_HIP(hipEventRecord(e->ev_trace[2 * s], st));
                     sd::launch_generic_trace(n_sub, st, e->dp_chunks, b, e->d_ptr.p, row0_base,
@@ -638,9 +659,9 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
             } else {
                 const bool ranked = e->p.ed_thr > -1;
                 if (ranked)  // main.cpp:91-93: per-chunk template prefilter
-                    sd::launch_edthr_filter(st, e->dp_chunks, C, e->T, e->p.ed_thr, e->dp_bases2,
+                    sd::launch_edthr_filter(st, e->dp_chunks, C, e->T, e->Lmax, e->p.ed_thr, e->dp_bases2,
                                             e->dp_nmask, e->d_peq.p, e->d_tlen.p, e->d_endvl.p,
-                                            e->d_endoff.p, e->d_dist.p, e->d_cendoff.p, e->d_crank.p);
+                                            e->d_endoff.p, e->d_dist.p, e->d_cendoff.p, e->d_crank.p, nullptr);
                 SD_HIP(hipEventRecord(e->ev_fill[0], st));
                 sd::launch_fast_fill(e->fplan, st, e->dp_chunks, C, e->dp_bases2, e->dp_nmask,
                                      e->d_ftable.p, e->d_flane.p, e->sc, e->d_B.p, e->d_argB.p,

@@ -66,12 +66,13 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
                      FastPlan& plan, std::string& why);
 
 // --ed_thr prefilter on the device (sd_filter.hip): infix edit distances, kept set and ranks per
-// chunk -> per-chunk lane constants (cendoff, crank: [chunk][64] packed {lo,hi} int16)
+// chunk -> per-chunk lane constants of the fast family (cendoff, crank: [chunk][64] packed {lo,hi}
+// int16; grank == nullptr) or the rank table of the generic family (grank: [chunk][T], 0xffff = dropped)
 void build_peq(const std::vector<std::string>& tseq, std::vector<unsigned long long>& peq);
-void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, int T, int ed_thr,
+void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, int T, int Lmax, int ed_thr,
                          const uint32_t* bases2, const uint32_t* nmask, const unsigned long long* peq,
                          const int32_t* tlen, const int32_t* end_vlane, const int32_t* end_off,
-                         int32_t* dist, uint32_t* cendoff, uint32_t* crank);
+                         int32_t* dist, uint32_t* cendoff, uint32_t* crank, uint16_t* grank);
 
 // number of checkpoint rows of the batch; fills ChunkDesc::pad with each chunk's first checkpoint
 int64_t fast_ckpt_rows_total(const FastPlan& plan, std::vector<ChunkDesc>& chunks);

@@ -36,11 +36,10 @@ __device__ __forceinline__ uint32_t add_b8(uint32_t u, uint32_t tb, int pair) {
 
 // fp16 variant: the byte pair of a slot holds bf8 (E5M2) values; one gfx950 instruction turns it into
 // the packed fp16 pair {lo plane, hi plane} (exact for the small integers of a score table, -inf pads)
-__device__ __forceinline__ uint32_t cvt_bf8x2(uint32_t tb, int pair) {
-    uint32_t v;
-    const float one = 1.0f;
-    if (pair == 0) asm("v_cvt_scalef32_pk_f16_bf8 %0, %1, %2" : "=v"(v) : "v"(tb), "v"(one));
-    else asm("v_cvt_scalef32_pk_f16_bf8 %0, %1, %2 op_sel:[1,0,0]" : "=v"(v) : "v"(tb), "v"(one));
+__device__ __forceinline__ uint32_t cvt_bf8x2(uint32_t tb, int pair, uint32_t one_s) {
+    uint32_t v;   // one_s: the bits of 1.0f in an SGPR (the scale operand; also what pins the slot skew)
+    if (pair == 0) asm("v_cvt_scalef32_pk_f16_bf8 %0, %1, %2" : "=v"(v) : "v"(tb), "s"(one_s));
+    else asm("v_cvt_scalef32_pk_f16_bf8 %0, %1, %2 op_sel:[1,0,0]" : "=v"(v) : "v"(tb), "s"(one_s));
     return v;
 }
 
@@ -69,7 +68,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
     (void)wave; (void)nw;
     // table value of a slot added to u: two SDWA byte adds (int8 table) or convert + packed add (bf8 table)
     auto add_tbl = [&](uint32_t u, uint32_t tb, int pair) {
-        if constexpr (F16) return CO::add(u, cvt_bf8x2(tb, pair));
+        if constexpr (F16) return CO::add(u, cvt_bf8x2(tb, pair, 0x3f800000u));
         else return add_b8(u, tb, pair);
     };
     ChunkSched sched;
@@ -176,6 +175,8 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
         if constexpr (F16) {
             // 4 ops per slot: u = max(S[x-1], KB); t = cvt(bf8 pair); v = u + t; S'[x] = max3(S'[x-1], v, S[x])
             uint32_t t_[P];
+            uint32_t KBs = (uint32_t)__builtin_amdgcn_readfirstlane((int)KB);
+            uint32_t one_s = 0x3f800000u;
 #pragma unroll
             for (int s = 0; s < P + 4; ++s) {
                 if (s >= 4) {
@@ -188,12 +189,19 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
                 }
                 if (s < P) {
                     const int q = s;
-                    u_[q] = q == 0 ? KB : CO::mx(L[q - 1], KB);
-                    t_[q] = cvt_bf8x2(tbg[(q >> 4) & 1][(q & 15) >> 1], q & 1);
+                    uint32_t u;
+                    if (q == 0) u = KB;
+                    else asm("v_pk_max_f16 %0, %1, %2" : "=v"(u) : "v"(L[q - 1]), "s"(KBs));
+                    u_[q] = u;
+                    t_[q] = cvt_bf8x2(tbg[(q >> 4) & 1][(q & 15) >> 1], q & 1, one_s);
                     if ((q & 15) == 2 && (q >> 4) + 1 < G) load_group(rcur, (q >> 4) + 1, ((q >> 4) + 1) & 1, t_[q]);
                 }
-                uint32_t& pinL = L[s >= 4 ? s - 4 : 0];
-                asm volatile("" : "+v"(KB), "+v"(pinL));
+                // pin the skew: this step's scalar operands are "redefined" here, so the compiler cannot batch
+                // the u / table conversions of later slots first (that would need 2P registers).  Scalar pins:
+                // an inline asm that defines a VGPR costs a wait state (s_nop) per step on gfx950.
+                // The chain value of this step is only READ by the pin (it must exist by now).
+                const uint32_t pinL = L[s >= 4 ? s - 4 : 0];
+                asm volatile("" : "+s"(KBs), "+s"(one_s) : "v"(pinL));
                 __builtin_amdgcn_sched_barrier(0);
             }
             (void)c_; (void)run;

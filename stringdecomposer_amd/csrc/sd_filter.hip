@@ -6,14 +6,17 @@
 // the first one and every other one with distance <= ed_thr kept IN THAT ORDER -- the order
 // matters because AlignPartClassicDP breaks score ties towards the first template of its list.
 //
-//  sd_hw_dist    one thread per (chunk, template): Myers' bit-vector algorithm (J. ACM 46(3), 1999)
-//                in its block form (Hyyro 2003) for patterns of up to 512 symbols, search variant
-//                (free leading / trailing text), minimum of the bottom-row score over all columns.
+//  sd_hw_dist<W> one lane per (chunk, template): Myers' bit-vector algorithm (J. ACM 46(3), 1999)
+//                in its block form (Hyyro 2003), W 64-bit words per template (patterns of up to 512
+//                symbols), match masks in LDS, search variant (free leading / trailing text), minimum
+//                of the bottom-row score over all columns.
 //  sd_rank_keep  one thread per (chunk, template): kept? + rank inside the filtered order; writes the
-//                per-chunk lane constants the ranked fill kernels use (end offsets of dropped
-//                templates become -inf, ties between template ends go to the smallest rank).
+//                per-chunk lane constants the ranked fast fills use (end offsets of dropped templates
+//                become -inf, ties between template ends go to the smallest rank) or the rank table of
+//                the generic family.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -23,23 +26,37 @@
 
 namespace sd {
 
+// One lane per (chunk, template) pair, consecutive lanes = consecutive templates of a chunk: the lanes of a
+// wave then read the same few chunks' bases (one broadcast load per 16 columns) and every lane does useful
+// work for any template count (a wave per chunk with the templates across the lanes would idle 40 of 64
+// lanes at 24 templates).  W = 64-bit words per template, a template parameter so that the delta vectors
+// live in exactly 4*W registers; the match masks of all templates sit in LDS ([template][symbol][word]).
+template <int W>
 __global__ __launch_bounds__(256) void sd_hw_dist(const ChunkDesc* __restrict__ chunks, int n_chunks,
                                                   int T, const uint32_t* __restrict__ bases2,
                                                   const uint32_t* __restrict__ nmask,
                                                   const unsigned long long* __restrict__ peq,
                                                   const int32_t* __restrict__ tlen,
-                                                  int32_t* __restrict__ dist) {
+                                                  int32_t* __restrict__ dist, int lds_templates) {
+    extern __shared__ unsigned long long speq[];   // [min(T, lds_templates)][5][W]
+    for (int idx = threadIdx.x; idx < lds_templates * 5 * W; idx += blockDim.x) {
+        const int j = idx / (5 * W), rem = idx % (5 * W);
+        speq[idx] = peq[(size_t)j * 40 + (size_t)(rem / W) * 8 + (rem % W)];
+    }
+    __syncthreads();
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long long)n_chunks * T) return;
     const int c = (int)(g / T), j = (int)(g % T);
     const ChunkDesc cd = chunks[c];
     const int m = tlen[j];
-    const int W = (m + 63) >> 6;
-    const unsigned long long* pq = peq + (size_t)j * 40;  // [5 symbols][8 words]
+    const int lastW = (m - 1) >> 6;
     const unsigned long long lastBit = 1ull << ((m - 1) & 63);
-    unsigned long long Pv[8], Mv[8];
+    const bool in_lds = j < lds_templates;
+    const unsigned long long* pq_l = speq + (size_t)j * 5 * W;
+    const unsigned long long* pq_g = peq + (size_t)j * 40;
+    unsigned long long Pv[W], Mv[W];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) { Pv[b] = ~0ull; Mv[b] = 0ull; }
+    for (int b = 0; b < W; ++b) { Pv[b] = ~0ull; Mv[b] = 0ull; }
     int score = m, best = m;
     const uint32_t* w = bases2 + cd.woff;
     const uint32_t* nm = cd.noff >= 0 ? nmask + cd.noff : nullptr;
@@ -53,16 +70,16 @@ __global__ __launch_bounds__(256) void sd_hw_dist(const ChunkDesc* __restrict__ 
         }
         int hin = 0;  // search variant: the row above the pattern costs nothing
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            if (b < W) {
-                unsigned long long Eq = pq[r * 8 + b];
+        for (int b = 0; b < W; ++b) {
+            if (b <= lastW) {
+                unsigned long long Eq = in_lds ? pq_l[r * W + b] : pq_g[r * 8 + b];
                 const unsigned long long pv = Pv[b], mv = Mv[b];
                 const unsigned long long Xv = Eq | mv;
                 if (hin < 0) Eq |= 1ull;
                 const unsigned long long Xh = (((Eq & pv) + pv) ^ pv) | Eq;
                 unsigned long long Ph = mv | ~(Xh | pv);
                 unsigned long long Mh = pv & Xh;
-                const unsigned long long top = (b == W - 1) ? lastBit : (1ull << 63);
+                const unsigned long long top = (b == lastW) ? lastBit : (1ull << 63);
                 int hout = 0;
                 if (Ph & top) hout = 1;
                 if (Mh & top) hout = -1;
@@ -81,16 +98,19 @@ __global__ __launch_bounds__(256) void sd_hw_dist(const ChunkDesc* __restrict__ 
     dist[(size_t)c * T + j] = best;
 }
 
-// endoff / rank arrays: [chunk][64 lanes] dwords, packed {lo plane, hi plane} int16
+// Kept set and order of a chunk (main.cpp:141-147): first = smallest (distance, index); kept = first or
+// distance <= ed_thr; rank = position in the (distance, index) order among the kept.  Written as the
+// per-chunk lane constants of the ranked fast fills (end offsets / ranks, [chunk][64 lanes] dwords, packed
+// {lo plane, hi plane} int16) or, for the generic family, as a rank table [chunk][T] (0xffff = dropped).
 __global__ void sd_rank_keep(int n_chunks, int T, int ed_thr, const int32_t* __restrict__ dist,
                              const int32_t* __restrict__ end_vlane, const int32_t* __restrict__ end_off,
-                             uint16_t* __restrict__ cendoff, uint16_t* __restrict__ crank) {
+                             uint16_t* __restrict__ cendoff, uint16_t* __restrict__ crank,
+                             uint16_t* __restrict__ grank) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long long)n_chunks * T) return;
     const int c = (int)(g / T), j = (int)(g % T);
     const int32_t* d = dist + (size_t)c * T;
     const int dj = d[j];
-    // first = smallest (distance, index); kept = first or distance <= ed_thr (main.cpp:141-147)
     int first = 0;
     for (int i = 1; i < T; ++i)
         if (d[i] < d[first]) first = i;
@@ -99,6 +119,10 @@ __global__ void sd_rank_keep(int n_chunks, int T, int ed_thr, const int32_t* __r
     for (int i = 0; i < T; ++i) {
         const bool ki = i == first || d[i] <= ed_thr;
         if (ki && (d[i] < dj || (d[i] == dj && i < j))) ++rank;
+    }
+    if (grank) {
+        grank[(size_t)c * T + j] = (uint16_t)(kept ? rank : 0xffff);
+        return;
     }
     const int v = end_vlane[j];  // virtual lane holding the template's end
     const size_t at = ((size_t)c * 64 + (v & 63)) * 2 + (v >> 6);
@@ -127,18 +151,29 @@ void build_peq(const std::vector<std::string>& tseq, std::vector<unsigned long l
         }
 }
 
-void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, int T, int ed_thr,
+void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, int T, int Lmax, int ed_thr,
                          const uint32_t* bases2, const uint32_t* nmask, const unsigned long long* peq,
                          const int32_t* tlen, const int32_t* end_vlane, const int32_t* end_off,
-                         int32_t* dist, uint32_t* cendoff, uint32_t* crank) {
+                         int32_t* dist, uint32_t* cendoff, uint32_t* crank, uint16_t* grank) {
     const long long total = (long long)n_chunks * T;
     const int grid = (int)((total + 255) / 256);
-    const size_t words = (size_t)n_chunks * 64;
-    hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, cendoff, words, 0x80008000u);
-    hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, crank, words, 0x7fff7fffu);
-    hipLaunchKernelGGL(sd_hw_dist, dim3(grid), dim3(256), 0, st, chunks, n_chunks, T, bases2, nmask, peq, tlen, dist);
+    if (!grank) {
+        const size_t words = (size_t)n_chunks * 64;
+        hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, cendoff, words, 0x80008000u);
+        hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, crank, words, 0x7fff7fffu);
+    }
+    const int W = std::max(1, (Lmax + 63) / 64);
+    // match masks in LDS: as many templates as fit in 64 KB (all of them up to ~540 at 3 words)
+#define SD_HW(WW)                                                                                              \
+    {                                                                                                          \
+        const int lt = std::min(T, (int)((64 * 1024) / (5 * WW * sizeof(unsigned long long))));                \
+        hipLaunchKernelGGL(sd_hw_dist<WW>, dim3(grid), dim3(256), (size_t)lt * 5 * WW * sizeof(unsigned long long), st, \
+                           chunks, n_chunks, T, bases2, nmask, peq, tlen, dist, lt);                           \
+    }
+    if (W <= 1) SD_HW(1) else if (W == 2) SD_HW(2) else if (W == 3) SD_HW(3) else if (W == 4) SD_HW(4) else SD_HW(8)
+#undef SD_HW
     hipLaunchKernelGGL(sd_rank_keep, dim3(grid), dim3(256), 0, st, n_chunks, T, ed_thr, dist, end_vlane, end_off,
-                       reinterpret_cast<uint16_t*>(cendoff), reinterpret_cast<uint16_t*>(crank));
+                       reinterpret_cast<uint16_t*>(cendoff), reinterpret_cast<uint16_t*>(crank), grank);
 }
 
 }  // namespace sd

@@ -1,7 +1,9 @@
-// sd_generic.hip -- generic (fallback) device path: any template set up to 32768 cells, int32
-// arithmetic, any scoring inside the INF bound.  One workgroup per chunk, the flattened template
-// axis blocked over the threads (Q cells per thread, in registers), 2-bit priority-encoded
-// back-pointers written to HBM, pointer-walking traceback.
+// sd_generic.hip -- generic (fallback) device path: any template set, int32 arithmetic, any scoring
+// inside the INF bound.  One workgroup per chunk, the flattened template axis blocked over the
+// threads (Q cells per thread, in registers; beyond 32 768 cells in tiles of 1024 x 32 cells with the
+// previous row in HBM), 2-bit priority-encoded back-pointers written to HBM, pointer-walking
+// traceback.  With the --ed_thr prefilter the B_i reduction skips dropped templates and breaks ties by
+// the chunk's filtered order (per-chunk rank table).
 //
 // Replaces AlignPartClassicDP (reference stringdecomposer/src/main.cpp:151-270):
 //   fill      main.cpp:171-216   -> sd_generic_fill
@@ -20,13 +22,31 @@
 
 namespace sd {
 
+namespace {
+// Key of a template end in the B_i reduction: value in the high half; in the low half what breaks ties --
+// the smallest template index (main.cpp:211-215, 230-236) or, with the --ed_thr prefilter, the smallest rank
+// in the chunk's filtered order (main.cpp:141-147).  A dropped template (rank 0xffff) never takes part.
+__device__ __forceinline__ long long end_key(int32_t val, int32_t j, const uint16_t* grank, size_t chunk_base) {
+    if (grank) {
+        const uint32_t rk = grank[chunk_base + (size_t)j];
+        if (rk == 0xffffu) return (long long)NEG_INF32 * 4294967296LL;
+        return (long long)val * 4294967296LL + (long long)(((0xffffu - rk) << 16) | (uint32_t)j);
+    }
+    return (long long)val * 4294967296LL + (long long)(0x7fffffff - j);
+}
+__device__ __forceinline__ int32_t key_tmpl(long long kb, bool ranked) {
+    const uint32_t lo = (uint32_t)(kb & 0xffffffffLL);
+    return ranked ? (int32_t)(lo & 0xffffu) : (int32_t)(0x7fffffff - (int32_t)lo);
+}
+}  // namespace
+
 template <int Q>
 __global__ __launch_bounds__(1024) void sd_generic_fill(
     const ChunkDesc* __restrict__ chunks, int chunk_begin, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint8_t* __restrict__ tmeta,
     const int32_t* __restrict__ tend_kd, const int32_t* __restrict__ tend_j, ScoreArgs sc,
     int rowBytes, uint8_t* __restrict__ ptr, uint64_t row0_base, int32_t* __restrict__ Bout,
-    int32_t* __restrict__ argBout) {
+    int32_t* __restrict__ argBout, const uint16_t* __restrict__ grank, int T) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, nw = blockDim.x >> 6;
     const int c = chunk_begin + blockIdx.x;
     const ChunkDesc cd = chunks[c];
@@ -121,9 +141,7 @@ __global__ __launch_bounds__(1024) void sd_generic_fill(
             codes |= (uint64_t)pc << (2 * q);
             if (meta[q] & CELL_END) {
                 const int x = t * Q + q;
-                const long long key = (long long)(Ef + tend_kd[x]) * 4294967296LL +
-                                      (long long)(0x7fffffff - tend_j[x]);
-                best = max(best, key);
+                best = max(best, end_key(Ef + tend_kd[x], tend_j[x], grank, (size_t)c * T));
             }
             left = Ef;
             pd = old;
@@ -147,8 +165,167 @@ __global__ __launch_bounds__(1024) void sd_generic_fill(
         Bi = (int32_t)(kb >> 32);
         if (t == 0) {
             Bout[boff + i + 1] = Bi;
-            argBout[boff + i + 1] = 0x7fffffff - (int32_t)(kb & 0xffffffffLL);
+            argBout[boff + i + 1] = key_tmpl(kb, grank != nullptr);
         }
+    }
+}
+
+// Template sets beyond 32 768 cells (hundreds of monomers): the same row-synchronous sweep with the flattened
+// template axis cut into tiles of 1024 threads x 32 cells that one workgroup processes in order, every row.
+// The previous row lives in HBM / L2 (`Estate`, one row per resident chunk) instead of registers; the in-row
+// deletion chain and the diagonal input cross a tile boundary through two carried values.
+__global__ __launch_bounds__(1024) void sd_generic_fill_tiled(
+    const ChunkDesc* __restrict__ chunks, int chunk_begin, const uint32_t* __restrict__ bases2,
+    const uint32_t* __restrict__ nmask, const uint8_t* __restrict__ tmeta,
+    const int32_t* __restrict__ tend_kd, const int32_t* __restrict__ tend_j, ScoreArgs sc,
+    int rowBytes, uint8_t* __restrict__ ptr, uint64_t row0_base, int32_t* __restrict__ Bout,
+    int32_t* __restrict__ argBout, const uint16_t* __restrict__ grank, int T, int n_tiles,
+    int32_t* __restrict__ Estate) {
+    constexpr int Q = 32;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int c = chunk_begin + blockIdx.x;
+    const ChunkDesc cd = chunks[c];
+    const int n = cd.n;
+    const int ins = sc.ins;
+    const int mD = sc.match - sc.del, xD = sc.mismatch - sc.del;
+    const size_t cells = (size_t)n_tiles * 1024 * Q;
+    int32_t* Est = Estate + (size_t)blockIdx.x * cells;
+
+    __shared__ int32_t waveV[16];
+    __shared__ int32_t waveF[16];
+    __shared__ int32_t waveOld[16];   // previous-row value of each wave's last cell
+    __shared__ long long waveKey[16];
+    __shared__ int32_t tileS, tileOld;
+
+    uint8_t* prow = ptr + (cd.row0 - row0_base) * (uint64_t)rowBytes;
+    const uint64_t boff = cd.row0 + (uint64_t)c;
+    int32_t Bi = 0;
+    uint32_t wbits = 0, nbits = 0;
+    for (int i = 0; i < n; ++i) {
+        if ((i & 15) == 0) wbits = bases2[cd.woff + (i >> 4)];
+        int r = (wbits >> (2 * (i & 15))) & 3;
+        if (cd.noff >= 0) {
+            if ((i & 31) == 0) nbits = nmask[cd.noff + (i >> 5)];
+            if ((nbits >> (i & 31)) & 1) r = 4;
+        }
+        const bool row0 = (i == 0);
+        const int32_t Bd = Bi + sc.del;
+        long long best = (long long)NEG_INF32 * 4294967296LL;
+        int32_t carryS = NEG_INF32;    // this row: final value of the last cell of the previous tile
+        int32_t carryOld = NEG_INF32;  // previous row: value of the last cell of the previous tile
+        for (int tile = 0; tile < n_tiles; ++tile) {
+            const size_t x0 = ((size_t)tile * 1024 + (size_t)t) * Q;
+            uint8_t meta[Q];
+            int32_t E[Q];
+            {
+                const uint4* mp = reinterpret_cast<const uint4*>(tmeta + x0);
+                const uint4 m0 = mp[0], m1 = mp[1];
+                const uint32_t mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+                for (int q = 0; q < Q; ++q) meta[q] = (uint8_t)(mw[q >> 2] >> (8 * (q & 3)));
+                if (row0) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) E[q] = NEG_INF32;
+                } else {
+                    const int4* ep = reinterpret_cast<const int4*>(Est + x0);
+#pragma unroll
+                    for (int q4 = 0; q4 < Q / 4; ++q4) {
+                        const int4 e = ep[q4];
+                        E[4 * q4] = e.x; E[4 * q4 + 1] = e.y; E[4 * q4 + 2] = e.z; E[4 * q4 + 3] = e.w;
+                    }
+                }
+            }
+            bool anyStart = false;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) anyStart |= (meta[q] & CELL_START) != 0;
+            // previous-row value of cell x0-1 (diagonal input of the thread's first cell)
+            if (lane == 63) waveOld[w] = E[Q - 1];
+            __syncthreads();
+            int32_t pdEdge = __shfl_up(E[Q - 1], 1);
+            if (lane == 0) pdEdge = w == 0 ? carryOld : waveOld[w - 1];
+            const int32_t lastOld = waveOld[15];
+
+            int32_t loc[Q];
+            int32_t run = NEG_INF32, pd = pdEdge;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const bool st = (meta[q] & CELL_START) != 0;
+                const int32_t mmd = ((meta[q] & CELL_CODE_MASK) == r) ? mD : xD;
+                int32_t cand;
+                if (row0) cand = st ? mmd + sc.del : mmd;
+                else if (st) cand = Bd + mmd;
+                else cand = max(max(pd, Bd) + mmd, E[q] + ins);
+                run = st ? cand : max(cand, run);
+                loc[q] = run;
+                pd = E[q];
+            }
+            int32_t v = run;
+            int fl = anyStart ? 1 : 0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int32_t v2 = __shfl_up(v, off);
+                const int f2 = __shfl_up(fl, off);
+                if (lane >= off) {
+                    if (!fl) v = max(v, v2);
+                    fl |= f2;
+                }
+            }
+            if (lane == 63) { waveV[w] = v; waveF[w] = fl; }
+            __syncthreads();
+            int32_t cw = carryS;
+            for (int w2 = 0; w2 < w; ++w2) cw = waveF[w2] ? waveV[w2] : max(cw, waveV[w2]);
+            const int32_t S = fl ? v : max(v, cw);
+            int32_t Sprev = __shfl_up(S, 1);
+            if (lane == 0) Sprev = cw;
+
+            int32_t left = Sprev;
+            pd = pdEdge;
+            bool before = true;
+            uint64_t codes = 0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const bool st = (meta[q] & CELL_START) != 0;
+                if (st) before = false;
+                const int32_t Ef = before ? max(loc[q], Sprev) : loc[q];
+                const int32_t old = E[q];
+                const int32_t mmd = ((meta[q] & CELL_CODE_MASK) == r) ? mD : xD;
+                int pc;
+                if (!st && Ef == left) pc = 0;
+                else if (!row0 && Ef == old + ins) pc = 1;
+                else if (!row0 && !st && Ef == pd + mmd) pc = 2;
+                else pc = 3;
+                codes |= (uint64_t)pc << (2 * q);
+                if (meta[q] & CELL_END) {
+                    const size_t x = x0 + q;
+                    best = max(best, end_key(Ef + tend_kd[x], tend_j[x], grank, (size_t)c * T));
+                }
+                left = Ef;
+                pd = old;
+                E[q] = Ef;
+            }
+            {
+                int4* ep = reinterpret_cast<int4*>(Est + x0);
+#pragma unroll
+                for (int q4 = 0; q4 < Q / 4; ++q4) ep[q4] = make_int4(E[4 * q4], E[4 * q4 + 1], E[4 * q4 + 2], E[4 * q4 + 3]);
+                *reinterpret_cast<uint64_t*>(prow + (size_t)i * rowBytes + x0 / 4) = codes;
+            }
+            if (t == 1023) { tileS = S; tileOld = lastOld; }
+            __syncthreads();
+            carryS = tileS;
+            carryOld = tileOld;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) best = max(best, __shfl_xor(best, off));
+        if (lane == 0) waveKey[w] = best;
+        __syncthreads();
+        long long kb = waveKey[0];
+        for (int w2 = 1; w2 < 16; ++w2) kb = max(kb, waveKey[w2]);
+        Bi = (int32_t)(kb >> 32);
+        if (t == 0) {
+            Bout[boff + i + 1] = Bi;
+            argBout[boff + i + 1] = key_tmpl(kb, grank != nullptr);
+        }
+        __syncthreads();   // waveKey / tile carries are rewritten by the next row
     }
 }
 
@@ -200,17 +377,22 @@ int generic_pick_q(int64_t sum_len) {
     const int qs[4] = {4, 8, 16, 32};
     for (int q : qs)
         if ((sum_len + q - 1) / q <= 1024) return q;
-    return -1;
+    return 32;   // tiled: ceil(sum_len / 32768) tiles of 1024 threads x 32 cells
 }
 
 void launch_generic_fill(int Q, int threads, int grid, hipStream_t st, const ChunkDesc* chunks,
                          int chunk_begin, const uint32_t* bases2, const uint32_t* nmask,
                          const uint8_t* tmeta, const int32_t* tend_kd, const int32_t* tend_j,
                          ScoreArgs sc, int rowBytes, uint8_t* ptr, uint64_t row0_base, int32_t* B,
-                         int32_t* argB) {
+                         int32_t* argB, const uint16_t* grank, int T, int n_tiles, int32_t* Estate) {
+    if (n_tiles > 1) {
+        hipLaunchKernelGGL(sd_generic_fill_tiled, dim3(grid), dim3(1024), 0, st, chunks, chunk_begin, bases2, nmask, tmeta,
+                           tend_kd, tend_j, sc, rowBytes, ptr, row0_base, B, argB, grank, T, n_tiles, Estate);
+        return;
+    }
 #define SD_LAUNCH(QQ)                                                                            \
     hipLaunchKernelGGL(sd_generic_fill<QQ>, dim3(grid), dim3(threads), 0, st, chunks, chunk_begin, \
-                       bases2, nmask, tmeta, tend_kd, tend_j, sc, rowBytes, ptr, row0_base, B, argB)
+                       bases2, nmask, tmeta, tend_kd, tend_j, sc, rowBytes, ptr, row0_base, B, argB, grank, T)
     switch (Q) {
         case 4: SD_LAUNCH(4); break;
         case 8: SD_LAUNCH(8); break;

@@ -13,7 +13,7 @@ void launch_generic_fill(int Q, int threads, int grid, hipStream_t st, const Chu
                          int chunk_begin, const uint32_t* bases2, const uint32_t* nmask,
                          const uint8_t* tmeta, const int32_t* tend_kd, const int32_t* tend_j,
                          ScoreArgs sc, int rowBytes, uint8_t* ptr, uint64_t row0_base, int32_t* B,
-                         int32_t* argB);
+                         int32_t* argB, const uint16_t* grank, int T, int n_tiles, int32_t* Estate);
 void launch_generic_trace(int n_sub, hipStream_t st, const ChunkDesc* chunks, int chunk_begin,
                           const uint8_t* ptr, uint64_t row0_base, int rowBytes, const int32_t* B,
                           const int32_t* argB, const int32_t* toff, const int32_t* tlen,

@@ -35,8 +35,6 @@ def _decompose_case(c, kernel, tmp_path):
 @pytest.mark.parametrize("name", case_names(include_edthr=True))
 def test_golden_fixture_raw_tsv(name, fam, tmp_path):
     c = load_case(name)
-    if c["ed_thr"] is not None and fam[0] == "generic":
-        pytest.skip("--ed_thr runs on the fast family only")
     try:
         got = _decompose_case(c, fam[1], tmp_path)
     except lib.SdError as e:
@@ -286,7 +284,7 @@ def test_random_template_set_shapes_vs_oracle(oracle, shape):
         try:
             got = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed)
         except lib.SdError as e:
-            assert ed > -1 and e.code == lib.SD_ERR_UNSUPPORTED  # --ed_thr outside the fast family
+            assert ed > -1 and hi > 512 and e.code == lib.SD_ERR_UNSUPPORTED  # --ed_thr: templates of up to 512 bp
             continue
         exp = oracle.decompose(rn, reads, mn, ms, threads=8, sc=sc, part=part, overlap=ov, ed_thr=ed)
         assert got == exp, (shape, sc, ed)
@@ -495,3 +493,46 @@ def test_nw_identity_kernel_equals_host_and_edlib(shape):
     a = lib.identity_segments(bad, starts[:20], ends[:20], tm, False, threads=2, device=0)
     b = lib.identity_segments(bad, starts[:20], ends[:20], tm, False, threads=2)
     assert all((x == y).all() for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("nm,lo,hi", [(100, 165, 178), (260, 150, 176), (70, 300, 480)])
+def test_template_sets_beyond_the_fast_family_vs_oracle(oracle, nm, lo, hi):
+    """Hundreds of monomers (the reference takes any monomer set, main.cpp:187-207): more than 128
+    templates run on the generic family, more than 32 768 template cells on its tiled form (previous row
+    in HBM); with and without --ed_thr (rank table instead of the fast family's lane constants)."""
+    st = synth.Stream(4321, nm)
+    ms = _random_monomers(st, nm, lo, hi)
+    mn = ["m%d" % j for j in range(nm)]
+    reads = []
+    for r in range(3):
+        parts = []
+        while sum(len(x) for x in parts) < 500 + 300 * r:
+            j = int(st.below(1, nm)[0])
+            codes = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), np.frombuffer(ms[j], dtype=np.uint8))
+            x = synth._to_ascii(synth.mutate(codes, st, 0.05, 0.03, 0.03))
+            parts.append(synth.revcomp_bytes(x) if st.below(1, 2)[0] else x)
+        b = bytearray(b"".join(parts))
+        b[len(b) // 2] = ord("N")
+        reads.append(bytes(b))
+    rn = ["r%d" % i for i in range(len(reads))]
+    e = lib.Engine(ms)
+    info = e.info()
+    e.close()
+    assert info["family"] == "generic" and info["sum_template_len"] > (32768 if nm != 100 else 30000)
+    for sc, part, ov, ed in [((-1, -1, -1, 1), 5000, 500, -1), ((-2, -3, -4, 2), 400, 60, -1),
+                             ((-1, -1, -1, 1), 700, 100, 40), ((-1, -1, -1, 1), 5000, 500, 0)]:
+        got = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed)
+        exp = oracle.decompose(rn, reads, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc, part=part, overlap=ov, ed_thr=ed)
+        assert got == exp, (nm, sc, ed)
+
+
+@pytest.mark.parametrize("thr", [0, 12, 40])
+def test_ed_thr_on_the_generic_family_vs_oracle(oracle, thr):
+    """--ed_thr with the generic kernels forced (kept set and tie order through the rank table)."""
+    mn, ms = synth.make_monomers(12, seed=41)
+    rn, rs = synth.make_reads(ms, 2, read_len=9000, seed=43)
+    rs[1] = rs[1][:1500] + b"NNNN" + rs[1][1504:4000]
+    for sc in [(-1, -1, -1, 1), (-1, -2, -1, 1)]:
+        got = lib.decompose(rn, rs, mn, ms, scoring=sc, ed_thr=thr, kernel=lib.KERNEL_GENERIC)
+        assert got == oracle.decompose(rn, rs, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc, ed_thr=thr)
+        assert got == lib.decompose(rn, rs, mn, ms, scoring=sc, ed_thr=thr, kernel=lib.KERNEL_FAST)

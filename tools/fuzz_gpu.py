@@ -39,7 +39,7 @@ t0 = time.time()
 fam = {"fast": 0, "generic": 0}
 for case in range(cases):
     shape = [(1, 5, 40), (3, 20, 90), (6, 100, 200), (12, 160, 180), (25, 150, 190), (50, 100, 180),
-             (64, 165, 178), (4, 300, 500), (2, 1, 30), (10, 60, 64)][rnd(10)]
+             (64, 165, 178), (4, 300, 500), (2, 1, 30), (10, 60, 64), (90, 100, 180), (230, 140, 176)][rnd(12)]
     nm = max(1, shape[0] - rnd(2))
     ms = monomers(nm, shape[1], shape[2], 0.15 if rnd(3) == 0 else 0.0)
     mn = ["m%d" % j for j in range(nm)]
@@ -101,6 +101,7 @@ if len(sys.argv) > 3:   # append to a log (copied to profiles/ after the run): w
     for fn in sorted(os.listdir(cs)):
         if fn.endswith((".hip", ".hpp")):
             src.update(open(os.path.join(cs, fn), "rb").read())
+    os.makedirs(os.path.dirname(os.path.abspath(sys.argv[3])), exist_ok=True)
     with open(sys.argv[3], "a") as f:
         f.write("%s  csrc-sha256 %s  %s\n" % (time.strftime("%Y-%m-%d %H:%M:%S"), src.hexdigest()[:16], summary))
 sys.exit(1 if bad else 0)
