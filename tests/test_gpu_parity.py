@@ -536,3 +536,29 @@ def test_ed_thr_on_the_generic_family_vs_oracle(oracle, thr):
         got = lib.decompose(rn, rs, mn, ms, scoring=sc, ed_thr=thr, kernel=lib.KERNEL_GENERIC)
         assert got == oracle.decompose(rn, rs, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc, ed_thr=thr)
         assert got == lib.decompose(rn, rs, mn, ms, scoring=sc, ed_thr=thr, kernel=lib.KERNEL_FAST)
+
+
+def _final_cases():
+    d = os.path.join(GOLDEN, "final")
+    return sorted(os.listdir(d)) if os.path.isdir(d) else []
+
+
+@pytest.mark.parametrize("name", _final_cases())
+def test_cli_vs_unmodified_reference_cli(name, tmp_path):
+    """The whole command line (native sd_run_files: DP, identities on the device, three TSVs) against the
+    outputs of the UNMODIFIED reference command line committed under tests/golden/final/: raw and _alt by
+    sha256, final byte for byte."""
+    import json
+    d = os.path.join(GOLDEN, "final", name)
+    with open(os.path.join(d, "params.json")) as f:
+        c = json.load(f)
+    out = str(tmp_path / "o")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "stringdecomposer")] +
+                       [os.path.join(GOLDEN, x) for x in c["inputs"]] + ["-o", out, "-t", "8"] + c["args"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]
+    rd = lambda fn: open(os.path.join(out, fn), "rb").read()  # noqa: E731
+    assert hashlib.sha256(rd("final_decomposition_raw.tsv")).hexdigest() == c["raw_sha256"]
+    with open(os.path.join(d, "final.tsv"), "rb") as f:
+        assert rd("final_decomposition.tsv") == f.read()
+    assert hashlib.sha256(rd("final_decomposition_alt.tsv")).hexdigest() == c["alt_sha256"]

@@ -426,3 +426,41 @@ def test_eight_concurrent_host_pipelines_report_aggregate_rate(capsys):
               % (threads, pack / 1e9, asm / 1e9))
     assert all(r["text_bytes"] > 0 and r["rows_per_s"] > 0 for r in res)
     assert pack > 2e8 and asm > 2e8
+
+
+FINAL = os.path.join(GOLDEN, "final")
+
+
+def final_cases():
+    return sorted(os.listdir(FINAL)) if os.path.isdir(FINAL) else []
+
+
+def load_final_case(name):
+    import json
+    with open(os.path.join(FINAL, name, "params.json")) as f:
+        meta = json.load(f)
+    meta["reads"], meta["monomers"] = [os.path.join(GOLDEN, p) for p in meta["inputs"]]
+    with open(os.path.join(FINAL, name, "final.tsv"), "rb") as f:
+        meta["final"] = f.read()
+    return meta
+
+
+@pytest.mark.parametrize("name", final_cases())
+def test_native_post_processing_vs_unmodified_reference_cli(name, tmp_path, oracle):
+    """Final and _alt TSVs of the UNMODIFIED reference command line (tests/golden/make_final_golden.py: the
+    reference's bin/stringdecomposer run here with its own dp binary and its vendored edlib): the raw rows of
+    the oracle must hash to the reference's raw file, and sd_convert_raw_tsv (host identities) must reproduce
+    the final TSV byte for byte and the _alt TSV by sha256 (the whole 2.67 MB file for the test data)."""
+    c = load_final_case(name)
+    raw = oracle.decompose_files(c["reads"], c["monomers"], threads=8)
+    assert hashlib.sha256(raw).hexdigest() == c["raw_sha256"]
+    rawf, fin, alt = str(tmp_path / "raw.tsv"), str(tmp_path / "f.tsv"), str(tmp_path / "f_alt.tsv")
+    with open(rawf, "wb") as f:
+        f.write(raw)
+    a = c["args"]
+    mi = int(a[a.index("-i") + 1]) if "-i" in a else 0
+    lib.convert_raw_tsv(rawf, c["reads"], c["monomers"], fin, alt, mi, "--second-best" in a, device=-1, threads=8)
+    with open(fin, "rb") as f:
+        assert f.read() == c["final"]
+    with open(alt, "rb") as f:
+        assert hashlib.sha256(f.read()).hexdigest() == c["alt_sha256"]
