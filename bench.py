@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 def cpu_baseline(mn, ms, rn, rs, gpu_rows_text):
     """Reference CPU path (`dp -t <threads>`) on a bounded sample of the benchmark reads.  The thread count
-    is swept on a small sub-sample (8 reads) over 16 / 32 / 64 / 128 / 256 threads -- stopping as soon as a
+    is swept on a sub-sample (16 reads) over 4 / 8 / 16 / 32 / 64 / 128 / 256 threads -- stopping as soon as a
     wider run is clearly slower: the reference's OpenMP driver works in groups of 2*t chunks with a barrier
     per group and allocates n*(T+1) vectors per chunk (main.cpp:84-102,156-169), it does not scale to the
     256 host cores -- and the best width is then timed on the whole sample, whose output is also compared
@@ -47,8 +47,8 @@ def cpu_baseline(mn, ms, rn, rs, gpu_rows_text):
     cores = os.cpu_count() or 1
     total_bp = sum(len(s) for s in rs)
     sample = "%d reads x %d bp of the benchmark read set (first reads of rank 0)" % (len(rs), len(rs[0]))
-    widths = sorted({min(cores, w) for w in (16, 32, 64, 128, 256)})
-    sub = min(8, len(rs))
+    widths = sorted({min(cores, w) for w in (4, 8, 16, 32, 64, 128, 256)})
+    sub = min(16, len(rs))
     sub_bp = sum(len(s) for s in rs[:sub])
     have_ref = oracle.have_ref_dp()
     if not have_ref:
@@ -96,6 +96,10 @@ def main():
     ap.add_argument("--kernel", choices=["auto", "generic", "fast"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-reads", type=int, default=32)
+    ap.add_argument("--timed-only", action="store_true",
+                    help="only the timed region (no second pipe mode, no device-resident repeat): for profilers, so "
+                         "that per-kernel averages are those of the timed launches")
+    ap.add_argument("--ed-thr", type=int, default=-1, help="--ed_thr prefilter (profiling the filter kernels; not the headline)")
     ap.add_argument("--pipe-mode", type=int, choices=[0, 1], default=0,
                     help="kernel streams of the timed region: 0 = in order on one stream (clean per-kernel spans), "
                          "1 = library default, traceback overlapped with the next fill; the other one is reported too")
@@ -150,7 +154,8 @@ def main():
         # traceback + compaction on a second, lower-priority stream so that they share the machine with the
         # next batch's fill (about 3 % faster, but the fill's event span then contains traceback work)
         os.environ["SD_PIPE_MODE"] = str(pipe_mode)
-        st = lib.Stream(ms, sub_batches=args.sub_batches, device=local_rank, kernel=kernel, threads=threads)
+        st = lib.Stream(ms, sub_batches=args.sub_batches, device=local_rank, kernel=kernel, threads=threads,
+                        ed_thr=args.ed_thr)
         inf = st.info()
         for _ in range(warmup):
             st.submit(readset)
@@ -180,14 +185,14 @@ def main():
     bp_total = shard.sum_over_ranks(dist, bp_rank, dev)
     n_chunks = lib.chunk_table_size([len(x) for x in rs])
     other = None
-    if ws == 1:   # the other kernel-stream mode, same K steps (secondary figure)
+    if ws == 1 and not args.timed_only:   # the other kernel-stream mode, same K steps (secondary figure)
         odt, _, od, _ = timed_steps(1 - args.pipe_mode, args.steps, min(args.warmup, 1), False)
         other = {"pipe_mode": 1 - args.pipe_mode, "bp_per_s": bp_rank * K / odt, "ms_per_step": odt / K * 1e3,
                  "kernel_event_ms_per_step": {"fill": od["fill_ms"] / K, "traceback": od["trace_ms"] / K}}
 
     # ---- the same K steps with the batch already packed and resident in HBM, one launch per kernel, no
     # overlap: clean per-kernel HIP-event times (device_resident; NOT the headline) ------------------
-    eng = lib.Engine(ms, device=local_rank, kernel=kernel, threads=threads)
+    eng = lib.Engine(ms, device=local_rank, kernel=kernel, threads=threads, ed_thr=args.ed_thr)
     t_load = time.perf_counter()
     eng.load_reads(rs)
     t_load = time.perf_counter() - t_load
@@ -195,13 +200,14 @@ def main():
     if args.resident_stream == "new":   # developer A/B: a created stream instead of the null stream
         _keep = torch.cuda.Stream()
         tstream = _keep.cuda_stream
-    for _ in range(min(args.warmup, 1)):
+    res_steps = 0 if args.timed_only else args.steps
+    for _ in range(min(args.warmup, 1) if res_steps else 0):
         eng.run(tstream)
         eng.total_rows()
     r_fill = r_trace = r_cmp = 0.0
     torch.cuda.synchronize()
     tr0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(res_steps):
         eng.run(tstream)
         eng.total_rows()
         tm = eng.timings()
@@ -220,7 +226,7 @@ def main():
     fill_s = d["fill_ms"] / 1e3 / launches                          # avg duration of one fill launch
     alg_per_launch = alg_bytes * K / launches
     achieved = alg_per_launch / fill_s / 1e9 if fill_s > 0 else 0.0
-    res_fill_s = r_fill / K / 1e3 / max(einfo["fill_launches"], 1)
+    res_fill_s = r_fill / max(res_steps, 1) / 1e3 / max(einfo["fill_launches"], 1)
     res_achieved = alg_bytes / max(einfo["fill_launches"], 1) / res_fill_s / 1e9 if res_fill_s > 0 else 0.0
     traffic = None
     valu = None
@@ -263,7 +269,7 @@ def main():
                    "sum_template_len": sumL, "chunks_per_gpu": n_chunks, "rows_per_gpu": rows,
                    "kernel_family": info["family"], "cells_per_lane": info["cells_per_lane"],
                    "cell_arithmetic": info["cells"] + (" (packed pairs holding exact integers)" if info["cells"] == "f16" else ""),
-                   "sub_batches": args.sub_batches, "host_threads": threads,
+                   "sub_batches": args.sub_batches, "host_threads": threads, "ed_thr": args.ed_thr,
                    "seed": args.seed, "sharding": "reads dealt to ranks in contiguous blocks, no collective"},
         # contract figure: SURVEY 8(d) algorithmic bytes of a fill launch / its HIP-event duration, launches of
         # the timed region
@@ -287,9 +293,10 @@ def main():
         "other_pipe_mode": other,
         "rows_out_per_gpu": rows_out, "hbm_workspace_bytes": einfo["workspace_bytes"],
         # kernels only, batch packed and resident in HBM before the clock starts, one launch per kernel
-        "device_resident": {"bp_per_s": bp_rank * K / dtr, "ms_per_step": dtr / K * 1e3,
-                            "kernel_ms_per_step": {"fill": r_fill / K, "traceback": r_trace / K, "compact": r_cmp / K},
-                            "fill_roofline_frac": res_achieved / HBM_PEAK_GBS, "load_reads_s": t_load},
+        "device_resident": None if not res_steps else {
+            "bp_per_s": bp_rank * res_steps / dtr, "ms_per_step": dtr / res_steps * 1e3,
+            "kernel_ms_per_step": {"fill": r_fill / res_steps, "traceback": r_trace / res_steps, "compact": r_cmp / res_steps},
+            "fill_roofline_frac": res_achieved / HBM_PEAK_GBS, "load_reads_s": t_load},
     }
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
         k = max(1, min(args.cpu_sample_reads, len(rs)))
