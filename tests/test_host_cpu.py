@@ -464,3 +464,9 @@ def test_native_post_processing_vs_unmodified_reference_cli(name, tmp_path, orac
         assert f.read() == c["final"]
     with open(alt, "rb") as f:
         assert hashlib.sha256(f.read()).hexdigest() == c["alt_sha256"]
+
+
+def test_reference_import_path_is_an_alias():
+    """north_star keeps the Python CLI `stringdecomposer.main`: the name resolves to this build's driver."""
+    import stringdecomposer.main as ref_name
+    assert ref_name.main is sdmain.main and ref_name.convert_tsv is sdmain.convert_tsv and ref_name.run is sdmain.run
