@@ -125,9 +125,13 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, ws))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libsd_hip has no CPU fallback)")
+    share = bool(os.environ.get("SD_BENCH_SHARE_GPU"))   # developer smoke test of the N > 1 path on a 1-GPU box:
+    if share:                                             # every rank on GPU 0, host-side (gloo) reductions
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = shard.init_process_group("nccl") if ws > 1 else None
-    dev = torch.device("cuda", local_rank)
+    dist = shard.init_process_group("gloo" if share else "nccl") if ws > 1 else None
+    dev = torch.device("cpu") if share else torch.device("cuda", local_rank)
+    bar_dev = None if (share or not dist) else local_rank
 
     # ---- workload: synthetic reads of this rank (read i depends only on (seed, i)) -------------
     mn, ms = synth.make_monomers(args.monomers, seed=args.seed)
@@ -157,12 +161,12 @@ def main():
         st = lib.Stream(ms, sub_batches=args.sub_batches, device=local_rank, kernel=kernel, threads=threads,
                         ed_thr=args.ed_thr)
         inf = st.info()
-        for _ in range(warmup):
+        for _ in range(max(warmup, 2)):   # at least one step per pipeline slot: buffers of both engines exist
             st.submit(readset)
             st.collect()
         a = st.stats()
         if bracket:
-            shard.barrier(dist, local_rank if dist else None)
+            shard.barrier(dist, bar_dev)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         nrows = 0
@@ -174,7 +178,7 @@ def main():
             nrows = st.collect()
         torch.cuda.synchronize()
         if bracket:
-            shard.barrier(dist, local_rank if dist else None)
+            shard.barrier(dist, bar_dev)
         sec = time.perf_counter() - t0
         b = st.stats()
         st.close()
