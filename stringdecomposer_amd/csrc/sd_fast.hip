@@ -773,7 +773,7 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
                       const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                       const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV,
                       uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order, int n_cu,
-                      const uint32_t* cendoff, const uint32_t* crank) {
+                      const uint32_t* cendoff, const uint32_t* crank, size_t min_lds) {
     const int NW = SD_FILL_NW;
     #ifndef SD_FILL_WPC
 #define SD_FILL_WPC 16   // resident fill waves per CU (4 per SIMD)
@@ -785,7 +785,8 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
                               ckbase, queue, order, n_cu, cendoff, crank);
         return;
     }
-    const size_t lds = (size_t)5 * plan.P4 * 64 * sizeof(uint32_t);
+    // min_lds (pipeline mode 2): ask for at least this much, so that a third workgroup never fits a CU
+    const size_t lds = std::max((size_t)5 * plan.P4 * 64 * sizeof(uint32_t), min_lds);
     const bool ranked = cendoff != nullptr;
 #define SD_FILL_K(PP, RK, HF)                                                                        \
     {                                                                                                \

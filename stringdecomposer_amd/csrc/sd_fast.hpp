@@ -81,7 +81,7 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
                       const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                       const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV,
                       uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order, int n_cu,
-                      const uint32_t* cendoff, const uint32_t* crank);
+                      const uint32_t* cendoff, const uint32_t* crank, size_t min_lds = 0);
 
 // wide variant (sd_fast_wide.hip), called by launch_fast_fill when plan.wide
 void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
