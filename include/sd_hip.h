@@ -92,6 +92,18 @@ int sd_run_files(const char* reads_fa, const char* monomers_fa, const sd_params*
                  const char* final_tsv_out, const char* alt_tsv_out, int32_t min_identity, int32_t second_best,
                  const double* lr_coef, char* errbuf, size_t errlen);
 
+/* The same for one rank of a multi-process launch: the read set is split into `world` contiguous groups of
+ * reads with about equal chunk counts and this call runs group `rank` completely (DP, identities, the three
+ * TSV texts of its reads) into its own files, which the launcher concatenates in rank order.  Only the
+ * reads of the group are alphabet-checked.  info (may be NULL): [0] first read, [1] one past the last,
+ * [2] reads in the file, [3] chunks of this rank.  SD_ERR_UNSUPPORTED (nothing written) when the read set
+ * cannot be split by reads -- one read holds more than half a rank's share, e.g. a single chromosome --
+ * then shard by chunk range (sd_decompose_files_range). */
+int sd_run_files_range(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank,
+                       int32_t world, const char* raw_tsv_out, const char* final_tsv_out,
+                       const char* alt_tsv_out, int32_t min_identity, int32_t second_best,
+                       const double* lr_coef, int64_t* info, char* errbuf, size_t errlen);
+
 /* convert_tsv (main.py:168-184) alone: an existing raw TSV + the two FASTA files -> final TSV and _alt TSV,
  * streamed in batches of reads.  device < 0: host identities (sd_identity_segments). */
 int sd_convert_raw_tsv(const char* raw_tsv, const char* reads_fa, const char* monomers_fa,

@@ -1749,13 +1749,21 @@ int32_t sd_pack_bases(const char* seq, int64_t n, uint32_t* words, uint32_t* nma
 // whole CLI job as one native call: FASTA files -> raw TSV + final TSV + _alt TSV, streamed per
 // device batch (main.py:186-197 run + :168-184 convert_tsv without the round trip through the raw file)
 // -------------------------------------------------------------------------------------------
-int sd_run_files(const char* reads_fa, const char* monomers_fa, const sd_params* p, const char* raw_tsv_out,
-                 const char* final_tsv_out, const char* alt_tsv_out, int32_t min_identity, int32_t second_best,
-                 const double* lr_coef, char* errbuf, size_t errlen) {
+// rank / world: this process handles the reads [lo, hi) of a split of the read set into `world` contiguous
+// groups of about equal chunk counts (world == 1: everything).  *info (may be null): [0] first read, [1] one
+// past the last read, [2] reads in the file, [3] chunks of this rank.  A read set that cannot be split by
+// reads (one read holds more than half a rank's share, e.g. a single chromosome) gives SD_ERR_UNSUPPORTED
+// before anything is written; the caller then shards by chunk range instead.
+static int run_files_impl(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank, int32_t world,
+                          const char* raw_tsv_out, const char* final_tsv_out, const char* alt_tsv_out,
+                          int32_t min_identity, int32_t second_best, const double* lr_coef, int64_t* info,
+                          char* errbuf, size_t errlen) {
     std::string err;
     int rc = validate_params(p, err);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
-    if (!reads_fa || !monomers_fa || !raw_tsv_out || !final_tsv_out || !alt_tsv_out || !lr_coef) return SD_ERR_PARAM;
+    if (!reads_fa || !monomers_fa || !raw_tsv_out || !final_tsv_out || !alt_tsv_out || !lr_coef || world < 1 || rank < 0 ||
+        rank >= world)
+        return SD_ERR_PARAM;
     const bool timing = getenv("SD_TIMING") != nullptr;
     const double t_begin = now_s();
     double t_prev = t_begin;
@@ -1767,29 +1775,55 @@ int sd_run_files(const char* reads_fa, const char* monomers_fa, const sd_params*
     };
     sd::FastaFile rf, mf;
     rc = rf.open(reads_fa, p->threads, err);                                  // main.cpp:394
-    if (rc == SD_OK) rc = rf.validate(0, rf.recs.size(), p->threads, err);
     if (rc == SD_OK) rc = mf.open(monomers_fa, p->threads, err);              // main.cpp:395
     if (rc == SD_OK) rc = mf.validate(0, mf.recs.size(), p->threads, err);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
-    lap("FASTA index + alphabet check");
     std::vector<sd::Seq> monos;
     for (const auto& r : mf.recs) monos.push_back(sd::Seq{std::string(r.name, r.name_len), std::string(r.seq, (size_t)r.len)});
     if (monos.empty()) { set_err(errbuf, errlen, "no monomers"); return SD_ERR_PARAM; }
-    std::vector<ReadView> reads;
-    reads.reserve(rf.recs.size());
+    std::vector<ReadView> all_reads;
+    all_reads.reserve(rf.recs.size());
     for (const auto& r : rf.recs) {
         if (r.len <= 0) { set_err(errbuf, errlen, "ERROR: Sequence " + std::string(r.name, r.name_len) + " is empty"); return SD_ERR_EMPTY; }
-        reads.push_back(ReadView{r.name, r.name_len, r.seq, r.len});
+        all_reads.push_back(ReadView{r.name, r.name_len, r.seq, r.len});
     }
     {
         // SeqIO.to_dict (main.py:65) refuses repeated read ids
         std::vector<std::pair<std::string, size_t>> nm;
-        nm.reserve(reads.size());
-        for (size_t r = 0; r < reads.size(); ++r) nm.emplace_back(std::string(reads[r].name, reads[r].name_len), r);
+        nm.reserve(all_reads.size());
+        for (size_t r = 0; r < all_reads.size(); ++r) nm.emplace_back(std::string(all_reads[r].name, all_reads[r].name_len), r);
         std::sort(nm.begin(), nm.end());
         for (size_t i = 1; i < nm.size(); ++i)
             if (nm[i].first == nm[i - 1].first) { set_err(errbuf, errlen, "Duplicate key '" + nm[i].first + "'"); return SD_ERR_FORMAT; }
     }
+    // this rank's reads: contiguous groups of about equal chunk counts
+    size_t r_lo = 0, r_hi = all_reads.size();
+    if (world > 1) {
+        std::vector<int64_t> cum(all_reads.size() + 1, 0);
+        int64_t biggest = 0;
+        for (size_t r = 0; r < all_reads.size(); ++r) {
+            const int64_t k = sd::chunk_plan(all_reads[r].len, p->part_size, p->overlap, [](int64_t, int32_t) {});
+            cum[r + 1] = cum[r] + k;
+            biggest = std::max(biggest, k);
+        }
+        const int64_t total = cum[all_reads.size()];
+        if (biggest * 2 * world > total) {
+            set_err(errbuf, errlen, "read set cannot be split by reads (one read holds more than half a rank's share)");
+            return SD_ERR_UNSUPPORTED;
+        }
+        auto bound = [&](int g) {
+            const int64_t want = total * g / world;
+            return (size_t)(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
+        };
+        r_lo = std::min(bound(rank), all_reads.size());
+        r_hi = rank + 1 == world ? all_reads.size() : std::min(bound(rank + 1), all_reads.size());
+        if (r_hi < r_lo) r_hi = r_lo;
+    }
+    rc = rf.validate(r_lo, r_hi, p->threads, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    lap("FASTA index + alphabet check");
+    std::vector<ReadView> reads(all_reads.begin() + (long)r_lo, all_reads.begin() + (long)r_hi);
+    if (info) { info[0] = (int64_t)r_lo; info[1] = (int64_t)r_hi; info[2] = (int64_t)all_reads.size(); info[3] = 0; }
     TemplateSet ts(monos);
     sd::PostProcessor pp;
     rc = pp.init(monos, min_identity, second_best != 0, lr_coef, p->device, p->threads, err);
@@ -1806,6 +1840,7 @@ int sd_run_files(const char* reads_fa, const char* monomers_fa, const sd_params*
     job.n_reads = (int32_t)reads.size();
     job.threads = p->threads;
     build_chunk_table(reads, p, job.table, job.nch);
+    if (info) info[3] = (int64_t)job.table.size();
     job.row_off = static_cast<int64_t*>(std::calloc(reads.size() + 1, sizeof(int64_t)));
     Pipeline pipe;
     rc = pipe.create(p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size());
@@ -1883,6 +1918,20 @@ int sd_run_files(const char* reads_fa, const char* monomers_fa, const sd_params*
                      t_post * 1e3, t_io * 1e3, (now_s() - t_begin) * 1e3);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
     return SD_OK;
+}
+
+int sd_run_files(const char* reads_fa, const char* monomers_fa, const sd_params* p, const char* raw_tsv_out,
+                 const char* final_tsv_out, const char* alt_tsv_out, int32_t min_identity, int32_t second_best,
+                 const double* lr_coef, char* errbuf, size_t errlen) {
+    return run_files_impl(reads_fa, monomers_fa, p, 0, 1, raw_tsv_out, final_tsv_out, alt_tsv_out, min_identity, second_best,
+                          lr_coef, nullptr, errbuf, errlen);
+}
+
+int sd_run_files_range(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank, int32_t world,
+                       const char* raw_tsv_out, const char* final_tsv_out, const char* alt_tsv_out, int32_t min_identity,
+                       int32_t second_best, const double* lr_coef, int64_t* info, char* errbuf, size_t errlen) {
+    return run_files_impl(reads_fa, monomers_fa, p, rank, world, raw_tsv_out, final_tsv_out, alt_tsv_out, min_identity,
+                          second_best, lr_coef, info, errbuf, errlen);
 }
 
 // -------------------------------------------------------------------------------------------

@@ -34,7 +34,7 @@ EXPORTS = [
     "sd_stream_create", "sd_stream_destroy", "sd_stream_submit", "sd_stream_collect", "sd_stream_stats",
     "sd_stream_info", "sd_pack_bases", "sd_identity_segments_dev", "sd_nw_release_cache",
     "sd_run_files", "sd_convert_raw_tsv", "sd_decompose_files_range", "sd_assemble_files_tsv",
-    "sd_host_stage_rates",
+    "sd_host_stage_rates", "sd_run_files_range",
 ]
 
 
@@ -113,6 +113,8 @@ def load():
                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     L.sd_run_files.argtypes = [C.c_char_p, C.c_char_p, P(Params), C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32,
                                C.c_int32, P(C.c_double), C.c_char_p, C.c_size_t]
+    L.sd_run_files_range.argtypes = [C.c_char_p, C.c_char_p, P(Params), C.c_int32, C.c_int32, C.c_char_p, C.c_char_p,
+                                     C.c_char_p, C.c_int32, C.c_int32, P(C.c_double), P(C.c_int64), C.c_char_p, C.c_size_t]
     L.sd_convert_raw_tsv.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int32, C.c_int32,
                                      P(C.c_double), C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]
     L.sd_decompose_files_range.argtypes = [C.c_char_p, C.c_char_p, P(Params), C.c_int32, C.c_int32, P(P(Rec)),
@@ -200,6 +202,24 @@ def run_files(reads_fa, monomers_fa, raw_tsv_out, final_tsv_out, alt_tsv_out, mi
                         coef, err, 4096)
     if rc != SD_OK:
         raise SdError(rc, err.value.decode(errors="replace"))
+
+
+def run_files_range(reads_fa, monomers_fa, rank, world, raw_tsv_out, final_tsv_out, alt_tsv_out, min_identity=0,
+                    second_best=False, lr_coef=(-31.48494996, 0.41784018, 0.69186882), **kw):
+    """One rank's group of reads of a multi-process launch, completely (sd_run_files_range) -> (first read, one
+    past the last read, reads in the file, chunks of this rank).  SdError(SD_ERR_UNSUPPORTED) when the read set
+    cannot be split by reads."""
+    L = load()
+    p = make_params(**kw)
+    err = C.create_string_buffer(4096)
+    coef = (C.c_double * 3)(*[float(x) for x in lr_coef])
+    info = (C.c_int64 * 4)()
+    rc = L.sd_run_files_range(os.fsencode(reads_fa), os.fsencode(monomers_fa), C.byref(p), int(rank), int(world),
+                              os.fsencode(raw_tsv_out), os.fsencode(final_tsv_out), os.fsencode(alt_tsv_out),
+                              int(min_identity), 1 if second_best else 0, coef, info, err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+    return tuple(info)
 
 
 def convert_raw_tsv(raw_tsv, reads_fa, monomers_fa, final_tsv_out, alt_tsv_out, min_identity=0, second_best=False,

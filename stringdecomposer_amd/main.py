@@ -364,11 +364,20 @@ def run(sequences, monomers, num_threads, scoring, batch_size, raw_file, ed_thr,
         # one process per GPU, each takes a contiguous range of the global chunk table (shard.py);
         # the records meet on rank 0 through a host-side (gloo) gather -- no device collective.
         dist = shard.init_process_group("gloo")
+        dev = local_rank % max(lib.device_count(), 1)
+        common = dict(scoring=(ins, dels, mm, match), part_size=int(batch_size), overlap=int(overlap), ed_thr=int(ed_thr),
+                      threads=int(num_threads), kernel=kernel, device=dev)
         try:
-            ok = shard.decompose_files_sharded(sequences, monomers, raw_file, dist, scoring=(ins, dels, mm, match),
-                                               part_size=int(batch_size), overlap=int(overlap), ed_thr=int(ed_thr),
-                                               threads=int(num_threads), kernel=kernel,
-                                               device=local_rank % max(lib.device_count(), 1))
+            ok = None
+            if final_file is not None:
+                # a set of reads: every rank runs its group of reads completely (DP + post-processing + text)
+                ok = shard.run_files_sharded(sequences, monomers, raw_file, final_file,
+                                             final_file[:-len(".tsv")] + "_alt.tsv", dist, min_identity=min_identity,
+                                             second_best=second_best, lr_coef=_lr_coef(), **common)
+            if ok is True:
+                return True if rank == 0 else None
+            # a single huge sequence (or no final file wanted): shard by chunk range, rank 0 assembles
+            ok = shard.decompose_files_sharded(sequences, monomers, raw_file, dist, **common)
         finally:
             shard.barrier(dist)
             dist.destroy_process_group()

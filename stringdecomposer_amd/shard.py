@@ -183,3 +183,72 @@ def decompose_files_sharded(reads_fa, monomers_fa, raw_tsv_out, dist, range_fn=N
     keep = {k: v for k, v in params.items() if k in ("scoring", "part_size", "overlap", "threads")}
     lib.assemble_files_tsv(reads_fa, monomers_fa, all_recs, all_off, raw_tsv_out, **keep)
     return True
+
+
+def _copy_into(src, dst, offset):
+    """Copy the file `src` into the existing file `dst` at byte `offset` (ranks do this concurrently)."""
+    n = os.path.getsize(src)
+    with open(src, "rb") as fi, open(dst, "r+b") as fo:
+        done = 0
+        use_cfr = hasattr(os, "copy_file_range")
+        while done < n:
+            if use_cfr:
+                try:
+                    k = os.copy_file_range(fi.fileno(), fo.fileno(), min(n - done, 1 << 30), done, offset + done)
+                except OSError:
+                    use_cfr, k = False, 0
+                if k:
+                    done += k
+                    continue
+                use_cfr = False
+            buf = os.pread(fi.fileno(), min(n - done, 8 << 20), done)
+            if not buf:
+                break
+            os.pwrite(fo.fileno(), buf, offset + done)
+            done += len(buf)
+    if done != n:
+        raise IOError("short copy of %s" % src)
+
+
+def run_files_sharded(reads_fa, monomers_fa, raw_out, final_out, alt_out, dist, run_fn=None, **params):
+    """The multi-process command line on a set of reads: the reads are dealt to the ranks in contiguous groups of
+    about equal chunk counts and EVERY rank runs its group completely on its GPU -- DP, identities, raw / final /
+    _alt TSV text (sd_run_files_range) -- into part files; the parts are then copied, all ranks at once, into
+    the three output files at their offsets.  No rank does another rank's post-processing and nothing but file
+    sizes crosses between processes.  Returns True on every rank, or the string "unsplittable" (nothing
+    written) when one read holds more than half a rank's share -- a single chromosome -- and the job has to be
+    sharded by chunk range instead (decompose_files_sharded).  A failure on any rank is raised on every rank
+    (the lowest failing rank's: the first offending read in file order)."""
+    from . import lib
+    rank, local_rank, ws = world()
+    params = dict(params, device=params.get("device", local_rank))
+    fn = run_fn or lib.run_files_range
+    outs = [raw_out, final_out, alt_out]
+    parts = ["%s.part%d" % (p, rank) for p in outs]
+    failure = None
+    try:
+        fn(reads_fa, monomers_fa, rank, ws, *parts, **params)
+    except lib.SdError as e:
+        failure = (e.code, e.msg)
+    status = [None] * ws
+    dist.all_gather_object(status, failure)
+    first = next((s for s in status if s is not None), None)
+    if first is not None:
+        for p in parts:
+            if os.path.exists(p):
+                os.remove(p)
+        if all(s is not None and s[0] == lib.SD_ERR_UNSUPPORTED for s in status):
+            return "unsplittable"
+        raise lib.SdError(*first)
+    sizes = [None] * ws
+    dist.all_gather_object(sizes, [os.path.getsize(p) for p in parts])
+    if rank == 0:
+        for k, p in enumerate(outs):
+            with open(p, "wb") as f:
+                f.truncate(sum(sz[k] for sz in sizes))
+    dist.barrier()
+    for k, p in enumerate(outs):
+        _copy_into(parts[k], p, sum(sz[k] for sz in sizes[:rank]))
+        os.remove(parts[k])
+    dist.barrier()
+    return True

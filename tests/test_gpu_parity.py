@@ -377,15 +377,25 @@ def test_chunk_range_form_equals_one_shot(oracle):
         lib.decompose_chunk_range(rs, ms, 0, n + 1)
 
 
-def test_cli_two_processes_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("data", ["one_sequence", "read_set"])
+def test_cli_two_processes_on_one_gpu(tmp_path, data):
     """The multi-GPU launch form of the CLI (one process per GPU under torch.distributed.run); here both
-    ranks share GPU 0.  Output files equal the single-process run."""
+    ranks share GPU 0.  Output files equal the single-process run.  One sequence: sharded by chunk range, rank 0
+    assembles; a read set: every rank runs its group of reads completely and the parts are spliced."""
     td = os.path.join(GOLDEN, "test_data")
+    rfa, mfa = os.path.join(td, "read.fa"), os.path.join(td, "DXZ1_star_monomers.fa")
+    if data == "read_set":
+        mn, ms = synth.make_monomers(12, seed=71)
+        rn, rs = synth.make_reads(ms, 7, read_len=21000, seed=72)
+        rs[3] = rs[3][:4000]
+        rfa, mfa = str(tmp_path / "r.fa"), str(tmp_path / "m.fa")
+        synth.write_fasta(rfa, rn, rs, width=60)
+        synth.write_fasta(mfa, mn, ms)
     outs = []
     for nproc in (1, 2):
         out = str(tmp_path / ("o%d" % nproc))
-        cmd = [sys.executable, os.path.join(ROOT, "bin", "stringdecomposer"), os.path.join(td, "read.fa"),
-               os.path.join(td, "DXZ1_star_monomers.fa"), "-o", out, "-t", "4", "--second-best"]
+        cmd = [sys.executable, os.path.join(ROOT, "bin", "stringdecomposer"), rfa,
+               mfa, "-o", out, "-t", "4", "--second-best"]
         if nproc > 1:
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                    "--master-addr", "127.0.0.1", "--master-port", "29631"] + cmd[1:]

@@ -200,3 +200,91 @@ def test_file_form_sharded_world_size_2_and_uniform_failure(tmp_path):
         else:
             msg = "ERROR: Sequence bad1 contains undefined symbol (not ACGT): x"
             assert [r[1:] for r in res] == [("err", (255, msg)), ("err", (255, msg))]
+
+
+# ---- read-granular form: every rank runs its reads completely ------------------------------------------
+def _checker_run_files_range(reads_fa, monomers_fa, rank, ws, raw_out, final_out, alt_out, min_identity=0,
+                             second_best=False, lr_coef=None, scoring=(-1, -1, -1, 1), part_size=5000, overlap=500, **_):
+    """lib.run_files_range with the CPU oracle standing in for the DP and the host identities for the device
+    kernel (test infrastructure): same split of the reads, same three part files."""
+    from oracle import binding as oracle
+    from stringdecomposer_amd import lib
+    names, seqs, _ = lib.fasta_load(reads_fa)
+    nch = [len(lib.chunk_plan(len(s), part_size, overlap)) for s in seqs]
+    total, cum = sum(nch), [0]
+    for k in nch:
+        cum.append(cum[-1] + k)
+    if max(nch) * 2 * ws > total:
+        raise lib.SdError(lib.SD_ERR_UNSUPPORTED, "read set cannot be split by reads")
+    import bisect
+    bound = lambda g: bisect.bisect_left(cum, total * g // ws)  # noqa: E731
+    lo, hi = bound(rank), (len(seqs) if rank + 1 == ws else bound(rank + 1))
+    mnames, mseqs, _ = lib.fasta_load(monomers_fa)
+    raw = oracle.decompose(names[lo:hi], seqs[lo:hi], mnames, mseqs, sc=scoring, part=part_size, overlap=overlap) if hi > lo else b""
+    with open(raw_out, "wb") as f:
+        f.write(raw)
+    lib.convert_raw_tsv(raw_out, reads_fa, monomers_fa, final_out, alt_out, min_identity, second_best,
+                        lr_coef or (-31.48494996, 0.41784018, 0.69186882), device=-1, threads=2)
+    return lo, hi, len(seqs), sum(nch[lo:hi])
+
+
+def _run_files_worker(rank, ws, port, q, d, reads_name):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ws),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from stringdecomposer_amd import lib
+    dist = shard.init_process_group("gloo")
+    out = os.path.join(d, "o_" + reads_name)
+    try:
+        ok = shard.run_files_sharded(os.path.join(d, reads_name), os.path.join(d, "m.fa"), out + "_raw.tsv", out + ".tsv",
+                                     out + "_alt.tsv", dist, run_fn=_checker_run_files_range, second_best=True,
+                                     scoring=(-1, -2, -1, 1), part_size=500, overlap=100, threads=2)
+        q.put((rank, "ok", ok))
+    except lib.SdError as e:
+        q.put((rank, "err", (e.code, e.msg)))
+    dist.destroy_process_group()
+
+
+def test_read_granular_sharding_world_size_2(tmp_path):
+    """run_files_sharded: every rank runs its group of reads completely and the part files land in the three
+    outputs at their offsets == the single-process result; a read set dominated by one sequence is refused
+    uniformly ("unsplittable") so that the launcher can fall back to chunk-range sharding."""
+    from oracle import binding as oracle
+    from stringdecomposer_amd import lib
+    mn, ms = synth.make_monomers(3, seed=2)
+    ms = [m[:60] for m in ms]
+    names, seqs = synth.make_reads(ms, 7, read_len=900, seed=5)
+    seqs[2] = seqs[2][:333]
+    n2, s2 = synth.make_reads(ms, 1, read_len=30000, seed=6)
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "many.fa"), names, seqs, width=70)
+    synth.write_fasta(os.path.join(d, "one.fa"), ["chr"] + names[:2], list(s2) + seqs[:2])
+    synth.write_fasta(os.path.join(d, "m.fa"), mn, ms)
+    for reads_name in ("many.fa", "one.fa"):
+        ws, port = 2, _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_run_files_worker, args=(r, ws, port, q, d, reads_name)) for r in range(ws)]
+        for p in ps:
+            p.start()
+        res = sorted(q.get(timeout=180) for _ in range(ws))
+        for p in ps:
+            p.join(60)
+            assert p.exitcode == 0
+        out = os.path.join(d, "o_" + reads_name)
+        if reads_name == "one.fa":
+            assert [r[1:] for r in res] == [("ok", "unsplittable")] * 2
+            assert not os.path.exists(out + ".tsv") and not any(".part" in f for f in os.listdir(d))
+            continue
+        assert [r[1:] for r in res] == [("ok", True)] * 2
+        raw = oracle.decompose(names, seqs, mn, ms, sc=(-1, -2, -1, 1), part=500, overlap=100)
+        with open(out + "_raw.tsv", "rb") as f:
+            assert f.read() == raw
+        exp_raw = os.path.join(d, "exp_raw.tsv")
+        with open(exp_raw, "wb") as f:
+            f.write(raw)
+        lib.convert_raw_tsv(exp_raw, os.path.join(d, "many.fa"), os.path.join(d, "m.fa"), os.path.join(d, "exp.tsv"),
+                            os.path.join(d, "exp_alt.tsv"), 0, True, device=-1, threads=2)
+        for a, b in ((out + ".tsv", "exp.tsv"), (out + "_alt.tsv", "exp_alt.tsv")):
+            with open(a, "rb") as f, open(os.path.join(d, b), "rb") as g:
+                assert f.read() == g.read()
+        assert not any(".part" in f for f in os.listdir(d))
