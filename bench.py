@@ -100,10 +100,11 @@ def main():
                     help="only the timed region (no second pipe mode, no device-resident repeat): for profilers, so "
                          "that per-kernel averages are those of the timed launches")
     ap.add_argument("--ed-thr", type=int, default=-1, help="--ed_thr prefilter (profiling the filter kernels; not the headline)")
-    ap.add_argument("--pipe-mode", type=int, choices=[0, 1, 2], default=0,
-                    help="kernel streams of the timed region: 0 = in order on one stream (clean per-kernel spans), "
-                         "2 = library default (traceback and the next fill overlap the current fill's drain), 1 = traceback "
-                         "overlap only; with 0 the default mode is timed as well and reported as other_pipe_mode")
+    ap.add_argument("--pipe-mode", type=int, choices=[0, 1, 2], default=2,
+                    help="kernel streams of the timed region: 2 = the library default (traceback and the next fill move into "
+                         "the current fill's drain; kernel event spans overlap), 0 = every kernel in order on one stream "
+                         "(clean per-kernel spans), 1 = traceback overlap only; the other of {2, 0} is timed as well and "
+                         "reported as other_pipe_mode")
     ap.add_argument("--resident-stream", choices=["null", "new"], default="null")
     ap.add_argument("--sub-batches", type=int, default=1,
                     help="device batches per step (two batches are in flight, across steps; 1 is fastest: the "
@@ -278,7 +279,8 @@ def main():
                    "sub_batches": args.sub_batches, "host_threads": threads, "ed_thr": args.ed_thr,
                    "seed": args.seed, "sharding": "reads dealt to ranks in contiguous blocks, no collective"},
         # contract figure: SURVEY 8(d) algorithmic bytes of a fill launch / its HIP-event duration, launches of
-        # the timed region
+        # the timed region (in the default stream mode a fill's span contains the neighbouring batch's traceback
+        # and the drain hand-over; isolated_* = the same kernel launched alone, from the device_resident steps)
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": None if traffic is None else
@@ -287,6 +289,8 @@ def main():
                      "kernel": kname,
                      "algorithmic_bytes_per_launch": alg_per_launch,
                      "avg_launch_ms": fill_s * 1e3, "launches_timed": launches, "valu_issue": valu,
+                     "isolated_avg_launch_ms": res_fill_s * 1e3 if res_steps else None,
+                     "isolated_frac": res_achieved / HBM_PEAK_GBS if res_steps else None,
                      "binding_resource": "VALU issue slots (the fill writes 0.28x the algorithmic bytes: pointers are "
                                          "recomputed by the traceback, not stored); the HBM fraction is the contract's "
                                          "notional figure",

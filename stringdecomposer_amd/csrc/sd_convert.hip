@@ -5,6 +5,7 @@
 // implementation (sd_post.hip) otherwise or for input the kernel does not take.
 #include <algorithm>
 #include <cctype>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -112,6 +113,9 @@ int PostProcessor::identities(const std::vector<std::pair<const char*, int64_t>>
 }
 
 namespace {
+inline double now_seconds() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 inline void put_f2(std::string& o, double v) {
     char b[64];
     const int n = std::snprintf(b, sizeof b, "%.2f", v);   // == Python "{:.2f}".format(v)
@@ -123,6 +127,7 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
                            std::string& alt, std::string& err) {
     const int64_t nB = row_off[n_reads];
     if (nB == 0) return SD_OK;
+    const double t_0 = now_seconds();
     const int T = (int)il_seq.size();
     const int nK = (int)keys.size();
     // text = the reads that have blocks, concatenated; blocks never cross a read
@@ -147,6 +152,7 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
             pos += reads[r].len;
         }
     }
+    const double t_a = now_seconds();
     std::vector<double> vals, hvals;
     int rc;
     if (!second_best) {
@@ -160,6 +166,7 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
         rc = identities(spans, seg_start, seg_len, nullptr, true, hvals, err);
         if (rc) return rc;
     }
+    const double t_b = now_seconds();
     // rows -> text, in slices of blocks formatted by all threads
     const int64_t grain = second_best ? 64 : 2048;
     const int64_t n_sl = (nB + grain - 1) / grain;
@@ -234,6 +241,7 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
             }
         }
     });
+    const double t_c = now_seconds();
     size_t tf = fin.size(), ta = alt.size();
     for (const std::string& p : pf) tf += p.size();
     for (const std::string& p : pa) ta += p.size();
@@ -241,6 +249,10 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
     alt.reserve(ta);
     for (const std::string& p : pf) fin += p;
     for (const std::string& p : pa) alt += p;
+    t_prepare += t_a - t_0;
+    t_identity += t_b - t_a;
+    t_format += t_c - t_b;
+    t_concat += now_seconds() - t_c;
     return SD_OK;
 }
 

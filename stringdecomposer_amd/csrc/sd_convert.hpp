@@ -29,6 +29,7 @@ class PostProcessor {
                 std::string& alt, std::string& err);
     int tmpl_of_name(const std::string& nm) const;   // first template of that name in the DP's order, -1 if none
     std::vector<std::string> tname;                  // the DP's template names: m, ..., m', ...
+    double t_prepare = 0, t_identity = 0, t_format = 0, t_concat = 0;   // seconds spent in process(), by stage
 
   private:
     int identities(const std::vector<std::pair<const char*, int64_t>>& spans, const std::vector<int64_t>& seg_start,

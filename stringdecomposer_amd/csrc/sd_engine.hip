@@ -910,6 +910,7 @@ struct Pipeline {
             budget = std::min<int64_t>(budget, (int64_t)(0.27 * (double)(free_b + held_bytes()) / per_row));
             budget = std::max<int64_t>(budget, (int64_t)p.part_size + p.overlap);
         }
+        if (const char* ev = getenv("SD_BATCH_ROWS")) { const long long v = atoll(ev); if (v > 0) budget = v; }  // developer A/B
         if (p.max_batch_rows > 0) budget = p.max_batch_rows;  // explicit cap (tests, small GPUs)
         return budget;
     }
@@ -1916,6 +1917,9 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         std::fprintf(stderr, "[sd timing] %zu batches: pack+enqueue %.1f ms, wait %.1f ms, raw text %.1f ms, post-processing %.1f ms, "
                      "file writes %.1f ms, total %.1f ms\n", batches.size(), pipe.pack_s * 1e3, pipe.wait_s * 1e3, t_fmt * 1e3,
                      t_post * 1e3, t_io * 1e3, (now_s() - t_begin) * 1e3);
+    if (timing)
+        std::fprintf(stderr, "[sd timing] post-processing: segments %.1f ms, identities %.1f ms, text %.1f ms, concatenation %.1f ms\n",
+                     pp.t_prepare * 1e3, pp.t_identity * 1e3, pp.t_format * 1e3, pp.t_concat * 1e3);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
     return SD_OK;
 }
