@@ -896,13 +896,14 @@ struct Pipeline {
         mlen.assign(mono_lens, mono_lens + n_mono);
         return sd_engine_create(&eng[0], &p, mseq.data(), mlen.data(), n_mono, eb, sizeof eb);
     }
-    // rows one batch may hold: <= 128 M (~2400 reads of 50 kb) and <= 27 % of the free HBM.  The kernels are
-    // persistent -- 4096 resident waves pull chunks from a queue -- so a launch is efficient only with a
-    // few chunks per wave, and every launch ends with a drain of about one chunk time: batches are kept as
-    // large as the budget allows (C2's 10 000 chunks are ONE batch; cutting them into 4 x 2 500 costs 1.4x,
-    // measured) and overlap comes from pipelining whole batches.
+    // rows one batch may hold: <= 64 M (~1200 reads of 50 kb, 18 GB of checkpoints) and <= 27 % of the free HBM.
+    // The kernels are persistent -- 4096 resident waves pull chunks from a queue -- so a launch is efficient
+    // only with a few chunks per wave: batches are kept large (C2's 10 000 chunks are ONE batch; cutting them
+    // into 4 x 2 500 costs 1.4x, measured) and overlap comes from pipelining whole batches.  Larger batches
+    // would not pay: the launch drain they amortise is hidden by the default stream mode, and multi-ten-GB
+    // allocations make a process start slow right after another one released the memory.
     int64_t row_budget() const {
-        int64_t budget = (int64_t)128 << 20;
+        int64_t budget = (int64_t)64 << 20;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             // per row: B + argB + records (24 B) + fast-family checkpoints (P*256 B every FAST_R rows)
