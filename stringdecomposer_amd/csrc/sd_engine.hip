@@ -1844,6 +1844,11 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     build_chunk_table(reads, p, job.table, job.nch);
     if (info) info[3] = (int64_t)job.table.size();
     job.row_off = static_cast<int64_t*>(std::calloc(reads.size() + 1, sizeof(int64_t)));
+    if (!job.row_off) {
+        for (FILE* f : {fr, ff, fa}) std::fclose(f);
+        set_err(errbuf, errlen, "out of host memory");
+        return SD_ERR_INTERNAL;
+    }
     Pipeline pipe;
     rc = pipe.create(p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size());
     if (rc) err = pipe.eb;

@@ -572,3 +572,25 @@ def test_cli_vs_unmodified_reference_cli(name, tmp_path):
     with open(os.path.join(d, "final.tsv"), "rb") as f:
         assert rd("final_decomposition.tsv") == f.read()
     assert hashlib.sha256(rd("final_decomposition_alt.tsv")).hexdigest() == c["alt_sha256"]
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the fields the driver parses (metric / value / unit / n_gpus / steps /
+    warmup / ms_per_step / scaling / dtype / data / config.workload / roofline / cpu_baseline); small workload."""
+    import json
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--reads", "120",
+                        "--cpu-sample-reads", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["unit"] == "bp/s" and j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["higher_is_better"] is True and j["vs_baseline"] is None and j["data"] == "synthetic" and j["dtype"] == "f16"
+    assert j["value"] > 1e8 and abs(j["value"] - 120 * 50000 / (j["ms_per_step"] / 1e3)) / j["value"] < 1e-6
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["isolated_frac"] > 0 and r["path_frac"] > 0
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["parity_on_sample"] is True and c["cores"] >= 1 and c["value"] > 0
+    assert j["other_pipe_mode"]["pipe_mode"] == 0 and j["device_resident"]["bp_per_s"] > 0
