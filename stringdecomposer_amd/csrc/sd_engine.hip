@@ -943,7 +943,9 @@ struct Pipeline {
         const char* ne = getenv("SD_PIPE_NULL");
         if (ne && ne[0] == '1') return;   // kernels on the null stream
         if (hipStreamCreateWithPriority(&fill_st, hipStreamNonBlocking, prio ? hi : 0) != hipSuccess) fill_st = nullptr;
-        if (mode >= 1 && fill_st && hipStreamCreateWithPriority(&trace_st, hipStreamNonBlocking, prio ? lo : 0) != hipSuccess)
+        const char* te = getenv("SD_PIPE_TRACE_PRIO");   // developer A/B: "hi" = traceback stream as urgent as the fills
+        if (mode >= 1 && fill_st &&
+            hipStreamCreateWithPriority(&trace_st, hipStreamNonBlocking, prio ? ((te && te[0] == 'h') ? hi : lo) : 0) != hipSuccess)
             trace_st = nullptr;
         if (mode == 2 && fill_st && hipStreamCreateWithPriority(&fill_st2, hipStreamNonBlocking, prio ? hi : 0) != hipSuccess)
             fill_st2 = nullptr;

@@ -8,8 +8,7 @@ j=json.loads(open("gpurun_out/r02d/$name.json").read().strip().splitlines()[-1])
 print("$name value %.3f G  ms/step %.2f" % (j["value"]/1e9, j["ms_per_step"]), {k:round(v,2) for k,v in j["kernel_ms_per_step"].items() if k!="note"}, {k:round(v,2) for k,v in j["host_ms_per_step"].items()})
 PY
 }
-EXTRA="--pipe-mode 0" run m0
-EXTRA="--pipe-mode 1" run m1
-EXTRA="--pipe-mode 2" run m2
-EXTRA="--pipe-mode 2 --steps 30" run m2_k30
-EXTRA="--pipe-mode 1 --steps 30" run m1_k30
+EXTRA="--pipe-mode 2 --steps 20" run m2
+EXTRA="--pipe-mode 2 --steps 20" run m2_q8 GPU_MAX_HW_QUEUES=8
+EXTRA="--pipe-mode 2 --steps 20" run m2_q8_prio0 GPU_MAX_HW_QUEUES=8 SD_PIPE_PRIO=0
+EXTRA="--pipe-mode 2 --steps 20" run m2_q16 GPU_MAX_HW_QUEUES=16
