@@ -183,7 +183,7 @@ struct sd_engine {
     sd::FastPlan fplan;
     DevBuf<uint32_t> d_ftable;       // LDS image of the (mm - del) table
     DevBuf<uint32_t> d_flane;        // per-lane constants
-    DevBuf<uint16_t> d_fslot;        // slot of template cell (j,k) in the lane layout
+    DevBuf<uint32_t> d_fslot;        // (wave, slot, virtual lane) of template cell (j,k) in the lane layout
     DevBuf<uint8_t> d_ftcodes;       // base code of template cell (j,k)
     DevBuf<uint32_t> d_fckpt;        // checkpoints
     DevBuf<int32_t> d_fckbase;       // per-checkpoint rebase values
@@ -391,8 +391,11 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
         int family = p->kernel;
         std::string why;
         const bool fast_ok = sd::fast_plan_build(e->tseq, e->sc, p->part_size + p->overlap, e->fplan, why);
-        if (family == 0) family = fast_ok ? 2 : 1;
-        if (family == 2 && !fast_ok) {
+        // the multi-wave wide layout has no ranked (--ed_thr) variant: such jobs run on the generic family
+        const bool fast_usable = fast_ok && !(e->fplan.waves > 1 && p->ed_thr > -1);
+        if (family == 0) family = fast_usable ? 2 : 1;
+        if (family == 2 && fast_ok && !fast_usable) why = "--ed_thr with more than 128 templates runs on the generic family";
+        if (family == 2 && !fast_usable) {
             set_err(errbuf, errlen, "fast kernel family not applicable: " + why);
             return SD_ERR_UNSUPPORTED;
         }
@@ -573,7 +576,7 @@ static int load_chunks_impl(sd_engine* e, const std::vector<const char*>& cptr,
                 e->d_cendoff.alloc(C * 64);
                 e->d_crank.alloc(C * 64);
             }
-            e->d_fckpt.alloc((size_t)nck * (size_t)e->fplan.P * 64);
+            e->d_fckpt.alloc((size_t)nck * (size_t)e->fplan.P * 64 * (size_t)e->fplan.waves);
             e->d_fckbase.alloc((size_t)nck + 1);
             ensure_events(e->ev_fill, 1);
             ensure_events(e->ev_trace, 1);
@@ -814,7 +817,7 @@ int sd_engine_info(sd_engine* e, int64_t info[8]) {
     info[1] = e->sumL;
     info[2] = (int64_t)e->chunks.size();
     info[3] = e->rows;
-    info[4] = e->family | ((e->family == 1 ? 0 : e->fplan.wide ? (e->fplan.f16 ? 4 : 3) : e->fplan.f16 ? 2 : 1) << 8);
+    info[4] = e->family | ((e->family == 1 ? 0 : e->fplan.waves > 1 ? 5 : e->fplan.wide ? (e->fplan.f16 ? 4 : 3) : e->fplan.f16 ? 2 : 1) << 8);
     info[5] = e->family == 1 ? e->Q : e->fplan.P;
     info[6] = (int64_t)e->workspace_bytes();
     info[7] = e->family == 1 ? (int64_t)e->subs.size() : 1;
@@ -907,7 +910,7 @@ struct Pipeline {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             // per row: B + argB + records (24 B) + fast-family checkpoints (P*256 B every FAST_R rows)
-            const double per_row = 26.0 + (eng[0]->family == 2 ? eng[0]->fplan.P * 256.0 / sd::FAST_R : 0.0);
+            const double per_row = 26.0 + (eng[0]->family == 2 ? eng[0]->fplan.P * 256.0 * eng[0]->fplan.waves / sd::FAST_R : 0.0);
             budget = std::min<int64_t>(budget, (int64_t)(0.27 * (double)(free_b + held_bytes()) / per_row));
             budget = std::max<int64_t>(budget, (int64_t)p.part_size + p.overlap);
         }

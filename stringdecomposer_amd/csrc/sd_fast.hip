@@ -336,13 +336,13 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
 template <int QK>
 __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_trace(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
-    const uint32_t* __restrict__ nmask, const uint16_t* __restrict__ slot_of,
+    const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ slot_of,
     const uint8_t* __restrict__ tcodes, const uint32_t* __restrict__ lane_consts,
     const int32_t* __restrict__ toff, const int32_t* __restrict__ tlen, ScoreArgs sc, int P,
     const int32_t* __restrict__ B, const int32_t* __restrict__ argV,
     const uint32_t* __restrict__ ckpt, const int32_t* __restrict__ ckbase,
     DevRec* __restrict__ recs, int32_t* __restrict__ rec_cnt, int* __restrict__ queue,
-    const int* __restrict__ order, int ckf16) {
+    const int* __restrict__ order, int ckf16, int bshift, int W) {
     constexpr int QP = QK <= 4 ? 4 : 8;       // cells per lane rounded up to whole int4 loads
     using pt_t = std::conditional_t<(QK <= 4), uint8_t, uint16_t>;
     __shared__ pt_t pt_all[4][FAST_R][64];      // 2-bit moves of the lane's cells
@@ -358,15 +358,16 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
     const int n = cd.n;
     ReadCursor rc{bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr};
     const int32_t* BVc = B + cd.row0 + (uint64_t)c;  // (B << 7) | arg-max virtual lane
-    auto Bof = [&](int r) { return BVc[r] >> 7; };
-    auto Vof = [&](int r) { return BVc[r] & 127; };
+    const int bmask = (1 << bshift) - 1;   // arg-max field: (wave << 7) | virtual lane
+    auto Bof = [&](int r) { return BVc[r] >> bshift; };
+    auto Vof = [&](int r) { return BVc[r] & bmask; };
     DevRec* out = recs + cd.row0;
     const int ins = sc.ins, del = sc.del;
     const int mD = sc.match - sc.del, xD = sc.mismatch - sc.del;
 
     auto tmpl_of = [&](int v) {
-        const uint32_t t = lane_consts[(v & 63) * FAST_LANE_WORDS + FLC_TMPL];
-        return (int)((v >> 6) ? (t >> 16) : (t & 0xffffu));
+        const uint32_t t = lane_consts[(((v >> 7) << 6) | (v & 63)) * FAST_LANE_WORDS + FLC_TMPL];
+        return (int)(((v >> 6) & 1) ? (t >> 16) : (t & 0xffffu));
     };
 
     int cnt = 0;
@@ -446,11 +447,11 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
             } else {
                 const int q0 = a / FAST_R - 1;
                 const int32_t cb = ckbase[cd.pad + q0];
-                const uint32_t* ckq = ckpt + ((uint64_t)cd.pad + q0) * (uint64_t)(P * 64);
+                const uint32_t* ckq = ckpt + ((uint64_t)cd.pad + q0) * (uint64_t)W * (uint64_t)(P * 64);
 #pragma unroll
                 for (int q = 0; q < QQ; ++q) {
-                    const int v = slot[q] & 127, s = slot[q] >> 7;
-                    const uint32_t wv = ckq[s * 64 + (v & 63)];
+                    const int v = slot[q] & 127, s = (slot[q] >> 7) & 511, wv_ = slot[q] >> 16;
+                    const uint32_t wv = ckq[(wv_ * P + s) * 64 + (v & 63)];
                     const uint32_t hw = (v >> 6) ? (wv >> 16) : (wv & 0xffffu);
                     const int32_t Ev = cb + (ckf16 ? (int)(float)__builtin_bit_cast(_Float16, (unsigned short)hw)
                                                    : (int)(short)hw);
@@ -605,14 +606,16 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     bool wide = false;
     if (P == 0) {
         // wide layout: one template per virtual lane
-        if (T > 128) { why = "more than 128 templates"; return false; }
+        if (T > 1024) { why = "more than 1024 templates"; return false; }
         if ((int64_t)(3 * Lmax + 2 * FAST_REBASE + 4) * maxabs > 8000) { why = "scores too large for the wide layout"; return false; }
         for (int p : FAST_WIDE_P_LIST)
             if (p >= Lmax) { P = p; break; }
         if (P == 0) { why = "template longer than the widest layout"; return false; }
         split = std::min(T, 64);
         wide = true;
+        if (T > 128) plan.waves = (T + 127) / 128;   // multi-wave wide layout: wave w holds templates [128 w, 128 w + 128)
     }
+    const int W = plan.waves;
 
     plan.wide = wide;
     {
@@ -631,7 +634,10 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     if (plan.Qk == 7) plan.Qk = 8;
     plan.vlane0.assign((size_t)T, 0);
     int Vmax = 1;
-    {
+    if (W > 1) {
+        for (int j = 0; j < T; ++j) plan.vlane0[(size_t)j] = j;   // global virtual lane = (wave << 7) | (plane << 6) | lane
+        plan.bshift = 10;
+    } else {
         int v = 0;
         for (int j = 0; j < T; ++j) {
             if (j == split) v = 64;
@@ -651,7 +657,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     }
 
     // per virtual lane: owner template and index inside it
-    std::vector<int> owner(128, -1), uidx(128, 0), nv(128, 0);
+    std::vector<int> owner((size_t)128 * W, -1), uidx((size_t)128 * W, 0), nv((size_t)128 * W, 0);
     for (int j = 0; j < T; ++j) {
         const int V = ((int)tseq[(size_t)j].size() + P - 1) / P;
         for (int u = 0; u < V; ++u) {
@@ -664,9 +670,9 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         const uint32_t h = (uint32_t)val & 0xffffu;
         w = plane ? ((w & 0x0000ffffu) | (h << 16)) : ((w & 0xffff0000u) | h);
     };
-    plan.lane_consts.assign((size_t)64 * FAST_LANE_WORDS, 0u);
-    for (int v = 0; v < 128; ++v) {
-        const int plane = v >> 6, lane = v & 63;
+    plan.lane_consts.assign((size_t)64 * W * FAST_LANE_WORDS, 0u);
+    for (int v = 0; v < 128 * W; ++v) {
+        const int plane = (v >> 6) & 1, lane = ((v >> 7) << 6) | (v & 63);   // lane index incl. the wave
         uint32_t* lc = &plan.lane_consts[(size_t)lane * FAST_LANE_WORDS];
         const int j = owner[(size_t)v];
         const bool start = j < 0 || uidx[(size_t)v] == 0;
@@ -703,6 +709,34 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
             const char* force = getenv("SD_FILL_CELLS");
             plan.f16 = bf_ok && ub <= 2040 && !(force && force[0] == 'i');
         }
+        if (W > 1) {
+            // multi-wave wide layout (sd_fast_wn.hip): LDS holds the template base codes, [wave][G][2 halves][64
+            // lanes][4 dwords], bytes as above; code 7 = padding; the two bf8 table bytes travel as kernel arguments
+            if (!plan.f16) { why = "more than 128 templates need bf8-exact table values and the fp16 score range"; return false; }
+            plan.bf8_match = (uint32_t)mb & 0xffu;
+            plan.bf8_mismatch = (uint32_t)xb & 0xffu;
+            plan.table.assign((size_t)W * G * 512, 0x07070707u);
+            int64_t sumLw = 0;
+            for (const std::string& s : tseq) sumLw += (int64_t)s.size();
+            plan.slot_of.assign((size_t)sumLw, 0);
+            plan.tcodes.assign((size_t)sumLw, 0);
+            int64_t xw = 0;
+            for (int j = 0; j < T; ++j) {
+                const std::string& s = tseq[(size_t)j];
+                const int wv = j >> 7, plane = (j >> 6) & 1, lane = j & 63;
+                for (int k = 0; k < (int)s.size(); ++k, ++xw) {
+                    const int cd = code_of(s[(size_t)k]);
+                    plan.tcodes[(size_t)xw] = (uint8_t)cd;
+                    plan.slot_of[(size_t)xw] = ((uint32_t)wv << 16) | ((uint32_t)k << 7) | (uint32_t)(j & 127);
+                    const int g = k / 16, s16 = k & 15, h = s16 >> 3, d = (s16 & 7) >> 1, odd = s16 & 1;
+                    uint32_t& w = plan.table[((((size_t)wv * G + g) * 2 + h) * 64 + lane) * 4 + d];
+                    const int sh = 16 * odd + 8 * plane;
+                    w = (w & ~(0xffu << sh)) | ((uint32_t)cd << sh);
+                }
+            }
+            plan.ok = true;
+            return true;
+        }
         plan.table.assign((size_t)5 * G * 512, plan.f16 ? 0xFCFCFCFCu : 0x80808080u);
         auto putb = [&](int grp, int v, int slot16, int val) {
             if (plan.f16) val = val == md ? mb : xb;
@@ -722,7 +756,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
             for (int k = 0; k < (int)s.size(); ++k, ++xw) {
                 const int cd = code_of(s[(size_t)k]);
                 plan.tcodes[(size_t)xw] = (uint8_t)cd;
-                plan.slot_of[(size_t)xw] = (uint16_t)((k << 7) | v);
+                plan.slot_of[(size_t)xw] = (uint32_t)((k << 7) | v);
                 for (int b = 0; b < 5; ++b) putb(b * G + k / 16, v, k & 15, cd == b ? md : xd);
             }
         }
@@ -744,7 +778,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
             const int plane = v >> 6, lane = v & 63;
             const int cd = code_of(s[(size_t)k]);
             plan.tcodes[(size_t)x] = (uint8_t)cd;
-            plan.slot_of[(size_t)x] = (uint16_t)((slot << 7) | v);
+            plan.slot_of[(size_t)x] = (uint32_t)((slot << 7) | v);
             for (int b = 0; b < 5; ++b) {
                 const int val = (cd == b ? sc.match : sc.mismatch) - sc.del - sc.ins;
                 uint32_t& w = plan.table[(((size_t)b * (P4 / 4) + slot / 4) * 64 + lane) * 4 + (slot & 3)];
@@ -780,6 +814,11 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
 #endif
     const int grid = std::min((n_chunks + NW - 1) / NW, (SD_FILL_WPC / NW) * n_cu);  // persistent
     (void)hipMemsetAsync(queue, 0, sizeof(int), st);
+    if (plan.wide && plan.waves > 1) {
+        launch_fast_fill_wn(plan, st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt, ckbase, queue,
+                            order, n_cu);
+        return;
+    }
     if (plan.wide) {
         launch_fast_fill_wide(plan, st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt,
                               ckbase, queue, order, n_cu, cendoff, crank);
@@ -816,7 +855,7 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
 }
 
 void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
-                       const uint32_t* bases2, const uint32_t* nmask, const uint16_t* slot_of,
+                       const uint32_t* bases2, const uint32_t* nmask, const uint32_t* slot_of,
                        const uint8_t* tcodes, const uint32_t* lane_consts, const int32_t* toff,
                        const int32_t* tlen, ScoreArgs sc, const int32_t* B, const int32_t* argV,
                        const uint32_t* ckpt, const int32_t* ckbase, DevRec* recs,
@@ -828,7 +867,7 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
 #define SD_TRACE(QQ)                                                                              \
     hipLaunchKernelGGL(sd_fast_trace<QQ>, dim3(grid), dim3(256), 0, st, chunks, n_chunks, bases2, \
                        nmask, slot_of, tcodes, lane_consts, toff, tlen, sc, plan.P, B, argV, ckpt, \
-                       ckbase, recs, rec_cnt, queue, order, plan.f16 ? 1 : 0)
+                       ckbase, recs, rec_cnt, queue, order, plan.f16 ? 1 : 0, plan.bshift, plan.waves)
     switch (plan.Qk) {
         case 1: SD_TRACE(1); break;
         case 2: SD_TRACE(2); break;

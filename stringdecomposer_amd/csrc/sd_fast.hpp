@@ -45,11 +45,14 @@ struct FastPlan {
     int split = 0;        // templates [0,split) in the lo plane
     int Lmax = 0;
     int Qk = 0;           // traceback: template cells per lane = ceil(Lmax/64)
+    int waves = 1;        // waves per chunk: 1, or ceil(T/128) for the multi-wave wide layout (sd_fast_wn.hip)
+    int bshift = 7;       // B words: (B_i << bshift) | arg-max (wave << 7 | virtual lane)
+    uint32_t bf8_match = 0, bf8_mismatch = 0;   // multi-wave wide layout: bf8 bytes of the two table values
     std::vector<int32_t> vlane0;         // first virtual lane of template j
     std::vector<uint32_t> table;         // narrow: [5][P4/4][64][4] packed int16 (mm - del - ins), NEG on padding
                                          // wide:   [5][P/16][2][64][4] dwords of int8 {lo,hi} pairs, -128 on padding
     std::vector<uint32_t> lane_consts;   // [64][FAST_LANE_WORDS]
-    std::vector<uint16_t> slot_of;       // per template cell x=toff[j]+k: (slot << 7) | vlane
+    std::vector<uint32_t> slot_of;       // per template cell x=toff[j]+k: (wave << 16) | (slot << 7) | vlane
     std::vector<uint8_t> tcodes;         // per template cell: base code
     std::vector<int32_t> end_vlane;      // virtual lane holding the end of template j
     std::vector<int32_t> end_off;        // (L_j - 1) * del
@@ -90,8 +93,14 @@ void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc
                            int32_t* ckbase, int* queue, const int* order, int n_cu,
                            const uint32_t* cendoff, const uint32_t* crank);
 
+// multi-wave wide variant (sd_fast_wn.hip): more than 128 templates, W = plan.waves waves per chunk
+void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
+                         const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                         const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
+                         int* queue, const int* order, int n_cu);
+
 void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
-                       const uint32_t* bases2, const uint32_t* nmask, const uint16_t* slot_of,
+                       const uint32_t* bases2, const uint32_t* nmask, const uint32_t* slot_of,
                        const uint8_t* tcodes, const uint32_t* lane_consts, const int32_t* toff,
                        const int32_t* tlen, ScoreArgs sc, const int32_t* B, const int32_t* argV,
                        const uint32_t* ckpt, const int32_t* ckbase, DevRec* recs,

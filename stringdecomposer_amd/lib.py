@@ -354,7 +354,8 @@ class Engine:
 def _info_dict(v):
     return {"n_templates": v[0], "sum_template_len": v[1], "n_chunks": v[2], "rows": v[3],
             "family": {1: "generic", 2: "fast"}.get(v[4] & 0xff, "?"),
-            "cells": {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table", 4: "f16/bf8-table"}.get(v[4] >> 8, "?"),
+            "cells": {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table", 4: "f16/bf8-table",
+                      5: "f16/bf8-codes x waves"}.get(v[4] >> 8, "?"),
             "cells_per_lane": v[5], "workspace_bytes": v[6], "fill_launches": v[7]}
 
 

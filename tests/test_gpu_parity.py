@@ -528,12 +528,33 @@ def test_template_sets_beyond_the_fast_family_vs_oracle(oracle, nm, lo, hi):
     e = lib.Engine(ms)
     info = e.info()
     e.close()
-    assert info["family"] == "generic" and info["sum_template_len"] > (32768 if nm != 100 else 30000)
+    # up to 1024 templates of <= 224 bp run on the multi-wave wide layout, longer ones on the generic family
+    assert info["sum_template_len"] > (32768 if nm != 100 else 30000)
+    assert (info["family"], info["cells"]) == (("fast", "f16/bf8-codes x waves") if hi <= 224 else ("generic", "int32"))
     for sc, part, ov, ed in [((-1, -1, -1, 1), 5000, 500, -1), ((-2, -3, -4, 2), 400, 60, -1),
                              ((-1, -1, -1, 1), 700, 100, 40), ((-1, -1, -1, 1), 5000, 500, 0)]:
-        got = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed)
         exp = oracle.decompose(rn, reads, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc, part=part, overlap=ov, ed_thr=ed)
+        got = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed)
         assert got == exp, (nm, sc, ed)
+        gen = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed, kernel=lib.KERNEL_GENERIC)
+        assert gen == exp, (nm, sc, ed, "generic")
+
+
+def test_multi_wave_wide_layout_long_reads_vs_generic_and_oracle(oracle):
+    """More than 128 templates on the fast path (sd_fast_fill_wn: W waves per chunk, template codes in LDS,
+    one workgroup barrier per row): 150 monomers = 300 templates = 3 waves, reads of 50 kb (checkpoints,
+    rebases, several chunks) against the generic family, one read against the oracle, N in the reads."""
+    mn, ms = synth.make_monomers(150, seed=31)
+    rn, rs = synth.make_reads(ms, 6, read_len=50000, seed=32)
+    rs[2] = rs[2][:20000] + b"N" * 7 + rs[2][20007:]
+    e = lib.Engine(ms)
+    assert e.info()["cells"] == "f16/bf8-codes x waves" and e.info()["n_templates"] == 300
+    e.close()
+    fast = lib.decompose(rn, rs, mn, ms)
+    gen = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_GENERIC)
+    assert fast == gen
+    short = [rs[0][:6000], rs[2][19000:21000], rs[3][:1]]
+    assert lib.decompose(rn[:3], short, mn, ms) == oracle.decompose(rn[:3], short, mn, ms, threads=min(32, os.cpu_count() or 1))
 
 
 @pytest.mark.parametrize("thr", [0, 12, 40])
