@@ -6,6 +6,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <chrono>
 #include <functional>
@@ -86,6 +89,11 @@ struct DevPool {
     }
 };
 DevPool g_pool;
+std::atomic<long long> g_alloc_ns{0};   // time spent in hipMalloc / hipHostMalloc (SD_TIMING report)
+struct AllocTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~AllocTimer() { g_alloc_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 template <class T>
 struct DevBuf {
@@ -114,6 +122,7 @@ struct DevBuf {
                 p = static_cast<T*>(q);
                 cap = got / sizeof(T);
             } else {
+                AllocTimer at;
                 hipError_t er = hipMalloc(reinterpret_cast<void**>(&p), bytes);
                 if (er != hipSuccess) {  // give the cached blocks back to the driver and retry once
                     (void)hipGetLastError();
@@ -143,6 +152,7 @@ struct PinBuf {
         if (count <= cap) return;
         free_();
         const size_t want = count + count / 8;  // a little slack: batches of similar size reuse it
+        AllocTimer at;
         SD_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocDefault));
         cap = want;
     }
@@ -1860,55 +1870,100 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     std::vector<std::pair<size_t, size_t>> batches;
     if (rc == SD_OK) plan_batches(job.table, 0, job.table.size(), pipe.row_budget(), 1, batches);
     lap("chunk table, engine");
-    int sink_rc = SD_OK;
+    // The rows of a batch are assembled on the driver thread (they come out of the engine's pinned buffer, which
+    // the next load reuses) and handed to a second host thread that turns them into the three texts and writes
+    // them, while the driver packs and enqueues the next batch.  At most two batches wait in the hand-over.
+    struct Work { size_t r0, r1; sd_rec* rows; std::vector<int64_t> off; };
+    std::mutex wq_m;
+    std::condition_variable wq_cv;
+    std::deque<Work> wq;
+    bool wq_done = false;
+    std::atomic<int> sink_rc{SD_OK};
+    std::string sink_err;
     double t_fmt = 0, t_post = 0, t_io = 0;
-    std::string raw, fin, alt;
-    std::vector<sd::PostRead> preads;
+    auto sink_loop = [&]() {
+        std::string raw, fin, alt;
+        std::vector<sd::PostRead> preads;
+        for (;;) {
+            Work w;
+            {
+                std::unique_lock<std::mutex> lk(wq_m);
+                wq_cv.wait(lk, [&] { return wq_done || !wq.empty(); });
+                if (wq.empty()) return;
+                w = std::move(wq.front());
+                wq.pop_front();
+            }
+            wq_cv.notify_all();
+            if (sink_rc.load() == SD_OK) {
+                double t0 = now_s();
+                // raw TSV (SaveBatch, main.cpp:272-285): slices of <= 32 k rows, so that a chromosome-sized read is
+                // formatted by all threads; a slice needs the end of the row before it
+                struct Slice { size_t r; int64_t a, b; };
+                std::vector<Slice> slices;
+                const int64_t* off = w.off.data();   // off[r - r0] .. : rows of read r
+                for (size_t r = w.r0; r < w.r1; ++r)
+                    for (int64_t a = off[r - w.r0]; a < off[r - w.r0 + 1]; a += 32768)
+                        slices.push_back(Slice{r, a, std::min<int64_t>(off[r - w.r0 + 1], a + 32768)});
+                std::vector<std::string> parts(slices.size());
+                sd::parallel_for((int64_t)slices.size(), p->threads, 1, [&](int64_t x) {
+                    const Slice& sl = slices[(size_t)x];
+                    sd::format_rows(parts[(size_t)x], reads[sl.r].name, reads[sl.r].name_len, ts.tnames, w.rows + sl.a,
+                                    (size_t)(sl.b - sl.a), sl.a > off[sl.r - w.r0] ? w.rows[sl.a - 1].end : 0);
+                });
+                raw.clear();
+                for (const std::string& q : parts) raw += q;
+                t_fmt += now_s() - t0;
+                t0 = now_s();
+                preads.clear();
+                for (size_t r = w.r0; r < w.r1; ++r)
+                    preads.push_back(sd::PostRead{reads[r].name, reads[r].name_len, reads[r].seq, reads[r].len});
+                fin.clear();
+                alt.clear();
+                std::string e2;
+                const int r2 = pp.process(preads.data(), preads.size(), w.rows, off, fin, alt, e2);
+                t_post += now_s() - t0;
+                t0 = now_s();
+                if (r2) {
+                    sink_err = e2;
+                    sink_rc.store(r2);
+                } else if (std::fwrite(raw.data(), 1, raw.size(), fr) != raw.size() ||
+                           std::fwrite(fin.data(), 1, fin.size(), ff) != fin.size() ||
+                           std::fwrite(alt.data(), 1, alt.size(), fa) != alt.size()) {
+                    sink_err = std::string("short write to ") + raw_tsv_out;
+                    sink_rc.store(SD_ERR_IO);
+                }
+                t_io += now_s() - t0;
+            }
+            std::free(w.rows);
+        }
+    };
+    std::thread sink_thread(sink_loop);
     auto sink = [&](size_t c0, size_t c1, const sd_rec* recs, const int64_t* roff) {
-        if (sink_rc) return;
+        if (sink_rc.load()) return;
         const size_t r0 = job.next_read;
         job.n_rows = 0;
         job.row_off[r0] = 0;
         job.add(c0, c1, recs, roff);
-        if (job.oom) { sink_rc = SD_ERR_INTERNAL; err = "out of host memory"; return; }
+        if (job.oom) { sink_err = "out of host memory"; sink_rc.store(SD_ERR_INTERNAL); return; }
         const size_t r1 = job.next_read;
         if (r1 == r0) return;
-        double t0 = now_s();
-        // raw TSV (SaveBatch, main.cpp:272-285): slices of <= 32 k rows, so that a chromosome-sized read is
-        // formatted by all threads; a slice needs the end of the row before it
-        struct Slice { size_t r; int64_t a, b; };
-        std::vector<Slice> slices;
-        for (size_t r = r0; r < r1; ++r)
-            for (int64_t a = job.row_off[r]; a < job.row_off[r + 1]; a += 32768)
-                slices.push_back(Slice{r, a, std::min<int64_t>(job.row_off[r + 1], a + 32768)});
-        std::vector<std::string> parts(slices.size());
-        sd::parallel_for((int64_t)slices.size(), p->threads, 1, [&](int64_t x) {
-            const Slice& sl = slices[(size_t)x];
-            sd::format_rows(parts[(size_t)x], reads[sl.r].name, reads[sl.r].name_len, ts.tnames, job.rows + sl.a,
-                            (size_t)(sl.b - sl.a), sl.a > job.row_off[sl.r] ? job.rows[sl.a - 1].end : 0);
-        });
-        raw.clear();
-        for (const std::string& q : parts) raw += q;
-        t_fmt += now_s() - t0;
-        t0 = now_s();
-        preads.clear();
-        for (size_t r = r0; r < r1; ++r) preads.push_back(sd::PostRead{reads[r].name, reads[r].name_len, reads[r].seq, reads[r].len});
-        fin.clear();
-        alt.clear();
-        const int r2 = pp.process(preads.data(), preads.size(), job.rows, job.row_off + r0, fin, alt, err);
-        t_post += now_s() - t0;
-        if (r2) { sink_rc = r2; return; }
-        t0 = now_s();
-        if (std::fwrite(raw.data(), 1, raw.size(), fr) != raw.size() || std::fwrite(fin.data(), 1, fin.size(), ff) != fin.size() ||
-            std::fwrite(alt.data(), 1, alt.size(), fa) != alt.size()) {
-            sink_rc = SD_ERR_IO;
-            err = std::string("short write to ") + raw_tsv_out;
-        }
-        t_io += now_s() - t0;
+        Work w;
+        w.r0 = r0;
+        w.r1 = r1;
+        w.rows = job.rows;
+        w.off.assign(job.row_off + r0, job.row_off + r1 + 1);
+        job.rows = nullptr;       // the next batch assembles into a fresh (or recycled) buffer
+        job.cap_rows = 0;
+        job.n_rows = 0;
+        std::unique_lock<std::mutex> lk(wq_m);
+        wq_cv.wait(lk, [&] { return wq.size() < 2; });
+        wq.push_back(std::move(w));
+        lk.unlock();
+        wq_cv.notify_all();
     };
     std::vector<const char*> cptr;
     std::vector<int32_t> clen;
-    for (size_t b = 0; b < batches.size() && rc == SD_OK && sink_rc == SD_OK; ++b) {
+    for (size_t b = 0; b < batches.size() && rc == SD_OK && sink_rc.load() == SD_OK; ++b) {
         const size_t c0 = batches[b].first, c1 = batches[b].second;
         cptr.clear();
         clen.clear();
@@ -1921,13 +1976,21 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     }
     const int rc2 = pipe.drain();
     if (rc == SD_OK && rc2) { rc = rc2; err = pipe.eb; }
-    if (rc == SD_OK) rc = sink_rc;
+    {
+        std::lock_guard<std::mutex> lk(wq_m);
+        wq_done = true;
+    }
+    wq_cv.notify_all();
+    sink_thread.join();
+    if (rc == SD_OK && sink_rc.load()) { rc = sink_rc.load(); err = sink_err; }
     const bool w1 = std::fclose(fr) == 0, w2 = std::fclose(ff) == 0, w3 = std::fclose(fa) == 0;
     if (rc == SD_OK && !(w1 && w2 && w3)) { rc = SD_ERR_IO; err = std::string("short write to ") + raw_tsv_out; }
     if (timing)
         std::fprintf(stderr, "[sd timing] %zu batches: pack+enqueue %.1f ms, wait %.1f ms, raw text %.1f ms, post-processing %.1f ms, "
                      "file writes %.1f ms, total %.1f ms\n", batches.size(), pipe.pack_s * 1e3, pipe.wait_s * 1e3, t_fmt * 1e3,
                      t_post * 1e3, t_io * 1e3, (now_s() - t_begin) * 1e3);
+    if (timing)
+        std::fprintf(stderr, "[sd timing] of which device / pinned allocations (hipMalloc, hipHostMalloc): %.1f ms\n", (double)g_alloc_ns.load() / 1e6);
     if (timing)
         std::fprintf(stderr, "[sd timing] post-processing: segments %.1f ms, identities %.1f ms, text %.1f ms, concatenation %.1f ms\n",
                      pp.t_prepare * 1e3, pp.t_identity * 1e3, pp.t_format * 1e3, pp.t_concat * 1e3);
