@@ -42,7 +42,7 @@ typedef struct sd_params {
     int32_t ed_thr;                    /* argv[10] (--ed_thr): -1 = off; >=0 = per-chunk prefilter */
     int32_t threads;                   /* argv[3] (-t): host threads for parse / format            */
     int32_t device;                    /* HIP device ordinal                                      */
-    int32_t kernel;                    /* 0 auto, 1 generic int32 workgroup kernel, 2 fast packed-int16 wave kernel */
+    int32_t kernel;                    /* 0 auto, 1 generic family (int32, workgroup per chunk), 2 fast family (packed 16-bit cells, wave(s) per chunk) */
     int32_t max_batch_rows;            /* 0 = size device batches from free HBM; >0 = cap on chunk rows per batch */
     int32_t reserved[5];
 } sd_params;

@@ -505,7 +505,7 @@ def test_nw_identity_kernel_equals_host_and_edlib(shape):
     assert all((x == y).all() for x, y in zip(a, b))
 
 
-@pytest.mark.parametrize("nm,lo,hi", [(100, 165, 178), (260, 150, 176), (70, 300, 480)])
+@pytest.mark.parametrize("nm,lo,hi", [(100, 165, 178), (260, 150, 176), (70, 300, 480), (520, 90, 120)])
 def test_template_sets_beyond_the_fast_family_vs_oracle(oracle, nm, lo, hi):
     """Hundreds of monomers (the reference takes any monomer set, main.cpp:187-207): more than 128
     templates run on the generic family, more than 32 768 template cells on its tiled form (previous row
@@ -530,7 +530,9 @@ def test_template_sets_beyond_the_fast_family_vs_oracle(oracle, nm, lo, hi):
     e.close()
     # up to 1024 templates of <= 224 bp run on the multi-wave wide layout, longer ones on the generic family
     assert info["sum_template_len"] > (32768 if nm != 100 else 30000)
-    assert (info["family"], info["cells"]) == (("fast", "f16/bf8-codes x waves") if hi <= 224 else ("generic", "int32"))
+    # (more than 1024 templates, or templates longer than 224 bp in a set of more than 128: generic family, tiled)
+    assert (info["family"], info["cells"]) == (("fast", "f16/bf8-codes x waves") if hi <= 224 and 2 * nm <= 1024
+                                               else ("generic", "int32"))
     for sc, part, ov, ed in [((-1, -1, -1, 1), 5000, 500, -1), ((-2, -3, -4, 2), 400, 60, -1),
                              ((-1, -1, -1, 1), 700, 100, 40), ((-1, -1, -1, 1), 5000, 500, 0)]:
         exp = oracle.decompose(rn, reads, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc, part=part, overlap=ov, ed_thr=ed)
