@@ -401,10 +401,8 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
         int family = p->kernel;
         std::string why;
         const bool fast_ok = sd::fast_plan_build(e->tseq, e->sc, p->part_size + p->overlap, e->fplan, why);
-        // the multi-wave wide layout has no ranked (--ed_thr) variant: such jobs run on the generic family
-        const bool fast_usable = fast_ok && !(e->fplan.waves > 1 && p->ed_thr > -1);
+        const bool fast_usable = fast_ok;
         if (family == 0) family = fast_usable ? 2 : 1;
-        if (family == 2 && fast_ok && !fast_usable) why = "--ed_thr with more than 128 templates runs on the generic family";
         if (family == 2 && !fast_usable) {
             set_err(errbuf, errlen, "fast kernel family not applicable: " + why);
             return SD_ERR_UNSUPPORTED;
@@ -583,8 +581,8 @@ static int load_chunks_impl(sd_engine* e, const std::vector<const char*>& cptr,
         } else {
             if (e->p.ed_thr > -1) {
                 e->d_dist.alloc(C * (size_t)e->T);
-                e->d_cendoff.alloc(C * 64);
-                e->d_crank.alloc(C * 64);
+                e->d_cendoff.alloc(C * 64 * (size_t)e->fplan.waves);
+                e->d_crank.alloc(C * 64 * (size_t)e->fplan.waves);
             }
             e->d_fckpt.alloc((size_t)nck * (size_t)e->fplan.P * 64 * (size_t)e->fplan.waves);
             e->d_fckbase.alloc((size_t)nck + 1);
@@ -675,7 +673,8 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                 if (ranked)  // main.cpp:91-93: per-chunk template prefilter
                     sd::launch_edthr_filter(st, e->dp_chunks, C, e->T, e->Lmax, e->p.ed_thr, e->dp_bases2,
                                             e->dp_nmask, e->d_peq.p, e->d_tlen.p, e->d_endvl.p,
-                                            e->d_endoff.p, e->d_dist.p, e->d_cendoff.p, e->d_crank.p, nullptr);
+                                            e->d_endoff.p, e->d_dist.p, e->d_cendoff.p, e->d_crank.p, nullptr,
+                                            e->fplan.waves);
                 SD_HIP(hipEventRecord(e->ev_fill[0], st));
                 sd::launch_fast_fill(e->fplan, st, e->dp_chunks, C, e->dp_bases2, e->dp_nmask,
                                      e->d_ftable.p, e->d_flane.p, e->sc, e->d_B.p, e->d_argB.p,

@@ -816,7 +816,7 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
     (void)hipMemsetAsync(queue, 0, sizeof(int), st);
     if (plan.wide && plan.waves > 1) {
         launch_fast_fill_wn(plan, st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt, ckbase, queue,
-                            order, n_cu);
+                            order, n_cu, cendoff, crank);
         return;
     }
     if (plan.wide) {

@@ -75,7 +75,7 @@ void build_peq(const std::vector<std::string>& tseq, std::vector<unsigned long l
 void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, int T, int Lmax, int ed_thr,
                          const uint32_t* bases2, const uint32_t* nmask, const unsigned long long* peq,
                          const int32_t* tlen, const int32_t* end_vlane, const int32_t* end_off,
-                         int32_t* dist, uint32_t* cendoff, uint32_t* crank, uint16_t* grank);
+                         int32_t* dist, uint32_t* cendoff, uint32_t* crank, uint16_t* grank, int waves = 1);
 
 // number of checkpoint rows of the batch; fills ChunkDesc::pad with each chunk's first checkpoint
 int64_t fast_ckpt_rows_total(const FastPlan& plan, std::vector<ChunkDesc>& chunks);
@@ -97,7 +97,7 @@ void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc
 void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                          const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                          const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
-                         int* queue, const int* order, int n_cu);
+                         int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank);
 
 void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                        const uint32_t* bases2, const uint32_t* nmask, const uint32_t* slot_of,

@@ -35,13 +35,14 @@ __device__ __forceinline__ uint32_t cvt_bf8_pair(uint32_t tb, int pair, uint32_t
 }
 }  // namespace
 
-template <int P>
+template <int P, bool RANKED>
 __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ codes,
     const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int W, uint32_t mb, uint32_t xb,
     int32_t* __restrict__ Bout, uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase,
-    int* __restrict__ queue, const int* __restrict__ order) {
+    int* __restrict__ queue, const int* __restrict__ order, const uint32_t* __restrict__ cendoff,
+    const uint32_t* __restrict__ crank) {
     static_assert(P % 16 == 0, "the code table is streamed 16 slots at a time");
     constexpr int G = P / 16;
     extern __shared__ uint32_t lds[];  // [W][G][2 halves][64 lanes][4 dwords] codes, then the exchange area
@@ -50,7 +51,8 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
         *reinterpret_cast<uint4*>(&lds[idx]) = *reinterpret_cast<const uint4*>(&codes[idx]);
     int32_t* xv = reinterpret_cast<int32_t*>(lds + TBL);   // [2 parities][8 waves] wave maxima
     int32_t* xa = xv + 16;                                 // [2][8] arg-max virtual lane of each wave
-    int32_t* xc = xa + 16;                                 // [1] chunk of the workgroup
+    int32_t* xr = xa + 16;                                 // [2][8] --ed_thr: smallest rank among each wave's maxima
+    int32_t* xc = xr + 16;                                 // [1] chunk of the workgroup
     __syncthreads();
 
     using CO = CellOps<true>;
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     const int lane = threadIdx.x & 63;
     const uint32_t* myc = lds + wave * (G * 512);
     const uint32_t* lc = lane_consts + (size_t)(wave * 64 + lane) * FAST_LANE_WORDS;
-    const uint32_t endOff = CO::from_i16x2(lc[FLC_ENDOFF]);
+    const uint32_t endOffPlan = lc[FLC_ENDOFF];
     const uint32_t row0adj = CO::from_i16x2(lc[FLC_ROW0]);
     const uint32_t ins2 = CO::splat(sc.ins);
 
@@ -75,6 +77,10 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
         const int n = cd.n;
         ReadStream rs;
         rs.init(bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr, n);
+        // --ed_thr: per-chunk end offsets (-inf for dropped templates) and tie-break ranks (main.cpp:141-147)
+        const size_t cl = ((size_t)c * (size_t)W + (size_t)wave) * 64 + (size_t)lane;
+        const uint32_t endOff = CO::from_i16x2(RANKED ? cendoff[cl] : endOffPlan);
+        const uint32_t rank2 = RANKED ? crank[cl] : 0u;
         int32_t* Bc = Bout + cd.row0 + (uint64_t)c;
         uint32_t* ck = ckpt + ((uint64_t)cd.pad * (uint64_t)W + (uint64_t)wave) * (uint64_t)(P * 64) + lane;
         int32_t* ckb = ckbase + cd.pad;
@@ -106,15 +112,27 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
             int lo, hi;
             CO::to_int(val, lo, hi);
             const int bw = wave_max(max(lo, hi));
-            const unsigned long long mlo = __ballot(lo == bw), mhi = __ballot(hi == bw);
+            unsigned long long mlo, mhi;
+            int kw = 0;
+            if (RANKED) {
+                // among equal values the first template of the chunk's filtered order wins (smallest rank)
+                const int klo = lo == bw ? (int)(rank2 & 0xffffu) : 0x7fff;
+                const int khi = hi == bw ? (int)(rank2 >> 16) : 0x7fff;
+                kw = -wave_max(-min(klo, khi));
+                mlo = __ballot(klo == kw);
+                mhi = __ballot(khi == kw);
+            } else {
+                mlo = __ballot(lo == bw);
+                mhi = __ballot(hi == bw);
+            }
             const int vw = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
             const int par = (row & 1) * 8;
-            if (lane == 0) { xv[par + wave] = bw; xa[par + wave] = vw; }
+            if (lane == 0) { xv[par + wave] = bw; xa[par + wave] = vw; xr[par + wave] = kw; }
             __syncthreads();
-            int b = xv[par], arg = xa[par];
+            int b = xv[par], arg = xa[par], rk = xr[par];
             for (int w2 = 1; w2 < W; ++w2) {
-                const int b2 = xv[par + w2];
-                if (b2 > b) { b = b2; arg = (w2 << 7) | xa[par + w2]; }
+                const int b2 = xv[par + w2], r2 = xr[par + w2];
+                if (b2 > b || (RANKED && b2 == b && r2 < rk)) { b = b2; rk = r2; arg = (w2 << 7) | xa[par + w2]; }
             }
             b = __builtin_amdgcn_readfirstlane(b);
             arg = __builtin_amdgcn_readfirstlane(arg);
@@ -217,18 +235,23 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
 void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                          const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                          const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
-                         int* queue, const int* order, int n_cu) {
+                         int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank) {
     const int W = plan.waves;
     const int per_cu = std::max(1, 8 / W);          // 213 VGPRs: two waves per SIMD, eight per CU
     const int grid = std::min(n_chunks, per_cu * n_cu);
     const size_t lds = ((size_t)W * (plan.P / 16) * 512 + 64) * sizeof(uint32_t);
-#define SD_FILLWN(PP)                                                                                           \
-    case PP:                                                                                                    \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill_wn<PP>),                           \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
-        hipLaunchKernelGGL((sd_fast_fill_wn<PP>), dim3(grid), dim3(W * 64), lds, st, chunks, n_chunks, bases2,    \
-                           nmask, table, lane_consts, sc, W, plan.bf8_match, plan.bf8_mismatch, B, ckpt, ckbase, \
-                           queue, order);                                                                       \
+    const bool ranked = cendoff != nullptr;
+#define SD_FILLWN_K(PP, RK)                                                                                      \
+    {                                                                                                            \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill_wn<PP, RK>),                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+        hipLaunchKernelGGL((sd_fast_fill_wn<PP, RK>), dim3(grid), dim3(W * 64), lds, st, chunks, n_chunks, bases2, \
+                           nmask, table, lane_consts, sc, W, plan.bf8_match, plan.bf8_mismatch, B, ckpt, ckbase,  \
+                           queue, order, cendoff, crank);                                                        \
+    }
+#define SD_FILLWN(PP)                                                   \
+    case PP:                                                            \
+        if (ranked) SD_FILLWN_K(PP, true) else SD_FILLWN_K(PP, false)   \
         break;
     switch (plan.P) {
         SD_FILLWN(80) SD_FILLWN(96) SD_FILLWN(112) SD_FILLWN(128) SD_FILLWN(144) SD_FILLWN(160)
@@ -236,6 +259,7 @@ void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* 
         default: break;
     }
 #undef SD_FILLWN
+#undef SD_FILLWN_K
 }
 
 }  // namespace sd

@@ -100,12 +100,12 @@ __global__ __launch_bounds__(256) void sd_hw_dist(const ChunkDesc* __restrict__ 
 
 // Kept set and order of a chunk (main.cpp:141-147): first = smallest (distance, index); kept = first or
 // distance <= ed_thr; rank = position in the (distance, index) order among the kept.  Written as the
-// per-chunk lane constants of the ranked fast fills (end offsets / ranks, [chunk][64 lanes] dwords, packed
+// per-chunk lane constants of the ranked fast fills (end offsets / ranks, [chunk][wave][64 lanes] dwords, packed
 // {lo plane, hi plane} int16) or, for the generic family, as a rank table [chunk][T] (0xffff = dropped).
 __global__ void sd_rank_keep(int n_chunks, int T, int ed_thr, const int32_t* __restrict__ dist,
                              const int32_t* __restrict__ end_vlane, const int32_t* __restrict__ end_off,
                              uint16_t* __restrict__ cendoff, uint16_t* __restrict__ crank,
-                             uint16_t* __restrict__ grank) {
+                             uint16_t* __restrict__ grank, int W) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long long)n_chunks * T) return;
     const int c = (int)(g / T), j = (int)(g % T);
@@ -124,8 +124,8 @@ __global__ void sd_rank_keep(int n_chunks, int T, int ed_thr, const int32_t* __r
         grank[(size_t)c * T + j] = (uint16_t)(kept ? rank : 0xffff);
         return;
     }
-    const int v = end_vlane[j];  // virtual lane holding the template's end
-    const size_t at = ((size_t)c * 64 + (v & 63)) * 2 + (v >> 6);
+    const int v = end_vlane[j];  // virtual lane holding the template's end: (wave << 7) | (plane << 6) | lane
+    const size_t at = (((size_t)c * W + (size_t)(v >> 7)) * 64 + (v & 63)) * 2 + ((v >> 6) & 1);
     cendoff[at] = (uint16_t)(kept ? end_off[j] : -32768);
     crank[at] = (uint16_t)(kept ? rank : 0x7fff);
 }
@@ -154,11 +154,11 @@ void build_peq(const std::vector<std::string>& tseq, std::vector<unsigned long l
 void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, int T, int Lmax, int ed_thr,
                          const uint32_t* bases2, const uint32_t* nmask, const unsigned long long* peq,
                          const int32_t* tlen, const int32_t* end_vlane, const int32_t* end_off,
-                         int32_t* dist, uint32_t* cendoff, uint32_t* crank, uint16_t* grank) {
+                         int32_t* dist, uint32_t* cendoff, uint32_t* crank, uint16_t* grank, int waves) {
     const long long total = (long long)n_chunks * T;
     const int grid = (int)((total + 255) / 256);
     if (!grank) {
-        const size_t words = (size_t)n_chunks * 64;
+        const size_t words = (size_t)n_chunks * 64 * (size_t)waves;
         hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, cendoff, words, 0x80008000u);
         hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, crank, words, 0x7fff7fffu);
     }
@@ -173,7 +173,7 @@ void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, 
     if (W <= 1) SD_HW(1) else if (W == 2) SD_HW(2) else if (W == 3) SD_HW(3) else if (W == 4) SD_HW(4) else SD_HW(8)
 #undef SD_HW
     hipLaunchKernelGGL(sd_rank_keep, dim3(grid), dim3(256), 0, st, n_chunks, T, ed_thr, dist, end_vlane, end_off,
-                       reinterpret_cast<uint16_t*>(cendoff), reinterpret_cast<uint16_t*>(crank), grank);
+                       reinterpret_cast<uint16_t*>(cendoff), reinterpret_cast<uint16_t*>(crank), grank, waves);
 }
 
 }  // namespace sd
