@@ -201,7 +201,9 @@ struct sd_engine {
     DevBuf<unsigned long long> d_peq;
     DevBuf<int32_t> d_endvl, d_endoff, d_dist;
     DevBuf<uint32_t> d_cendoff, d_crank;
-    DevBuf<int> d_queue;             // work-queue heads of the persistent kernels (fill, trace)
+    DevBuf<int> d_queue;             // work-queue heads of the persistent kernels: a fresh zeroed (fill, trace) pair per run
+    int q_run = 0;                   // pairs handed out since the array was last zeroed
+    static constexpr int QN = 2048;
     int n_cu = 256;
 
     // batch
@@ -395,7 +397,8 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
             hipDeviceProp_t prop;
             SD_HIP(hipGetDeviceProperties(&prop, p->device));
             e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            e->d_queue.alloc(2);
+            e->d_queue.alloc(2 * (size_t)sd_engine::QN);
+            SD_HIP(hipMemset(e->d_queue.p, 0, sizeof(int) * 2 * (size_t)sd_engine::QN));
         }
         // kernel family
         int family = p->kernel;
@@ -670,6 +673,13 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                 }
             } else {
                 const bool ranked = e->p.ed_thr > -1;
+                if (e->q_run == sd_engine::QN) {  // every queue head used once: zero them again (no kernel of this
+                    SD_HIP(hipMemsetAsync(e->d_queue.p, 0, sizeof(int) * 2 * (size_t)sd_engine::QN, st));  // engine is running)
+                    e->q_run = 0;
+                }
+                int* qfill = e->d_queue.p + 2 * e->q_run;
+                int* qtrace = qfill + 1;
+                ++e->q_run;
                 if (ranked)  // main.cpp:91-93: per-chunk template prefilter
                     sd::launch_edthr_filter(st, e->dp_chunks, C, e->T, e->Lmax, e->p.ed_thr, e->dp_bases2,
                                             e->dp_nmask, e->d_peq.p, e->d_tlen.p, e->d_endvl.p,
@@ -678,7 +688,7 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                 SD_HIP(hipEventRecord(e->ev_fill[0], st));
                 sd::launch_fast_fill(e->fplan, st, e->dp_chunks, C, e->dp_bases2, e->dp_nmask,
                                      e->d_ftable.p, e->d_flane.p, e->sc, e->d_B.p, e->d_argB.p,
-                                     e->d_fckpt.p, e->d_fckbase.p, e->d_queue.p, e->dp_order, e->n_cu,
+                                     e->d_fckpt.p, e->d_fckbase.p, qfill, e->dp_order, e->n_cu,
                                      ranked ? e->d_cendoff.p : nullptr, ranked ? e->d_crank.p : nullptr,
                                      e->lds_gate ? 54 * 1024 : 0);
                 SD_HIP(hipEventRecord(e->ev_fill[1], st));
@@ -687,7 +697,7 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                 sd::launch_fast_trace(e->fplan, ts, e->dp_chunks, C, e->dp_bases2, e->dp_nmask,
                                       e->d_fslot.p, e->d_ftcodes.p, e->d_flane.p, e->d_toff.p,
                                       e->d_tlen.p, e->sc, e->d_B.p, e->d_argB.p, e->d_fckpt.p,
-                                      e->d_fckbase.p, e->d_recs.p, e->d_cnt.p, e->d_queue.p + 1, e->dp_order,
+                                      e->d_fckbase.p, e->d_recs.p, e->d_cnt.p, qtrace, e->dp_order,
                                       e->n_cu);
                 SD_HIP(hipEventRecord(e->ev_trace[1], ts));
                 e->fill_launches = 1;

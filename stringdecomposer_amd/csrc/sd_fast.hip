@@ -813,7 +813,8 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
 #define SD_FILL_WPC 16   // resident fill waves per CU (4 per SIMD)
 #endif
     const int grid = std::min((n_chunks + NW - 1) / NW, (SD_FILL_WPC / NW) * n_cu);  // persistent
-    (void)hipMemsetAsync(queue, 0, sizeof(int), st);
+    // `queue` points at a zeroed work-queue head that no earlier launch has used (sd_engine hands out a fresh
+    // one per run): no memset kernel sits between the launches of a stream
     if (plan.wide && plan.waves > 1) {
         launch_fast_fill_wn(plan, st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt, ckbase, queue,
                             order, n_cu, cendoff, crank);
@@ -863,7 +864,6 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
     int bpc = 8;
     if (const char* ev = getenv("SD_TRACE_BPC")) bpc = std::max(1, atoi(ev));  // developer knob
     const int grid = std::min((n_chunks + 3) / 4, bpc * n_cu);  // persistent: 8 workgroups of 4 waves per CU
-    (void)hipMemsetAsync(queue, 0, sizeof(int), st);
 #define SD_TRACE(QQ)                                                                              \
     hipLaunchKernelGGL(sd_fast_trace<QQ>, dim3(grid), dim3(256), 0, st, chunks, n_chunks, bases2, \
                        nmask, slot_of, tcodes, lane_consts, toff, tlen, sc, plan.P, B, argV, ckpt, \

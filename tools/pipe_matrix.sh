@@ -9,6 +9,4 @@ print("$name value %.3f G  ms/step %.2f" % (j["value"]/1e9, j["ms_per_step"]), {
 PY
 }
 EXTRA="--pipe-mode 2 --steps 20" run m2
-EXTRA="--pipe-mode 2 --steps 20" run m2_q8 GPU_MAX_HW_QUEUES=8
-EXTRA="--pipe-mode 2 --steps 20" run m2_q8_prio0 GPU_MAX_HW_QUEUES=8 SD_PIPE_PRIO=0
-EXTRA="--pipe-mode 2 --steps 20" run m2_q16 GPU_MAX_HW_QUEUES=16
+EXTRA="--pipe-mode 0 --steps 20" run m0
