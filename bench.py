@@ -172,12 +172,17 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         nrows = 0
+        depth = int(os.environ.get("SD_BENCH_DEPTH", "1"))   # developer A/B: steps kept outstanding before collecting
+        out = 0
         for k in range(steps):
             st.submit(readset)
-            if k > 0:
-                nrows = st.collect()     # rows of step k-1 are in host memory
-        if steps > 0:
+            out += 1
+            if out > depth:
+                nrows = st.collect()     # rows of an earlier step are in host memory
+                out -= 1
+        while out > 0:
             nrows = st.collect()
+            out -= 1
         torch.cuda.synchronize()
         if bracket:
             shard.barrier(dist, bar_dev)

@@ -893,18 +893,19 @@ namespace {
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 struct Pipeline {
-    static constexpr int NS = 2;
+    static constexpr int NSMAX = 3;
+    int NS = 2;                                    // batches in flight (SD_PIPE_SLOTS=3: developer A/B)
     sd_params p{};
     std::vector<const char*> mseq;
     std::vector<int32_t> mlen;
-    sd_engine* eng[NS] = {nullptr, nullptr};
-    hipStream_t copy_st[NS] = {nullptr, nullptr};  // per slot: H2D of the batch, D2H of its records
+    sd_engine* eng[NSMAX] = {nullptr, nullptr, nullptr};
+    hipStream_t copy_st[NSMAX] = {nullptr, nullptr, nullptr};  // per slot: H2D of the batch, D2H of its records
     hipStream_t fill_st = nullptr;                 // fills of all batches, in order
     hipStream_t fill_st2 = nullptr;                // mode 2: fills of the odd batches (see make_streams)
     int mode = 1;
     hipStream_t trace_st = nullptr;                // traceback + compaction of all batches (lower priority)
     bool streams_tried = false;
-    RecSink sinks[NS];
+    RecSink sinks[NSMAX];
     uint64_t pushed = 0, popped = 0;
     char eb[1024] = {0};
     // accumulated over all batches: HIP-event kernel times (ms) and host stage times (s)
@@ -914,6 +915,7 @@ struct Pipeline {
 
     int create(const sd_params* pp, const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono) {
         p = *pp;
+        if (const char* ev = getenv("SD_PIPE_SLOTS")) NS = std::min(NSMAX, std::max(1, atoi(ev)));
         mseq.assign(mono_seqs, mono_seqs + n_mono);
         mlen.assign(mono_lens, mono_lens + n_mono);
         return sd_engine_create(&eng[0], &p, mseq.data(), mlen.data(), n_mono, eb, sizeof eb);
@@ -1026,7 +1028,7 @@ struct Pipeline {
         if (inflight() > 0) (void)hipDeviceSynchronize();  // nothing may still run on buffers we free
         for (sd_engine* e : eng)
             if (e) sd_engine_destroy(e);
-        for (hipStream_t s2 : {copy_st[0], copy_st[1], fill_st, fill_st2, trace_st})
+        for (hipStream_t s2 : {copy_st[0], copy_st[1], copy_st[2], fill_st, fill_st2, trace_st})
             if (s2) (void)hipStreamDestroy(s2);
     }
 };

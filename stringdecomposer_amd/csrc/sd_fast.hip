@@ -578,17 +578,20 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     if (T > 65535) { why = "too many templates"; return false; }
     auto ab = [](int v) { return v < 0 ? -v : v; };
     const int maxabs = std::max(std::max(ab(sc.ins), ab(sc.del)), std::max(ab(sc.mismatch), ab(sc.match)));
-    // Range of a stored cell between two rebases (FAST_REBASE rows), relative to the row maximum at
-    // the rebase:
-    //   max(REBASE + 1, Lmax) * mpos   (at most one positive score per consumed read base)
-    // + Lmax * (|ins| + |del|)         (E = D - k*del, and insertions already paid inside an instance)
-    // + REBASE * |ins|                 (the per-row insertion credit of the stored form)
-    // plus a few single scores for the intermediate sums.  Real cells are never below
-    // -(Lmax + 2) * maxabs, so with ub <= 12000 the int16 "-inf" (-32768 + anything added) stays below them.
-    const int mpos = std::max(std::max(sc.match, sc.mismatch), 0);
-    const int64_t ub = (int64_t)std::max(FAST_REBASE + 1, Lmax) * mpos +
-                       (int64_t)Lmax * (ab(sc.ins) + ab(sc.del)) + (int64_t)FAST_REBASE * ab(sc.ins) +
-                       8 * (int64_t)maxabs + 8;
+    // Range of a stored cell S = E - base - tp*ins between two rebases (tp <= FAST_REBASE rows, base = B at the
+    // last rebase; base = 0 before the first one).  From any cell (i, j, k) the rest of the template can be
+    // deleted, so D[i][j][k] <= D[i][j][L-1] + (L-1-k)*|del| <= B_{i+1} + (L-1-k)*|del|, i.e.
+    //     E[i][x] = D + k*|del| <= B_{i+1} + (Lmax-1)*|del|                      (whatever the scores);
+    // B grows by at most G = max(0, smax - del) per row (turn the last aligned row of the best path into a
+    // deletion) and falls by at most |ins| per row, and before the first rebase B_1 >= -(Lmax*|del| + max|score|).
+    //     |S| <= (Lmax-1)*|del| + (REBASE+1)*G + REBASE*|ins|  (+ a few single scores for the intermediate sums)
+    // (Round 1 charged (REBASE+1)*max(match, mismatch, 0) for the growth of B instead of (REBASE+1)*G: with a
+    // large |del|, long templates and non-positive match scores -- e.g. 0,-4,-4,-1 on 480-bp monomers -- the
+    // fp16 cells left the exact-integer range; found by tools/fuzz_gpu.py seed 906.)
+    const int smax = std::max(sc.match, sc.mismatch);
+    const int64_t G = std::max(0, smax - sc.del);
+    const int64_t ub = (int64_t)(Lmax - 1) * ab(sc.del) + (int64_t)(FAST_REBASE + 1) * G +
+                       (int64_t)FAST_REBASE * ab(sc.ins) + 8 * (int64_t)maxabs + 8;
     if (ub > 12000) { why = "scores too large for int16 cells"; return false; }
     if (Lmax > 64 * 8) { why = "template longer than 512 bp"; return false; }
 

@@ -153,10 +153,12 @@ def test_full_c2_size_families_agree():
     assert dig["fast"] == dig["generic"]
 
 
-@pytest.mark.parametrize("sc,cells", [((-2, -1, -3, 6), "f16"), ((-2, -2, -3, 7), "int16"),
-                                      ((-1, -1, -1, 1), "f16"), ((0, 0, -1, 11), "f16"), ((0, 0, -1, 12), "int16"),
+@pytest.mark.parametrize("sc,cells", [((-2, -1, -3, 6), "f16"), ((-2, -2, -3, 8), "f16"), ((-2, -2, -3, 9), "int16"),
+                                      ((-1, -1, -1, 1), "f16"), ((0, 0, -1, 14), "f16"), ((0, 0, -1, 15), "int16"),
+                                      # a large |del| with non-positive scores: the range is (Lmax-1)*|del| wide
+                                      ((0, -6, -4, -1), "f16"), ((0, -7, -4, -1), "int16"), ((-1, -5, -2, 1), "f16"),
                                       # a common factor is divided out on the device and multiplied back
-                                      ((-10, -10, -10, 10), "f16"), ((-4, -6, -8, 4), "f16"), ((0, 0, -3, 36), "int16")])
+                                      ((-10, -10, -10, 10), "f16"), ((-4, -6, -8, 4), "f16"), ((0, 0, -3, 45), "int16")])
 def test_fill_cell_format_switch_at_the_fp16_range_limit(oracle, sc, cells):
     """The fill uses packed fp16 cells while the score range keeps every value an exact integer
     (fast_plan_build), packed int16 beyond.  Scorings on both sides of the switch, on reads that
@@ -171,6 +173,28 @@ def test_fill_cell_format_switch_at_the_fp16_range_limit(oracle, sc, cells):
     e.close()
     got = lib.decompose(rn, rs, mn, ms, scoring=sc, kernel=lib.KERNEL_FAST)
     assert got == oracle.decompose(rn, rs, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc)
+
+
+FUZZ = os.path.join(GOLDEN, "fuzz")
+
+
+@pytest.mark.parametrize("case", sorted(os.listdir(FUZZ)) if os.path.isdir(FUZZ) else [])
+def test_fuzz_regressions(oracle, case):
+    """Inputs on which tools/fuzz_gpu.py once found a mismatch (kept as data: reads, monomers, parameters).
+    fuzz_fail_906_791: scoring 0,-4,-4,-1 on 300-480 bp monomers -- the fp16 cells left the exact-integer range
+    because the range bound ignored that B can grow by (smax - del) per row (csrc/sd_fast.hip, fast_plan_build)."""
+    d = os.path.join(FUZZ, case)
+    rn, rs, _ = lib.fasta_load(os.path.join(d, "r.fa"))
+    mn, ms, _ = lib.fasta_load(os.path.join(d, "m.fa"))
+    sc, part, ov, ed = eval(open(os.path.join(d, "params.txt")).read())
+    exp = oracle.decompose(rn, rs, mn, ms, threads=8, sc=sc, part=part, overlap=ov, ed_thr=ed)
+    for e2 in sorted({ed, -1}):
+        for sub in (ms, ms[:1]):
+            want = exp if (e2 == ed and sub is ms) else oracle.decompose(rn, rs, mn[:len(sub)], sub, threads=8, sc=sc,
+                                                                        part=part, overlap=ov, ed_thr=e2)
+            for fam in (lib.KERNEL_AUTO, lib.KERNEL_GENERIC):
+                got = lib.decompose(rn, rs, mn[:len(sub)], sub, scoring=sc, part_size=part, overlap=ov, ed_thr=e2, kernel=fam)
+                assert got == want, (case, e2, len(sub), fam)
 
 
 def test_single_long_sequence_custom_scoring_vs_oracle(oracle):

@@ -48,6 +48,12 @@ for case in range(cases):
           (-1, -1, -1, -1), (-4, -4, 3, 3)][rnd(14)]
     if rnd(3) == 0:   # random scorings: exercises both cell formats (fp16 / int16) around the range switch
         sc = (-rnd(9), -rnd(9), rnd(13) - 8, rnd(13) - 2)
+    if rnd(4) == 0:   # the largest |del| that still selects fp16 cells for this set (csrc/sd_fast.hip: ub <= 2040)
+        Lmax, i_, mm_, ma_ = max(len(m) for m in ms), rnd(3), rnd(7) - 5, rnd(5) - 2
+        def ub(d):
+            return ((Lmax - 1) * d + 129 * max(0, max(mm_, ma_) + d) + 128 * i_ + 8 * max(i_, d, abs(mm_), abs(ma_)) + 8)
+        d = max([x for x in range(0, 40) if ub(x) <= 2040] or [0])
+        sc = (-i_, -d, mm_, ma_)
     part, ov = [(5000, 500), (700, 100), (333, 77), (150, 20), (5000, 0)][rnd(5)]
     reads = []
     for r in range(1 + rnd(3)):
