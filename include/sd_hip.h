@@ -180,7 +180,8 @@ int sd_engine_timings(sd_engine* e, float ms[4]);
  * [4] low byte: kernel family actually used (1 generic, 2 fast); bits 8..: cell arithmetic of the fill
  *     (0 int32, 1 packed int16, 2 packed fp16 [exact small integers], 3 wide: int16 cells / int8 table,
  *      4 wide: fp16 cells / bf8 table, 5 multi-wave wide: fp16 cells / template codes in LDS, > 128 templates)
- * [5] cells-per-lane parameter P (fast) or Q
+ * [5] generic: cells-per-thread parameter Q; fast: slots per lane P in bits 0..15, bits 16..: the last slot
+ *     of a lane whose diagonal input needs the maximum with the start term (0 = every slot takes it)
  * [6] bytes of HBM workspace allocated [7] number of fill launches per run */
 int sd_engine_info(sd_engine* e, int64_t info[8]);
 

@@ -837,7 +837,7 @@ int sd_engine_info(sd_engine* e, int64_t info[8]) {
     info[2] = (int64_t)e->chunks.size();
     info[3] = e->rows;
     info[4] = e->family | ((e->family == 1 ? 0 : e->fplan.waves > 1 ? 5 : e->fplan.wide ? (e->fplan.f16 ? 4 : 3) : e->fplan.f16 ? 2 : 1) << 8);
-    info[5] = e->family == 1 ? e->Q : e->fplan.P;
+    info[5] = e->family == 1 ? e->Q : (e->fplan.P | ((int64_t)e->fplan.floor_slots << 16));
     info[6] = (int64_t)e->workspace_bytes();
     info[7] = e->family == 1 ? (int64_t)e->subs.size() : 1;
     return SD_OK;

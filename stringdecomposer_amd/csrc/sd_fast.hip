@@ -28,301 +28,9 @@
 
 #include "sd_fast.hpp"
 #include "sd_fast_dev.hpp"
+#include "sd_fast_fill.hpp"
 
 namespace sd {
-
-
-// ---------------------------------------------------------------------------------------------
-// fill
-// ---------------------------------------------------------------------------------------------
-// Stored state of a wave after row i: S[x] = E[i][x] - base - tp*ins  (tp = rows since the last
-// rebase), so that the insertion move costs nothing:
-//   S_new[x] = max( max(S[x-1], B_i + del - tp*ins) + (mm - del - ins),  S[x],  S_new[x-1] )
-// i.e. 4 packed ops per cell pair: u = max(pd, KB); v = u + tbl; cand = max(v, old); run = max(run, cand).
-#ifndef SD_FILL_NW
-#define SD_FILL_NW 8   // waves (= chunks) per workgroup; two workgroups per CU
-#endif
-//
-// F16 variant: the same recurrence on packed fp16 (every value is an integer of magnitude < 2048,
-// hence exact; -inf is the padding / "no predecessor" value).  gfx950 has v_pk_maximum3_f16, which
-// folds the last two maxima:  u = max(S[x-1], KB);  v = u + tbl;  S_new[x] = max3(S_new[x-1], v, S[x])
-// -- 3 packed ops per cell pair instead of 4.  fast_plan_build() enables it when the score range
-// fits (FastPlan::f16); the checkpoints then hold fp16 pairs (the traceback converts them).
-template <int P, bool RANKED, bool F16>
-__global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
-    const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
-    const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
-    const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int H, int32_t* __restrict__ Bout,
-    int32_t* __restrict__ argV, uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase,
-    int* __restrict__ queue, const int* __restrict__ order, const uint32_t* __restrict__ cendoff,
-    const uint32_t* __restrict__ crank) {
-    constexpr int P4 = (P + 3) & ~3;
-    extern __shared__ uint32_t lds[];  // [5][P4/4][64][4]
-    constexpr int TBL = 5 * P4 * 64;
-    using CO = CellOps<F16>;
-    constexpr uint32_t NEGC = CO::NEG;
-    for (int idx = threadIdx.x * 4; idx < TBL; idx += blockDim.x * 4) {
-        uint4 q = *reinterpret_cast<const uint4*>(&table[idx]);
-        if constexpr (F16) {
-            q.x = CO::from_i16x2(q.x); q.y = CO::from_i16x2(q.y);
-            q.z = CO::from_i16x2(q.z); q.w = CO::from_i16x2(q.w);
-        }
-        *reinterpret_cast<uint4*>(&lds[idx]) = q;
-    }
-    __syncthreads();
-
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nw = (int)(blockDim.x >> 6);
-    const int lane = threadIdx.x & 63;
-    (void)wave; (void)nw;
-    ChunkSched sched;
-    sched.init(queue, order, n_chunks);
-    for (int c = sched.next(); c >= 0; c = sched.next()) {
-    const ChunkDesc cd = chunks[c];
-    const int n = cd.n;
-    ReadStream rs;
-    rs.init(bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr, n);
-
-    const uint32_t* lc = lane_consts + lane * FAST_LANE_WORDS;
-    const uint32_t startMask = lc[FLC_STARTMASK];
-    const uint32_t contMask = lc[FLC_CONTMASK];
-    const uint32_t cont2Mask = lc[FLC_CONT2];
-    const uint32_t endOffPlan = lc[FLC_ENDOFF];
-    // --ed_thr: per-chunk end offsets (-inf for dropped templates) and tie-break ranks
-    // fp16, unranked: the whole B reduction stays in fp16 (no per-row int conversions); `del` is folded
-    // into the end offsets so that the wave maximum is directly the start term B_i + del of the next row
-    constexpr bool HRED = F16 && !RANKED;
-    // HRED row tail.  With a_l = max(last slot, K_l) the total of virtual lane l:
-    //   * the end cell of a template is the maximum of a_l over ALL its lanes (prefix maximum along the
-    //     template), so the B reduction takes every lane's total with its template's end offset
-    //     (FLC_ENDALL) and does not need the scanned value of the end lane;
-    //   * the carry K_l of the row (exclusive scan of a over the template's earlier lanes) is also the
-    //     true last-slot value of lane l-1, i.e. the diagonal input of slot 0 in the next row, and
-    //     KB = max(K, B+del) >= K: slot 0's u is KB itself;
-    //   * totals never decrease from row to row in the stored domain (the insertion move is "keep"),
-    //     so the new carry replaces the old one without a max.
-    const uint32_t endOff = HRED ? CO::from_i16x2(pk_adds(lc[FLC_ENDALL], pack2(sc.del)))
-                                 : CO::from_i16x2(RANKED ? cendoff[(size_t)c * 64 + lane] : endOffPlan);
-    const uint32_t rank2 = RANKED ? crank[(size_t)c * 64 + lane] : 0u;
-    const uint32_t row0adj = CO::from_i16x2(lc[FLC_ROW0]);
-    const uint32_t ins2 = CO::splat(sc.ins);
-
-    int32_t* Bc = Bout + cd.row0 + (uint64_t)c;
-    uint32_t* ck = ckpt + (uint64_t)cd.pad * (uint64_t)(P * 64) + lane;
-    int32_t* ckb = ckbase + cd.pad;
-
-    uint32_t L[P];
-    uint32_t tb[P4];
-    uint32_t K = NEGC;
-    int base = 0, Brel = 0, tp = 0;
-    uint32_t bdel16 = 0;  // HRED: fp16 bits of (row maximum + del), relative like the cells
-    int accBV = 0;  // (B << 7 | arg-max virtual lane) of the last <=64 rows, one row per lane
-
-    // `after` pins the LDS reads behind the value it names (the last slot of the row being
-    // finished): hoisted above the slot loop they would need a second register set + 35 copies
-    auto load_table = [&](int r, uint32_t& after) {
-        uint32_t off = (uint32_t)(r * (P4 * 64) + lane * 4);
-        asm volatile("" : "+v"(off), "+v"(after));
-        const uint32_t* t = lds + off;
-#pragma unroll
-        for (int c4 = 0; c4 < P4 / 4; ++c4) {
-            const uint4 q = *reinterpret_cast<const uint4*>(t + c4 * 256);
-            tb[4 * c4 + 0] = q.x; tb[4 * c4 + 1] = q.y; tb[4 * c4 + 2] = q.z; tb[4 * c4 + 3] = q.w;
-        }
-    };
-    // exclusive, template-segmented prefix maximum over the virtual lanes (both planes at once):
-    // H = Vmax-1 carry hops of one lane each (DPP wave_shr:1)
-    auto excl_scan = [&](uint32_t a) {
-        uint32_t inc = a;
-        if (H <= 4) {  // doubling: window of 4 previous lanes (the masks keep it inside the template;
-                       // with H = 0 they are all zero and the result is -inf everywhere)
-            inc = CO::mx(inc, bfi(contMask, lane_up(inc, 1), NEGC));
-            inc = CO::mx(inc, bfi(cont2Mask, lane_up(lane_up(inc, 1), 1), NEGC));
-        } else {
-            for (int h = 1; h < H; ++h) inc = CO::mx(a, bfi(contMask, lane_up(inc, 1), NEGC));
-        }
-        return bfi(contMask, lane_up(inc, 1), NEGC);
-    };
-    // B_{row} (relative to base) = max over template ends; arg = smallest virtual lane attaining it
-    auto reduce_ends = [&](uint32_t Eend, int row) {
-        if constexpr (HRED) {
-            const uint32_t val = CO::add(Eend, endOff);
-            uint32_t m;
-            asm("v_max_f16_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
-                "s_nop 1\n\t"
-                "v_max_f16_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                "s_nop 1\n\t"
-                "v_max_f16_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-                "s_nop 1\n\t"
-                "v_max_f16_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-                "s_nop 1\n\t"
-                "v_max_f16_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-                "s_nop 1\n\t"
-                "v_max_f16_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-                "s_nop 1\n\t"
-                "v_max_f16_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
-                : "=&v"(m) : "v"(val));
-            const uint32_t b16 = (uint32_t)__builtin_amdgcn_readlane((int)m, 63) & 0xffffu;
-            unsigned long long mlo, mhi;
-            asm("v_cmp_eq_f16_e64 %0, %1, %2" : "=s"(mlo) : "v"(val), "s"(b16));
-            asm("v_cmp_eq_f16_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:WORD_0" : "=s"(mhi) : "v"(val), "s"(b16));
-            const int vlo = __ffsll((long long)mlo) - 1, vhi = 63 + __ffsll((long long)mhi);  // both scalar
-            const int v = vlo >= 0 ? vlo : vhi;
-            bdel16 = b16;
-            const int slot = (row - 1) & 63;
-            acc_put(accBV, (int)((b16 << 7) | (uint32_t)v), slot);
-            if (slot == 63 || row == n) {
-                // 64 rows at once: fp16 -> int, B = base + (b + del) - del + tp_row * ins
-                const uint32_t w = (uint32_t)accBV;
-                const int bi = (int)(float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 7));
-                const int tpl = tp - (slot - lane);
-                const int Bv = base + bi - sc.del + tpl * sc.ins;
-                if (lane <= slot) Bc[row - slot + lane] = (int)(((uint32_t)Bv << 7) | (w & 127u));
-            }
-            return;
-        }
-        const uint32_t val = CO::add(Eend, endOff);
-        int lo, hi;
-        CO::to_int(val, lo, hi);
-        const int b = wave_max(max(lo, hi));
-        unsigned long long mlo, mhi;
-        if (RANKED) {
-            // ties go to the first template of the chunk's filtered order (main.cpp:141-147)
-            const int klo = lo == b ? (int)(rank2 & 0xffffu) : 0x7fff;
-            const int khi = hi == b ? (int)(rank2 >> 16) : 0x7fff;
-            const int kmin = -wave_max(-min(klo, khi));
-            mlo = __ballot(klo == kmin);
-            mhi = __ballot(khi == kmin);
-        } else {
-            mlo = __ballot(lo == b);
-            mhi = __ballot(hi == b);
-        }
-        const int v = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
-        Brel = b + tp * sc.ins;
-        const int slot = (row - 1) & 63;
-        acc_put(accBV, (int)(((uint32_t)(base + Brel) << 7) | (uint32_t)v), slot);
-        if (slot == 63 || row == n) {
-            if (lane <= slot) Bc[row - slot + lane] = accBV;
-        }
-    };
-
-    // ---- row 0 (main.cpp:171-182): E[0][k] = max(E[0][k-1], mm_k - del), E[0][0] = mm_0
-    uint32_t pin = 0;
-    load_table(rs.code(0), pin);
-    rs.advance(0);
-    L[0] = CO::add(tb[0], row0adj);
-#pragma unroll
-    for (int q = 1; q < P; ++q) L[q] = CO::mx(L[q - 1], CO::add(tb[q], ins2));
-    load_table(rs.code(1), L[P - 1]);
-    rs.advance(1);
-    if constexpr (HRED) reduce_ends(L[P - 1], 1);
-    K = excl_scan(L[P - 1]);
-    uint32_t Eend = CO::mx(L[P - 1], K);
-    if constexpr (!HRED) reduce_ends(Eend, 1);
-
-    for (int i = 1; i < n; ++i) {
-        if ((i & (FAST_R - 1)) == 0) {
-            if ((i & (FAST_REBASE - 1)) == 0) {
-                // rebase the int16 state on B_i and fold the row offset tp*ins back in
-                if constexpr (HRED)
-                    Brel = __builtin_amdgcn_readfirstlane((int)(float)__builtin_bit_cast(_Float16, (unsigned short)bdel16)) -
-                           sc.del + tp * sc.ins;
-                const uint32_t d2 = CO::splat(F16 ? -(Brel - tp * sc.ins) : Brel - tp * sc.ins);
-                base += Brel;
-                Brel = 0;
-                tp = 0;
-                if constexpr (HRED) bdel16 = __builtin_amdgcn_readfirstlane((int)(CO::splat(sc.del) & 0xffffu));
-                if constexpr (F16) {
-                    K = bfi(startMask, NEGC, CO::add(K, d2));
-                    Eend = CO::add(Eend, d2);
-#pragma unroll
-                    for (int s = 0; s < P; ++s) L[s] = CO::add(L[s], d2);
-                } else {
-                K = bfi(startMask, NEG2, pk_subs(K, d2));
-                Eend = pk_subs(Eend, d2);
-#pragma unroll
-                for (int s = 0; s < P; ++s) L[s] = pk_subs(L[s], d2);
-                }
-            }
-            // checkpoint the (true) row i-1 for the traceback: E = ckbase + stored value
-            const int q = (i / FAST_R) - 1;
-#pragma unroll
-            for (int s = 0; s < P; ++s) ck[(uint64_t)q * (P * 64) + s * 64] = CO::mx(L[s], K);
-            if (lane == 0) ckb[q] = base + tp * sc.ins;
-        }
-        uint32_t KB;
-        if constexpr (HRED) {
-            // max(K, {b+del, b+del}): the scalar's low half feeds both lanes of the packed op
-            asm("v_pk_max_f16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(KB) : "v"(K), "s"(bdel16));
-        } else {
-            KB = CO::mx(K, CO::splat(Brel + sc.del - tp * sc.ins));
-        }
-        // slot 0's diagonal input is the true last slot of the previous lane = this lane's carry K, and
-        // KB >= K: its u is KB itself (all variants)
-        const uint32_t w0 = bfi(startMask, NEGC, L[0]);
-        uint32_t u_[P], v_[P], c_[P];
-        uint32_t run = 0;
-        // software-pipelined over the slots so that no packed op consumes the result of the
-        // instruction right before it (gfx950 needs a wait state there)
-        if constexpr (F16) {
-#pragma unroll
-            for (int s = 0; s < P + 4; ++s) {
-                if (s >= 4) {
-                    const int q = s - 4;
-                    // slot 0 (HRED): the old carry K joins the chain here, so that the last slot is the
-                    // lane total without a separate max(L[P-1], K) at the end of the row
-                    L[q] = q == 0 ? CO::mx3(v_[0], w0, K) : CO::mx3(L[q - 1], v_[q], L[q]);
-                }
-                if (s >= 2 && s - 2 < P) {
-                    const int q = s - 2;
-                    v_[q] = CO::add(u_[q], tb[q]);
-                }
-                if (s < P) {
-                    const int q = s;
-                    if (q == 0) u_[q] = KB;
-                    else u_[q] = CO::mx(L[q - 1], KB);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            (void)c_; (void)run;
-        } else {
-#pragma unroll
-        for (int s = 0; s < P + 3; ++s) {
-            if (s >= 3) {
-                const int q = s - 3;
-                run = q == 0 ? c_[0] : pk_max(run, c_[q]);
-                L[q] = run;
-            }
-            if (s >= 2 && s - 2 < P) {
-                const int q = s - 2;
-                c_[q] = pk_max(v_[q], q == 0 ? w0 : L[q]);
-            }
-            if (s >= 1 && s - 1 < P) {
-                const int q = s - 1;
-                v_[q] = pk_adds(u_[q], tb[q]);
-            }
-            if (s < P) {
-                const int q = s;
-                u_[q] = q == 0 ? KB : pk_max(L[q - 1], KB);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        }
-        load_table(rs.code(i + 1), L[P - 1]);  // unconditional (clamped): keeps tb[] out of phi copies
-        rs.advance(i + 1);
-        const uint32_t a = F16 ? L[P - 1] : CO::mx(L[P - 1], K);  // fp16: K already joined the chain
-        ++tp;
-        if constexpr (HRED) {
-            reduce_ends(a, i + 1);
-            K = excl_scan(a);
-        } else {
-            K = excl_scan(a);           // totals never decrease: the new carry replaces the old one
-            Eend = CO::mx(a, K);
-            reduce_ends(Eend, i + 1);
-        }
-    }
-    }  // chunk queue
-}
 
 // ---------------------------------------------------------------------------------------------
 // traceback with per-template recomputation
@@ -629,6 +337,20 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     }
     plan.P = P;
     plan.P4 = (P + 3) & ~3;
+    // last slot whose diagonal input needs the floor (see the slot loop of sd_fast_fill): per virtual lane and
+    // read symbol, the slots q >= 1 where the table value exceeds every earlier one of the lane (q >= 1)
+    plan.floor_slots = 1;
+    for (int j = 0; j < T; ++j) {
+        const std::string& s = tseq[(size_t)j];
+        for (int k0 = 0; k0 < (int)s.size(); k0 += P)
+            for (int b = 0; b < 5; ++b) {
+                int run = INT32_MIN;
+                for (int q = 1; q < P && k0 + q < (int)s.size(); ++q) {
+                    const int val = code_of(s[(size_t)(k0 + q)]) == b ? sc.match : sc.mismatch;
+                    if (val > run) { run = val; plan.floor_slots = std::max(plan.floor_slots, q); }
+                }
+            }
+    }
     plan.T = T;
     plan.split = split;
     plan.Lmax = Lmax;
@@ -847,6 +569,12 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
             if (ranked) SD_FILL_K(PP, true, false) else SD_FILL_K(PP, false, false)                  \
         }                                                                                            \
         break;
+    // fp16 cells, 150-200 bp monomers: the variants that skip the dominated start-term maxima (sd_fast_fl.hip);
+    // SD_FILL_FULLFLOOR=1 keeps the full kernel (developer A/B and the parity test of the two)
+    if (!getenv("SD_FILL_FULLFLOOR") &&
+        launch_fast_fill_fl(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, argV,
+                            ckpt, ckbase, queue, order, cendoff, crank))
+        return;
     switch (plan.P) {
         SD_FILL(4) SD_FILL(8) SD_FILL(12) SD_FILL(16) SD_FILL(20) SD_FILL(24) SD_FILL(28) SD_FILL(30)
         SD_FILL(31) SD_FILL(32) SD_FILL(33) SD_FILL(34) SD_FILL(35) SD_FILL(36) SD_FILL(37) SD_FILL(38)

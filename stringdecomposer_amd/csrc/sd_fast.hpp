@@ -47,6 +47,7 @@ struct FastPlan {
     int Qk = 0;           // traceback: template cells per lane = ceil(Lmax/64)
     int waves = 1;        // waves per chunk: 1, or ceil(T/128) for the multi-wave wide layout (sd_fast_wn.hip)
     int bshift = 7;       // B words: (B_i << bshift) | arg-max (wave << 7 | virtual lane)
+    int floor_slots = 0;  // last slot of a lane whose diagonal input needs the max with the start term (see sd_fast_fill)
     uint32_t bf8_match = 0, bf8_mismatch = 0;   // multi-wave wide layout: bf8 bytes of the two table values
     std::vector<int32_t> vlane0;         // first virtual lane of template j
     std::vector<uint32_t> table;         // narrow: [5][P4/4][64][4] packed int16 (mm - del - ins), NEG on padding
@@ -86,6 +87,13 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
                       uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order, int n_cu,
                       const uint32_t* cendoff, const uint32_t* crank, size_t min_lds = 0);
 
+// variants with the start-term maximum in the first slots of a lane only (sd_fast_fl.hip); false = not covered
+bool launch_fast_fill_fl(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks,
+                         int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                         const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
+                         int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
+                         const uint32_t* crank);
+
 // wide variant (sd_fast_wide.hip), called by launch_fast_fill when plan.wide
 void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                            const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
@@ -93,11 +101,21 @@ void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc
                            int32_t* ckbase, int* queue, const int* order, int n_cu,
                            const uint32_t* cendoff, const uint32_t* crank);
 
+bool launch_fast_fill_wide_fl(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks,
+                              int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                              const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
+                              int* queue, const int* order, const uint32_t* cendoff, const uint32_t* crank);
+
 // multi-wave wide variant (sd_fast_wn.hip): more than 128 templates, W = plan.waves waves per chunk
 void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                          const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                          const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
                          int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank);
+
+bool launch_fast_fill_wn_fl(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks,
+                            int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                            const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
+                            int* queue, const int* order, const uint32_t* cendoff, const uint32_t* crank);
 
 void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                        const uint32_t* bases2, const uint32_t* nmask, const uint32_t* slot_of,

@@ -1,0 +1,57 @@
+// sd_fast_fl.hip -- instantiations of sd_fast_fill (sd_fast_fill.hpp) that take the maximum of a slot's
+// diagonal input with the start term only in the first FL slots of a lane.
+//
+// In the recurrence  S'[x] = max3(S'[x-1], max(S[x-1], KB) + tbl[x], S[x])  the term KB + tbl[x] (KB = the
+// row's start term B_i + del joined with the lane's lazy carry) is one more candidate of slot x.  S' is a
+// prefix maximum along the slots, and tbl takes two values per read symbol, so KB + tbl[x] can only raise
+// S'[x] where tbl[x] exceeds every tbl[x'] of an earlier slot x' >= 1 of the lane -- slot 1 and the first
+// slot holding the read's base (main.cpp:187-207 evaluates the start term in every cell; this is the same
+// maximum with the dominated candidates left out).  fast_plan_build finds the last such slot over all lanes
+// and the five read symbols (FastPlan::floor_slots: 15 on the synthetic 12-monomer set, 23 on the DXZ1
+// monomers of the reference's test data); behind it a slot costs 2 packed ops instead of 3.
+//
+// Only the slot counts of 150-200 bp monomer sets (P = 30..40) and the fp16 cell format get these variants;
+// everything else runs the full kernels of sd_fast.hip.
+#include "sd_fast_fill.hpp"
+
+namespace sd {
+
+bool launch_fast_fill_fl(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks,
+                         int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                         const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
+                         int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
+                         const uint32_t* crank) {
+    if (!plan.f16 || plan.wide || plan.P < 30 || plan.P > 40 || plan.floor_slots < 1) return false;
+    int fl = 0;
+    for (int c : {12, 16, 20, 24, 28})
+        if (plan.floor_slots <= c && c + 2 < plan.P) { fl = c; break; }
+    if (fl == 0) return false;
+    const bool ranked = cendoff != nullptr;
+#define SD_FL_K(PP, RK, FF)                                                                           \
+    {                                                                                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, true, FF>),     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+        hipLaunchKernelGGL((sd_fast_fill<PP, RK, true, FF>), dim3(grid), dim3(SD_FILL_NW * 64), lds,  \
+                           st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, plan.H, B,   \
+                           argV, ckpt, ckbase, queue, order, cendoff, crank);                        \
+        return true;                                                                                 \
+    }
+#define SD_FL_F(PP, FF)                                                                               \
+    if (fl == FF && FF + 2 < PP) {                                                                   \
+        if (ranked) SD_FL_K(PP, true, FF) else SD_FL_K(PP, false, FF)                                 \
+    }
+#define SD_FL(PP)                                                                                     \
+    case PP:                                                                                         \
+        SD_FL_F(PP, 12) SD_FL_F(PP, 16) SD_FL_F(PP, 20) SD_FL_F(PP, 24) SD_FL_F(PP, 28)               \
+        break;
+    switch (plan.P) {
+        SD_FL(30) SD_FL(31) SD_FL(32) SD_FL(33) SD_FL(34) SD_FL(35) SD_FL(36) SD_FL(37) SD_FL(38) SD_FL(39) SD_FL(40)
+        default: break;
+    }
+#undef SD_FL
+#undef SD_FL_F
+#undef SD_FL_K
+    return false;
+}
+
+}  // namespace sd

@@ -1,0 +1,223 @@
+// sd_fast_wn_fill.hpp -- the multi-wave wide fill kernel, shared by sd_fast_wn.hip and sd_fast_wn_fl.hip (the
+// variant that skips the start-term maximum behind the first FL slots; see sd_fast_fl.hip).  Described at
+// the top of sd_fast_wn.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "sd_fast.hpp"
+#include "sd_fast_dev.hpp"
+
+namespace sd {
+
+namespace {
+__device__ __forceinline__ uint32_t cvt_bf8_pair(uint32_t tb, int pair, uint32_t one_s) {
+    uint32_t v;
+    if (pair == 0) asm("v_cvt_scalef32_pk_f16_bf8 %0, %1, %2" : "=v"(v) : "v"(tb), "s"(one_s));
+    else asm("v_cvt_scalef32_pk_f16_bf8 %0, %1, %2 op_sel:[1,0,0]" : "=v"(v) : "v"(tb), "s"(one_s));
+    return v;
+}
+}  // namespace
+
+template <int P, bool RANKED, int FL = P>
+__global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
+    const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
+    const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ codes,
+    const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int W, uint32_t mb, uint32_t xb,
+    int32_t* __restrict__ Bout, uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase,
+    int* __restrict__ queue, const int* __restrict__ order, const uint32_t* __restrict__ cendoff,
+    const uint32_t* __restrict__ crank) {
+    static_assert(P % 16 == 0, "the code table is streamed 16 slots at a time");
+    constexpr int G = P / 16;
+    extern __shared__ uint32_t lds[];  // [W][G][2 halves][64 lanes][4 dwords] codes, then the exchange area
+    const int TBL = W * G * 512;
+    for (int idx = threadIdx.x * 4; idx < TBL; idx += blockDim.x * 4)
+        *reinterpret_cast<uint4*>(&lds[idx]) = *reinterpret_cast<const uint4*>(&codes[idx]);
+    int32_t* xv = reinterpret_cast<int32_t*>(lds + TBL);   // [2 parities][8 waves] wave maxima
+    int32_t* xa = xv + 16;                                 // [2][8] arg-max virtual lane of each wave
+    int32_t* xr = xa + 16;                                 // [2][8] --ed_thr: smallest rank among each wave's maxima
+    int32_t* xc = xr + 16;                                 // [1] chunk of the workgroup
+    __syncthreads();
+
+    using CO = CellOps<true>;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const uint32_t* myc = lds + wave * (G * 512);
+    const uint32_t* lc = lane_consts + (size_t)(wave * 64 + lane) * FAST_LANE_WORDS;
+    const uint32_t endOffPlan = lc[FLC_ENDOFF];
+    const uint32_t row0adj = CO::from_i16x2(lc[FLC_ROW0]);
+    const uint32_t ins2 = CO::splat(sc.ins);
+
+    for (;;) {
+        if (threadIdx.x == 0) {
+            const int q = atomicAdd(queue, 1);
+            xc[0] = q < n_chunks ? order[q] : -1;
+        }
+        __syncthreads();
+        const int c = __builtin_amdgcn_readfirstlane(xc[0]);
+        __syncthreads();
+        if (c < 0) break;
+        const ChunkDesc cd = chunks[c];
+        const int n = cd.n;
+        ReadStream rs;
+        rs.init(bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr, n);
+        // --ed_thr: per-chunk end offsets (-inf for dropped templates) and tie-break ranks (main.cpp:141-147)
+        const size_t cl = ((size_t)c * (size_t)W + (size_t)wave) * 64 + (size_t)lane;
+        const uint32_t endOff = CO::from_i16x2(RANKED ? cendoff[cl] : endOffPlan);
+        const uint32_t rank2 = RANKED ? crank[cl] : 0u;
+        int32_t* Bc = Bout + cd.row0 + (uint64_t)c;
+        uint32_t* ck = ckpt + ((uint64_t)cd.pad * (uint64_t)W + (uint64_t)wave) * (uint64_t)(P * 64) + lane;
+        int32_t* ckb = ckbase + cd.pad;
+
+        uint32_t L[P];
+        uint32_t cg[2][8];  // 16 slots of codes per buffer: dword d = slots 2d, 2d+1 as {lo, hi, lo, hi} bytes
+        int base = 0, Brel = 0, tp = 0;
+        int accBV = 0;
+
+        auto load_group = [&](int g, int buf, uint32_t& after) {
+            uint32_t off = (uint32_t)(g * 512 + lane * 4);
+            asm volatile("" : "+v"(off), "+v"(after));
+            const uint4 q0 = *reinterpret_cast<const uint4*>(myc + off);
+            const uint4 q1 = *reinterpret_cast<const uint4*>(myc + off + 256);
+            cg[buf][0] = q0.x; cg[buf][1] = q0.y; cg[buf][2] = q0.z; cg[buf][3] = q0.w;
+            cg[buf][4] = q1.x; cg[buf][5] = q1.y; cg[buf][6] = q1.z; cg[buf][7] = q1.w;
+        };
+        // the eight table bytes of a row symbol r: code 0..4 -> match / mismatch, 5..7 -> -inf (padding = 7)
+        auto pool_of = [&](int r, uint32_t& plo, uint32_t& phi) {
+            uint32_t lo = xb * 0x01010101u, hi = 0xFCFCFC00u | xb;
+            if (r < 4) lo = (lo & ~(0xffu << (8 * r))) | (mb << (8 * r));
+            else hi = 0xFCFCFC00u | mb;
+            plo = lo;
+            phi = hi;
+        };
+        // B_{row} = max over ALL template ends of the chunk; arg = smallest (wave, virtual lane) attaining it
+        auto reduce_ends = [&](uint32_t Eend, int row) {
+            const uint32_t val = CO::add(Eend, endOff);
+            int lo, hi;
+            CO::to_int(val, lo, hi);
+            const int bw = wave_max(max(lo, hi));
+            unsigned long long mlo, mhi;
+            int kw = 0;
+            if (RANKED) {
+                // among equal values the first template of the chunk's filtered order wins (smallest rank)
+                const int klo = lo == bw ? (int)(rank2 & 0xffffu) : 0x7fff;
+                const int khi = hi == bw ? (int)(rank2 >> 16) : 0x7fff;
+                kw = -wave_max(-min(klo, khi));
+                mlo = __ballot(klo == kw);
+                mhi = __ballot(khi == kw);
+            } else {
+                mlo = __ballot(lo == bw);
+                mhi = __ballot(hi == bw);
+            }
+            const int vw = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
+            const int par = (row & 1) * 8;
+            if (lane == 0) { xv[par + wave] = bw; xa[par + wave] = vw; xr[par + wave] = kw; }
+            __syncthreads();
+            int b = xv[par], arg = xa[par], rk = xr[par];
+            for (int w2 = 1; w2 < W; ++w2) {
+                const int b2 = xv[par + w2], r2 = xr[par + w2];
+                if (b2 > b || (RANKED && b2 == b && r2 < rk)) { b = b2; rk = r2; arg = (w2 << 7) | xa[par + w2]; }
+            }
+            b = __builtin_amdgcn_readfirstlane(b);
+            arg = __builtin_amdgcn_readfirstlane(arg);
+            Brel = b + tp * sc.ins;
+            if (wave == 0) {
+                const int slot = (row - 1) & 63;
+                acc_put(accBV, (int)(((uint32_t)(base + Brel) << 10) | (uint32_t)arg), slot);
+                if (slot == 63 || row == n) {
+                    if (lane <= slot) Bc[row - slot + lane] = accBV;
+                }
+            }
+        };
+
+        // ---- row 0 (main.cpp:171-182)
+        {
+            const int r0 = rs.code(0);
+            rs.advance(0);
+            uint32_t plo, phi;
+            pool_of(r0, plo, phi);
+            uint32_t pin = 0;
+            uint32_t run = 0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                load_group(g, 0, pin);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int q = 16 * g + s;
+                    const uint32_t tb = __builtin_amdgcn_perm(phi, plo, cg[0][s >> 1]);
+                    const uint32_t t16 = CO::add(q == 0 ? row0adj : ins2, cvt_bf8_pair(tb, s & 1, 0x3f800000u));
+                    run = q == 0 ? t16 : CO::mx(run, t16);
+                    L[q] = run;
+                }
+                pin = run;
+            }
+            reduce_ends(L[P - 1], 1);
+        }
+        int rnext = rs.code(1);
+        rs.advance(1);
+        load_group(0, 0, L[P - 1]);
+        for (int i = 1; i < n; ++i) {
+            const int rcur = rnext;
+            if ((i & (FAST_R - 1)) == 0) {
+                if ((i & (FAST_REBASE - 1)) == 0) {
+                    const uint32_t d2 = CO::splat(Brel - tp * sc.ins);
+                    base += Brel;
+                    Brel = 0;
+                    tp = 0;
+#pragma unroll
+                    for (int s = 0; s < P; ++s) L[s] = CO::sub(L[s], d2);
+                }
+                const int q = (i / FAST_R) - 1;
+                uint32_t* ckq = ck + (uint64_t)q * (uint64_t)W * (uint64_t)(P * 64);
+#pragma unroll
+                for (int s = 0; s < P; ++s) ckq[s * 64] = L[s];
+                if (wave == 0 && lane == 0) ckb[q] = base + tp * sc.ins;
+            }
+            const uint32_t KB = CO::splat(Brel + sc.del - tp * sc.ins);
+            uint32_t plo, phi;
+            pool_of(rcur, plo, phi);
+            uint32_t u_[P], v_[P], t_[P];
+            uint32_t KBs = (uint32_t)__builtin_amdgcn_readfirstlane((int)KB);
+            uint32_t one_s = 0x3f800000u;
+            uint32_t tbw = 0;
+            // 4.5 ops per slot: [perm per 2 slots]; t = cvt(bf8 pair); u = max(S[x-1], KB); v = u + t;
+            // S'[x] = max3(S'[x-1], v, S[x]), software-pipelined over the slots like the single-wave kernel
+#pragma unroll
+            for (int s = 0; s < P + 4; ++s) {
+                if (s >= 4) {
+                    const int q = s - 4;
+                    L[q] = q == 0 ? v_[0] : CO::mx3(L[q - 1], v_[q], L[q]);  // k == 0: start term only
+                }
+                if (s >= 2 && s - 2 < P) {
+                    const int q = s - 2;
+                    v_[q] = CO::add(u_[q], t_[q]);
+                }
+                if (s < P) {
+                    const int q = s;
+                    uint32_t u;
+                    // behind slot FL the start term is dominated (FastPlan::floor_slots, see sd_fast_fl.hip)
+                    if (q == 0) u = KB;
+                    else if (q > FL) u = L[q - 1];
+                    else asm("v_pk_max_f16 %0, %1, %2" : "=v"(u) : "v"(L[q - 1]), "s"(KBs));
+                    u_[q] = u;
+                    if ((q & 1) == 0) tbw = __builtin_amdgcn_perm(phi, plo, cg[(q >> 4) & 1][(q & 15) >> 1]);
+                    t_[q] = cvt_bf8_pair(tbw, q & 1, one_s);
+                    if ((q & 15) == 2 && (q >> 4) + 1 < G) load_group((q >> 4) + 1, ((q >> 4) + 1) & 1, t_[q]);
+                }
+                const uint32_t pinL = L[s >= 4 ? s - 4 : 0];
+                asm volatile("" : "+s"(KBs), "+s"(one_s) : "v"(pinL));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rnext = rs.code(i + 1);
+            rs.advance(i + 1);
+            load_group(0, 0, L[P - 1]);
+            ++tp;
+            reduce_ends(L[P - 1], i + 1);
+        }
+        __syncthreads();   // the exchange area and xc are rewritten for the next chunk
+    }
+}
+
+}  // namespace sd

@@ -356,7 +356,9 @@ def _info_dict(v):
             "family": {1: "generic", 2: "fast"}.get(v[4] & 0xff, "?"),
             "cells": {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table", 4: "f16/bf8-table",
                       5: "f16/bf8-codes x waves"}.get(v[4] >> 8, "?"),
-            "cells_per_lane": v[5], "workspace_bytes": v[6], "fill_launches": v[7]}
+            "cells_per_lane": v[5] if (v[4] & 0xff) == 1 else v[5] & 0xffff,
+            "floor_slots": 0 if (v[4] & 0xff) == 1 else v[5] >> 16,
+            "workspace_bytes": v[6], "fill_launches": v[7]}
 
 
 class ReadSet:

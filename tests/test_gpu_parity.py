@@ -566,6 +566,61 @@ def test_template_sets_beyond_the_fast_family_vs_oracle(oracle, nm, lo, hi):
         assert gen == exp, (nm, sc, ed, "generic")
 
 
+def _late_base_monomers():
+    """Monomers whose lanes meet a base late or never: long homopolymer / two-letter prefixes, a base that is
+    missing altogether, an N in the middle of a lane -- the cases that decide FastPlan::floor_slots."""
+    st = synth.Stream(77, 3)
+    rnd = lambda n, alpha=b"ACGT": bytes(alpha[int(x)] for x in st.below(n, len(alpha)))
+    ms = [b"A" * 19 + rnd(150), rnd(30, b"AT") + rnd(140), rnd(171, b"ACT"), rnd(20) + b"N" + rnd(150),
+          rnd(165), b"ACGT" + rnd(166), rnd(60) + b"C" * 25 + rnd(90), rnd(175), rnd(168), rnd(172),
+          rnd(33, b"GC") + rnd(140), rnd(170)]   # 12 monomers -> 24 templates of 5 lanes: P = 35
+    return ["m%d" % i for i in range(len(ms))], ms
+
+
+@pytest.mark.parametrize("name", ["synthetic12", "dxz1", "late_bases", "late_bases_ed", "wide64", "wide64_ed", "waves140"])
+def test_fill_without_dominated_start_maxima(oracle, name):
+    """csrc/sd_fast_fl.hip: behind the first FL slots of a lane the fill leaves out the maximum with the start
+    term (the candidate is dominated there).  Same rows as the full kernel (SD_FILL_FULLFLOOR=1) and as the
+    oracle, for template sets with small, typical and large floor_slots, with and without --ed_thr."""
+    ed = -1
+    if name == "synthetic12":
+        mn, ms = synth.make_monomers(12, seed=1)
+    elif name == "dxz1":
+        mn, ms, _ = lib.fasta_load(os.path.join(GOLDEN, "test_data", "DXZ1_star_monomers.fa"))
+    elif name.startswith("wide64"):
+        mn, ms = synth.make_monomers(64, seed=7)       # 128 templates: one per virtual lane, bf8 table
+        ed = 60 if name.endswith("_ed") else -1
+    elif name == "waves140":
+        mn, ms = synth.make_monomers(140, seed=8)      # 280 templates: three waves per chunk
+    else:
+        mn, ms = _late_base_monomers()
+        ed = 40 if name.endswith("_ed") else -1
+    rn, rs = synth.make_reads(ms, 3, read_len=9000 if len(ms) <= 12 else 2500, seed=11)
+    st = synth.Stream(5, 9)
+    rs = list(rs) + [(ms[0].replace(b"N", b"A") * 30)[:3000], synth._ACGT[st.below(2500, 4)].tobytes(),
+                     b"G" * 400 + ms[-1].replace(b"N", b"C") * 4 + b"N" * 3 + ms[1].replace(b"N", b"C") * 3]
+    rn = ["r%d" % i for i in range(len(rs))]
+    e = lib.Engine(ms, kernel=lib.KERNEL_FAST, ed_thr=ed)
+    info = e.info()
+    e.close()
+    if len(ms) <= 12:
+        assert info["cells"] == "f16" and 30 <= info["cells_per_lane"] <= 40
+    else:
+        assert info["cells"] in ("f16/bf8-table", "f16/bf8-codes x waves"), info
+    lo, hi = {"synthetic12": (8, 16), "dxz1": (17, 24), "late_bases": (25, 40), "late_bases_ed": (25, 40),
+              "wide64": (8, 32), "wide64_ed": (8, 32), "waves140": (8, 48)}[name]
+    assert lo <= info["floor_slots"] <= hi, info
+    exp = oracle.decompose(rn, rs, mn, ms, threads=8, ed_thr=ed)
+    got = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, ed_thr=ed)
+    os.environ["SD_FILL_FULLFLOOR"] = "1"
+    try:
+        full = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, ed_thr=ed)
+    finally:
+        del os.environ["SD_FILL_FULLFLOOR"]
+    assert full == exp
+    assert got == exp
+
+
 def test_multi_wave_wide_layout_long_reads_vs_generic_and_oracle(oracle):
     """More than 128 templates on the fast path (sd_fast_fill_wn: W waves per chunk, template codes in LDS,
     one workgroup barrier per row): 150 monomers = 300 templates = 3 waves, reads of 50 kb (checkpoints,
