@@ -338,13 +338,14 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     plan.P = P;
     plan.P4 = (P + 3) & ~3;
     // last slot whose diagonal input needs the floor (see the slot loop of sd_fast_fill): per virtual lane and
-    // read symbol, the slots q >= 1 where the table value exceeds every earlier one of the lane (q >= 1)
+    // read symbol, the slots q >= 1 where the table value exceeds every earlier one of the lane (slot 0 always
+    // takes the start term / the carry: its candidate KB + tbl[0] is in the chain from there on)
     plan.floor_slots = 1;
     for (int j = 0; j < T; ++j) {
         const std::string& s = tseq[(size_t)j];
         for (int k0 = 0; k0 < (int)s.size(); k0 += P)
             for (int b = 0; b < 5; ++b) {
-                int run = INT32_MIN;
+                int run = code_of(s[(size_t)k0]) == b ? sc.match : sc.mismatch;
                 for (int q = 1; q < P && k0 + q < (int)s.size(); ++q) {
                     const int val = code_of(s[(size_t)(k0 + q)]) == b ? sc.match : sc.mismatch;
                     if (val > run) { run = val; plan.floor_slots = std::max(plan.floor_slots, q); }

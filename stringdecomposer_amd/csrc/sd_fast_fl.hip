@@ -10,8 +10,8 @@
 // and the five read symbols (FastPlan::floor_slots: 15 on the synthetic 12-monomer set, 23 on the DXZ1
 // monomers of the reference's test data); behind it a slot costs 2 packed ops instead of 3.
 //
-// Only the slot counts of 150-200 bp monomer sets (P = 30..40) and the fp16 cell format get these variants;
-// everything else runs the full kernels of sd_fast.hip.
+// Only slot counts P >= 30 (P = 30..40 here, 42..64 in sd_fast_fl_long.hip) and the fp16 cell format get these
+// variants; everything else runs the full kernels of sd_fast.hip.
 #include "sd_fast_fill.hpp"
 
 namespace sd {
@@ -21,7 +21,10 @@ bool launch_fast_fill_fl(const FastPlan& plan, hipStream_t st, int grid, size_t 
                          const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
                          int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
                          const uint32_t* crank) {
-    if (!plan.f16 || plan.wide || plan.P < 30 || plan.P > 40 || plan.floor_slots < 1) return false;
+    if (!plan.f16 || plan.wide || plan.P < 30 || plan.floor_slots < 1) return false;
+    if (plan.P > 40)
+        return launch_fast_fill_fl_long(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
+                                        argV, ckpt, ckbase, queue, order, cendoff, crank);
     int fl = 0;
     for (int c : {12, 16, 20, 24, 28})
         if (plan.floor_slots <= c && c + 2 < plan.P) { fl = c; break; }

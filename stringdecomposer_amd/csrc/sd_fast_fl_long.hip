@@ -1,0 +1,43 @@
+// sd_fast_fl_long.hip -- the variants of sd_fast_fl.hip for P = 42..64 slots per lane (sets of 13 to 23 monomers
+// of ~170 bp, or longer monomers), in their own translation unit so that the library builds in parallel.
+#include "sd_fast_fill.hpp"
+
+namespace sd {
+
+bool launch_fast_fill_fl_long(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks,
+                              int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                              const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
+                              int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
+                              const uint32_t* crank) {
+    if (!plan.f16 || plan.wide || plan.P <= 40 || plan.floor_slots < 1) return false;
+    const int fl = plan.floor_slots <= 16 ? 16 : plan.floor_slots <= 24 ? 24 : plan.floor_slots <= 32 ? 32 : 0;
+    if (fl == 0) return false;
+    const bool ranked = cendoff != nullptr;
+#define SD_FL_K(PP, RK, FF)                                                                           \
+    {                                                                                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, true, FF>),     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
+        hipLaunchKernelGGL((sd_fast_fill<PP, RK, true, FF>), dim3(grid), dim3(SD_FILL_NW * 64), lds,  \
+                           st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, plan.H, B,   \
+                           argV, ckpt, ckbase, queue, order, cendoff, crank);                        \
+        return true;                                                                                 \
+    }
+#define SD_FL_F(PP, FF)                                                                               \
+    if (fl == FF) {                                                                                  \
+        if (ranked) SD_FL_K(PP, true, FF) else SD_FL_K(PP, false, FF)                                 \
+    }
+#define SD_FL(PP)                                                                                     \
+    case PP:                                                                                         \
+        SD_FL_F(PP, 16) SD_FL_F(PP, 24) SD_FL_F(PP, 32)                                               \
+        break;
+    switch (plan.P) {
+        SD_FL(42) SD_FL(44) SD_FL(46) SD_FL(48) SD_FL(52) SD_FL(56) SD_FL(60) SD_FL(64)
+        default: break;
+    }
+#undef SD_FL
+#undef SD_FL_F
+#undef SD_FL_K
+    return false;
+}
+
+}  // namespace sd

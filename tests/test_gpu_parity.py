@@ -577,7 +577,8 @@ def _late_base_monomers():
     return ["m%d" % i for i in range(len(ms))], ms
 
 
-@pytest.mark.parametrize("name", ["synthetic12", "dxz1", "late_bases", "late_bases_ed", "wide64", "wide64_ed", "waves140"])
+@pytest.mark.parametrize("name", ["synthetic12", "dxz1", "late_bases", "late_bases_ed", "synthetic16", "synthetic20_ed",
+                                  "wide64", "wide64_ed", "waves140"])
 def test_fill_without_dominated_start_maxima(oracle, name):
     """csrc/sd_fast_fl.hip: behind the first FL slots of a lane the fill leaves out the maximum with the start
     term (the candidate is dominated there).  Same rows as the full kernel (SD_FILL_FULLFLOOR=1) and as the
@@ -587,6 +588,11 @@ def test_fill_without_dominated_start_maxima(oracle, name):
         mn, ms = synth.make_monomers(12, seed=1)
     elif name == "dxz1":
         mn, ms, _ = lib.fasta_load(os.path.join(GOLDEN, "test_data", "DXZ1_star_monomers.fa"))
+    elif name == "synthetic16":
+        mn, ms = synth.make_monomers(16, seed=4)       # 32 templates of 4 lanes: P = 44 (sd_fast_fl_long.hip)
+    elif name == "synthetic20_ed":
+        mn, ms = synth.make_monomers(20, seed=6)       # 40 templates of 3 lanes: P = 60
+        ed = 50
     elif name.startswith("wide64"):
         mn, ms = synth.make_monomers(64, seed=7)       # 128 templates: one per virtual lane, bf8 table
         ed = 60 if name.endswith("_ed") else -1
@@ -605,10 +611,12 @@ def test_fill_without_dominated_start_maxima(oracle, name):
     e.close()
     if len(ms) <= 12:
         assert info["cells"] == "f16" and 30 <= info["cells_per_lane"] <= 40
+    elif len(ms) <= 20:
+        assert info["cells"] == "f16" and 42 <= info["cells_per_lane"] <= 64
     else:
         assert info["cells"] in ("f16/bf8-table", "f16/bf8-codes x waves"), info
     lo, hi = {"synthetic12": (8, 16), "dxz1": (17, 24), "late_bases": (25, 40), "late_bases_ed": (25, 40),
-              "wide64": (8, 32), "wide64_ed": (8, 32), "waves140": (8, 48)}[name]
+              "synthetic16": (8, 24), "synthetic20_ed": (8, 32), "wide64": (8, 32), "wide64_ed": (8, 32), "waves140": (8, 48)}[name]
     assert lo <= info["floor_slots"] <= hi, info
     exp = oracle.decompose(rn, rs, mn, ms, threads=8, ed_thr=ed)
     got = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, ed_thr=ed)
