@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
                 cl.code[q] = kk < Lj ? (int)tcodes[x0 + kk] : 7;
                 cl.slot[q] = kk < Lj ? (int)slot_of[x0 + kk] : 0;
 #pragma unroll
-                for (int b = 0; b < 5; ++b) mt[b][lane][q] = (int16_t)(4 * (cl.code[q] == b ? mD : xD) - 2);
+                for (int b = 0; b < 5; ++b) mt[b][lane][q] = (int16_t)(4 * ((cl.code[q] == b ? mD : xD) - ins) - 1);
             }
             return cl;
         };
@@ -113,9 +113,12 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
         // Cells are kept as T = 4*E + 3, and every candidate of the cell update carries the reference's
         // traceback priority in its two low bits -- DEL 3 > INS 2 > DIAG 1 > START 0 (main.cpp:242-253) -- so
         // that ONE maximum yields both the value and, among equal values, the move the reference's equality
-        // tests would pick first; no compares.  With Bd2 = 4*(B_i + del) + 2 and mm4 = 4*(mm - del) - 2:
-        //     diag / start:  max(T[k-1], Bd2) + mm4   -> 4*(E[k-1] + mm - del) + 1  or  4*(B_i + mm) + 0
-        //     insertion:     T[k] + (4*ins - 1)       -> 4*(E[k] + ins) + 2
+        // tests would pick first; no compares.  Rows are kept in the fill's row-shifted domain E' = E - i*ins, where
+        // the insertion move is "keep", and a finished row is stored with the INSERTION tag, T = 4*E' + 2, so that
+        // the insertion candidate of the next row is the stored value itself.  With Bd1 = 4*(B_i + del - (i-1)*ins) + 1
+        // and mm4 = 4*(mm - del - ins) - 1:
+        //     diag / start:  max(T[k-1], Bd1) + mm4   -> 4*(E'[k-1] + mm - del - ins) + 1  or  4*(start term) + 0
+        //     insertion:     T[k]                     -> 4*E'[k] + 2
         //     deletion:      (left cell's result) | 3
         auto block = [&](auto qq_c, const Cells cl, const int i_in, const int k_in) -> Pos {
             constexpr int QQ = decltype(qq_c)::value;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
                     const int tg = Ef == left ? 3 : 0;  // k == 0: left = -inf
                     bits |= (uint32_t)tg << (2 * q);
                     left = Ef;
-                    T[q] = 4 * Ef + 3;
+                    T[q] = 4 * Ef + 2;
                 }
                 pt[0][lane] = (pt_t)bits;
                 rstart = 1;
@@ -163,16 +166,16 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
                     const uint32_t hw = (v >> 6) ? (wv >> 16) : (wv & 0xffffu);
                     const int32_t Ev = cb + (ckf16 ? (int)(float)__builtin_bit_cast(_Float16, (unsigned short)hw)
                                                    : (int)(short)hw);
-                    T[q] = 4 * max(Ev, -0x08000000) + 3;  // padding cells hold the fill's "-inf": keep them far below, no overflow
+                    // row a-1, shifted by (a-1)*ins; padding cells hold the fill's "-inf": keep them far below, no overflow
+                    T[q] = 4 * (max(Ev, -0x08000000) - (a - 1) * ins) + 2;
                 }
                 rstart = a;
             }
             // per-row scalars of the block, one row per lane (read once, then v_readlane per row)
             const int rl = a + lane;
             const bool rvalid = rl >= 1 && rl <= i;
-            const int vBd = rvalid ? 4 * (Bof(rl) + del) + 2 : 0;
+            const int vBd = rvalid ? 4 * (Bof(rl) + del - (rl - 1) * ins) + 1 : 0;
             const int vR = rvalid ? rc.code(rl) : 0;
-            const int ins4 = 4 * ins - 1;
             for (int r_i = rstart; r_i <= i; ++r_i) {
                 const int r = __builtin_amdgcn_readlane(vR, r_i - a);
                 const int32_t Bd2 = __builtin_amdgcn_readlane(vBd, r_i - a);
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
 #pragma unroll
                 for (int q = 0; q < QQ; ++q) {
                     const int32_t v = max(pd, Bd2) + mm4[q];   // diag (tag 1) / start (tag 0); lane 0: pd = -inf
-                    const int32_t w = T[q] + ins4;             // insertion (tag 2)
+                    const int32_t w = T[q];                    // insertion (tag 2): the stored value itself
                     if (q == 0) {
                         // k == 0 (lane 0): the fill never takes the insertion there, but the reference's
                         // traceback tests it (main.cpp:245): the value stays v; the move is INS iff w == v
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
                 for (int q = 0; q < QQ; ++q) {
                     const int32_t Ef = max(loc[q], X);
                     bits = __builtin_amdgcn_alignbit((uint32_t)Ef, bits, 2);   // tag into the top, oldest cell lowest
-                    T[q] = Ef | 3;
+                    asm("v_and_or_b32 %0, %1, -4, 2" : "=v"(T[q]) : "v"(Ef));   // (Ef & ~3) | 2 in one op
                 }
                 pt[r_i - a][lane] = (pt_t)(bits >> (32 - 2 * QQ));
             }
