@@ -116,11 +116,7 @@ namespace {
 inline double now_seconds() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-inline void put_f2(std::string& o, double v) {
-    char b[64];
-    const int n = std::snprintf(b, sizeof b, "%.2f", v);   // == Python "{:.2f}".format(v)
-    o.append(b, (size_t)n);
-}
+inline void put_f2(std::string& o, double v) { put_fixed2(o, v); }   // == Python "{:.2f}".format(v)
 }  // namespace
 
 int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off, std::string& fin,

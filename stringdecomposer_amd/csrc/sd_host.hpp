@@ -122,6 +122,41 @@ inline void put_int(std::string& o, int64_t v) {
     o.append(buf + p, 24 - p);
 }
 
+// "%.2f" of a double, appended: the correctly rounded (ties to even, on the exact binary value) two-decimal
+// text that printf and Python's "{:.2f}".format give (main.py:157-165), without printf: the value is
+// m * 2^-sh exactly, so floor(100 v) and the remainder come from one 128-bit product.  snprintf takes
+// 0.4-0.6 us per call and the final TSV holds four such fields per row (the _alt TSV one per row).
+inline void put_fixed2(std::string& o, double v) {
+    uint64_t bits;
+    std::memcpy(&bits, &v, sizeof bits);
+    const int ex = (int)((bits >> 52) & 0x7ff);
+    uint64_t m = bits & ((1ull << 52) - 1);
+    if (ex == 0x7ff || ex >= 1023 + 40) {   // inf / nan / |v| >= 2^40: not a percentage; let printf do it
+        char b[400];
+        const int n = std::snprintf(b, sizeof b, "%.2f", v);
+        o.append(b, (size_t)n);
+        return;
+    }
+    int sh;   // |v| = m * 2^-sh
+    if (ex) { m |= 1ull << 52; sh = 1075 - ex; } else sh = 1074;
+    const unsigned __int128 num = (unsigned __int128)m * 100u;   // < 2^60
+    uint64_t q = 0;
+    if (sh < 64) {   // sh >= 13 here
+        const uint64_t n64 = (uint64_t)num;
+        q = n64 >> sh;
+        const uint64_t rem = n64 & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+        if (rem > half || (rem == half && (q & 1))) ++q;
+    }                // sh >= 64: 100 |v| < 2^-4, rounds to 0
+    char buf[32];
+    int p = 32;
+    buf[--p] = (char)('0' + q % 10); q /= 10;
+    buf[--p] = (char)('0' + q % 10); q /= 10;
+    buf[--p] = '.';
+    do { buf[--p] = (char)('0' + q % 10); q /= 10; } while (q);
+    if (bits >> 63) buf[--p] = '-';
+    o.append(buf + p, (size_t)(32 - p));
+}
+
 // SaveBatch (main.cpp:272-285).  The reference prints to_string(float identity) == "%f"; the
 // identity is an integer-valued float (|v| < 1e6 < 2^24 by the range check in the engine), so
 // "%f" is exactly "<int>.000000".

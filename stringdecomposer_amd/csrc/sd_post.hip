@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/sd_hip.h"
+#include "sd_host.hpp"
 
 namespace {
 
@@ -275,7 +276,6 @@ extern "C" int sd_format_alt_rows(const char* const* read_names, int32_t n_reads
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n_blocks));
     std::atomic<int64_t> next{0};
     auto work = [&]() {
-        char num[64];
         for (;;) {
             const int64_t b = next.fetch_add(1);
             if (b >= n_blocks) break;
@@ -289,8 +289,7 @@ extern "C" int sd_format_alt_rows(const char* const* read_names, int32_t n_reads
                     o += head;
                     o += keys[(size_t)k];
                     o.append(mid, (size_t)ml);
-                    const int nl = std::snprintf(num, sizeof num, "%.2f", vals[(size_t)r * n_keys + k]);
-                    o.append(num, (size_t)nl);
+                    sd::put_fixed2(o, vals[(size_t)r * n_keys + k]);
                     o += (k == own_key[r]) ? "\t*\n" : "\t-\n";
                 }
             }

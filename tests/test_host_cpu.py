@@ -470,3 +470,27 @@ def test_reference_import_path_is_an_alias():
     """north_star keeps the Python CLI `stringdecomposer.main`: the name resolves to this build's driver."""
     import stringdecomposer.main as ref_name
     assert ref_name.main is sdmain.main and ref_name.convert_tsv is sdmain.convert_tsv and ref_name.run is sdmain.run
+
+
+def test_two_decimal_text_equals_python_format():
+    """sd::put_fixed2 (csrc/sd_host.hpp) writes the identity columns of the final and _alt TSVs without printf; it
+    has to be "{:.2f}".format(v) (main.py:157-165) for every double: exact ties, the nearest doubles of x.xx5,
+    identities m / c * 100, random bit patterns, negative zero, subnormals, huge values."""
+    import random
+    import struct
+    rnd = random.Random(5)
+    vals = [i / 1000.0 for i in range(0, 30000)]
+    vals += [i * 0.125 * j / 4 for i in range(1, 800) for j in (1, 3, 5, 7)]
+    vals += [m / c * 100 for c in range(1, 300) for m in range(0, c + 1, 3)]
+    vals += [struct.unpack("<d", struct.pack("<Q", rnd.getrandbits(64)))[0] for _ in range(60000)]
+    vals += [rnd.uniform(-5, 105) for _ in range(30000)]
+    vals += [0.0, -0.0, -1.0, 0.005, 0.015, 0.025, 0.035, 1e-300, 5e-324, -1e-9, 99.995, 100.0, 1e12 - 0.005,
+             2.0 ** 39 + 0.125, 2.0 ** 40, 1e15, float("inf"), float("-inf")]
+    v = np.array([x for x in vals if x == x], dtype=np.float64).reshape(-1, 1)
+    n = v.shape[0]
+    z = np.zeros(n, dtype=np.int64)
+    txt = lib.format_alt_rows("r", ["k"], z, z, np.zeros(n, dtype=np.int32), v, threads=3)
+    got = [line.split("\t")[4] for line in txt.split("\n")[:-1]]
+    assert len(got) == n
+    bad = [(x, g) for x, g in zip(v[:, 0].tolist(), got) if "{:.2f}".format(x) != g]
+    assert not bad, bad[:5]
