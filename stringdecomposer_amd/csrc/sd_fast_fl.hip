@@ -7,7 +7,7 @@
 // S'[x] where tbl[x] exceeds every tbl[x'] of an earlier slot x' >= 1 of the lane -- slot 1 and the first
 // slot holding the read's base (main.cpp:187-207 evaluates the start term in every cell; this is the same
 // maximum with the dominated candidates left out).  fast_plan_build finds the last such slot over all lanes
-// and the five read symbols (FastPlan::floor_slots: 15 on the synthetic 12-monomer set, 23 on the DXZ1
+// and the five read symbols (FastPlan::floor_slots: 16 on the synthetic 12-monomer set, 24 on the DXZ1
 // monomers of the reference's test data); behind it a slot costs 2 packed ops instead of 3.
 //
 // Only slot counts P >= 30 (P = 30..40 here, 42..64 in sd_fast_fl_long.hip) and the fp16 cell format get these
