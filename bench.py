@@ -81,7 +81,31 @@ def cpu_baseline(mn, ms, rn, rs, gpu_rows_text):
         out, dt = run(True, best[0])
     return {"value": total_bp / dt, "unit": "bp/s", "cores": best[0], "kind": "reference" if have_ref else "port",
             "sample": sample, "seconds": round(dt, 3), "host_cores_available": cores,
+            "cpu_quota_cores": cpu_quota_cores(),
             "thread_sweep": sweep, "parity_on_sample": bool(out == gpu_rows_text)}
+
+
+def cpu_quota_cores():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota); None = unlimited.  The GPU
+    boxes of this pool show 256 logical CPUs but run under a quota of 16."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+            q, per = float(f.read()), float(g.read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
+def usable_cores():
+    n = os.cpu_count() or 1
+    q = cpu_quota_cores()
+    return n if q is None else max(1, min(n, int(q + 0.5)))
 
 
 def main():
@@ -142,7 +166,9 @@ def main():
     bp_rank = sum(len(s) for s in rs)
 
     kernel = {"auto": 0, "generic": 1, "fast": 2}[args.kernel]
-    threads = max(1, min(32, (os.cpu_count() or 1) // max(ws, 1)))
+    # host threads of this rank: its share of the CPUs the container may actually use (threads beyond a cgroup
+    # quota only get the whole process group throttled)
+    threads = max(1, min(32, usable_cores() // max(ws, 1)))
     K = max(args.steps, 1)
 
     # ---- the timed region: SURVEY.md 8(d) -- sequences in host memory -> chunk -> 2-bit pack -> H2D ->
@@ -170,6 +196,7 @@ def main():
         if bracket:
             shard.barrier(dist, bar_dev)
         torch.cuda.synchronize()
+        c0 = os.times()
         t0 = time.perf_counter()
         nrows = 0
         depth = int(os.environ.get("SD_BENCH_DEPTH", "1"))   # developer A/B: steps kept outstanding before collecting
@@ -187,9 +214,14 @@ def main():
         if bracket:
             shard.barrier(dist, bar_dev)
         sec = time.perf_counter() - t0
+        c1 = os.times()
         b = st.stats()
         st.close()
-        return sec, nrows, {k: b[k] - a[k] for k in b}, inf
+        dd = {k: b[k] - a[k] for k in b}
+        # CPU time of this process (all host threads, user + system) over the timed region: what one rank asks
+        # of the host per step -- the N-GPU node has to supply N times that within one step time
+        dd["host_cpu_ms_per_step"] = ((c1.user - c0.user) + (c1.system - c0.system)) * 1e3 / max(steps, 1)
+        return sec, nrows, dd, inf
 
     dt, rows_out, d, info = timed_steps(args.pipe_mode, args.steps, args.warmup, True)
     dt = shard.max_over_ranks(dist, dt, dev)
@@ -304,7 +336,11 @@ def main():
         "kernel_ms_per_step": {"fill": d["fill_ms"] / K, "traceback": d["trace_ms"] / K, "compact": d["compact_ms"] / K,
                                "note": "HIP-event spans per batch, summed; batches on the two streams overlap"},
         "host_ms_per_step": {"pack_upload_enqueue": d["host_pack_ms"] / K, "wait_for_device": d["host_wait_ms"] / K,
-                             "d2h_assemble": d["host_assemble_ms"] / K},
+                             "d2h_assemble": d["host_assemble_ms"] / K,
+                             "process_cpu_ms": d["host_cpu_ms_per_step"],
+                             "cpu_quota_cores": cpu_quota_cores(),
+                             "note": "wall ms of the host stages of one step; process_cpu_ms = CPU time of all host "
+                                     "threads of this rank per step (user + system)"},
         "other_pipe_mode": other,
         "rows_out_per_gpu": rows_out, "hbm_workspace_bytes": einfo["workspace_bytes"],
         # kernels only, batch packed and resident in HBM before the clock starts, one launch per kernel

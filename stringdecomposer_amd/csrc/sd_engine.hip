@@ -392,6 +392,15 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
     }
     try {
         SD_HIP(hipSetDevice(p->device));
+        {
+            // Host threads that wait for the device sleep instead of spinning.  A rank of the pipelined path waits
+            // ~14 of every 16 ms; spinning, it burns a whole CPU for that (measured: 34.5 -> 21.5 ms of CPU time
+            // per 16.3-ms step and rank, same step time), which an 8-GPU node whose ranks share the host CPUs
+            // (or a container CPU quota) cannot spare.  SD_HOST_WAIT=spin keeps the runtime's default.
+            const char* hw = getenv("SD_HOST_WAIT");
+            if (!(hw && hw[0] == 's') && hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess)
+                (void)hipGetLastError();
+        }
         e->device = p->device;
         {
             hipDeviceProp_t prop;
@@ -438,10 +447,13 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
             e->d_peq.upload(peq);
         }
         SD_HIP(hipEventCreate(&e->ev_run0));
-        SD_HIP(hipEventCreate(&e->ev_run1));
+        // the events the host waits on put the waiting thread to sleep (interrupt) instead of spinning: a rank
+        // waits ~14 of 16 ms per step, and on a node where the host CPUs are shared by 8 ranks (or capped by a
+        // cgroup quota) a spinning waiter per rank takes the time the packers need
+        SD_HIP(hipEventCreateWithFlags(&e->ev_run1, hipEventBlockingSync));
         SD_HIP(hipEventCreate(&e->ev_cmp0));
         SD_HIP(hipEventCreate(&e->ev_cmp1));
-        SD_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+        SD_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming | hipEventBlockingSync));
     } catch (const HipFail& f) {
         set_err(errbuf, errlen, f.msg);
         return SD_ERR_HIP;
