@@ -576,8 +576,10 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
     // fp16 cells, 150-200 bp monomers: the variants that skip the dominated start-term maxima (sd_fast_fl.hip);
     // SD_FILL_FULLFLOOR=1 keeps the full kernel (developer A/B and the parity test of the two)
     if (!getenv("SD_FILL_FULLFLOOR") &&
-        launch_fast_fill_fl(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, argV,
-                            ckpt, ckbase, queue, order, cendoff, crank))
+        (plan.f16 ? launch_fast_fill_fl(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
+                                        argV, ckpt, ckbase, queue, order, cendoff, crank)
+                  : launch_fast_fill_fl_i16(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc,
+                                            B, argV, ckpt, ckbase, queue, order, cendoff, crank)))
         return;
     switch (plan.P) {
         SD_FILL(4) SD_FILL(8) SD_FILL(12) SD_FILL(16) SD_FILL(20) SD_FILL(24) SD_FILL(28) SD_FILL(30)

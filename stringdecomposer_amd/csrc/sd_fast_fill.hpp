@@ -291,7 +291,7 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
             }
             if (s < P) {
                 const int q = s;
-                u_[q] = q == 0 ? KB : pk_max(L[q - 1], KB);
+                u_[q] = q == 0 ? KB : q <= FL ? pk_max(L[q - 1], KB) : L[q - 1];   // see the fp16 loop
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -577,17 +577,23 @@ def _late_base_monomers():
     return ["m%d" % i for i in range(len(ms))], ms
 
 
-@pytest.mark.parametrize("name", ["synthetic12", "dxz1", "late_bases", "late_bases_ed", "synthetic16", "synthetic20_ed",
+@pytest.mark.parametrize("name", ["synthetic12", "synthetic12_i16", "dxz1_i16_ed", "dxz1", "late_bases", "late_bases_ed",
+                                  "synthetic16", "synthetic20_ed",
                                   "wide64", "wide64_ed", "waves140"])
 def test_fill_without_dominated_start_maxima(oracle, name):
     """csrc/sd_fast_fl.hip: behind the first FL slots of a lane the fill leaves out the maximum with the start
     term (the candidate is dominated there).  Same rows as the full kernel (SD_FILL_FULLFLOOR=1) and as the
     oracle, for template sets with small, typical and large floor_slots, with and without --ed_thr."""
     ed = -1
-    if name == "synthetic12":
+    sc = (-1, -1, -1, 1)
+    if name.startswith("synthetic12"):
         mn, ms = synth.make_monomers(12, seed=1)
-    elif name == "dxz1":
+        if name.endswith("_i16"):
+            sc = (-2, -2, -3, 9)                       # beyond the fp16 range: packed int16 cells (sd_fast_fl_i16.hip)
+    elif name.startswith("dxz1"):
         mn, ms, _ = lib.fasta_load(os.path.join(GOLDEN, "test_data", "DXZ1_star_monomers.fa"))
+        if name.endswith("_i16_ed"):
+            sc, ed = (0, 0, -1, 15), 45
     elif name == "synthetic16":
         mn, ms = synth.make_monomers(16, seed=4)       # 32 templates of 4 lanes: P = 44 (sd_fast_fl_long.hip)
     elif name == "synthetic20_ed":
@@ -606,23 +612,24 @@ def test_fill_without_dominated_start_maxima(oracle, name):
     rs = list(rs) + [(ms[0].replace(b"N", b"A") * 30)[:3000], synth._ACGT[st.below(2500, 4)].tobytes(),
                      b"G" * 400 + ms[-1].replace(b"N", b"C") * 4 + b"N" * 3 + ms[1].replace(b"N", b"C") * 3]
     rn = ["r%d" % i for i in range(len(rs))]
-    e = lib.Engine(ms, kernel=lib.KERNEL_FAST, ed_thr=ed)
+    e = lib.Engine(ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc)
     info = e.info()
     e.close()
     if len(ms) <= 12:
-        assert info["cells"] == "f16" and 30 <= info["cells_per_lane"] <= 40
+        assert info["cells"] == ("int16" if "_i16" in name else "f16") and 30 <= info["cells_per_lane"] <= 40
     elif len(ms) <= 20:
         assert info["cells"] == "f16" and 42 <= info["cells_per_lane"] <= 64
     else:
         assert info["cells"] in ("f16/bf8-table", "f16/bf8-codes x waves"), info
-    lo, hi = {"synthetic12": (8, 16), "dxz1": (17, 24), "late_bases": (25, 40), "late_bases_ed": (25, 40),
+    lo, hi = {"synthetic12": (8, 16), "synthetic12_i16": (8, 16), "dxz1": (17, 24), "dxz1_i16_ed": (17, 24),
+              "late_bases": (25, 40), "late_bases_ed": (25, 40),
               "synthetic16": (8, 24), "synthetic20_ed": (8, 32), "wide64": (8, 32), "wide64_ed": (8, 32), "waves140": (8, 48)}[name]
     assert lo <= info["floor_slots"] <= hi, info
-    exp = oracle.decompose(rn, rs, mn, ms, threads=8, ed_thr=ed)
-    got = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, ed_thr=ed)
+    exp = oracle.decompose(rn, rs, mn, ms, threads=8, ed_thr=ed, sc=sc)
+    got = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc)
     os.environ["SD_FILL_FULLFLOOR"] = "1"
     try:
-        full = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, ed_thr=ed)
+        full = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc)
     finally:
         del os.environ["SD_FILL_FULLFLOOR"]
     assert full == exp
