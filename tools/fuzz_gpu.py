@@ -39,7 +39,8 @@ t0 = time.time()
 fam = {"fast": 0, "generic": 0}
 for case in range(cases):
     shape = [(1, 5, 40), (3, 20, 90), (6, 100, 200), (12, 160, 180), (25, 150, 190), (50, 100, 180),
-             (64, 165, 178), (4, 300, 500), (2, 1, 30), (10, 60, 64), (90, 100, 180), (230, 140, 176)][rnd(12)]
+             (64, 165, 178), (4, 300, 500), (2, 1, 30), (10, 60, 64), (90, 100, 180), (230, 140, 176),
+             (16, 150, 190), (20, 160, 180), (14, 120, 175)][rnd(15)]   # the last three: P = 42..64 (sd_fast_fl_long.hip)
     nm = max(1, shape[0] - rnd(2))
     ms = monomers(nm, shape[1], shape[2], 0.15 if rnd(3) == 0 else 0.0)
     mn = ["m%d" % j for j in range(nm)]
