@@ -306,7 +306,10 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     if (ub > 12000) { why = "scores too large for int16 cells"; return false; }
     if (Lmax > 64 * 8) { why = "template longer than 512 bp"; return false; }
 
+    // narrow layout: the smallest slot counts P whose lanes fit the two planes; the first three are candidates,
+    // the one with the fewest cell ops per row wins (2P + the FL level its lanes allow, see below)
     int P = 0, split = 0;
+    std::vector<std::pair<int, int>> cand;   // (P, split)
     for (int p : FAST_P_LIST) {
         int used = 0, s = 0;
         while (s < T && used + ((int)tseq[s].size() + p - 1) / p <= 64) {
@@ -315,8 +318,12 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         }
         int used2 = 0;
         for (int j = s; j < T; ++j) used2 += ((int)tseq[j].size() + p - 1) / p;
-        if (used2 <= 64) { P = p; split = s; break; }
+        if (used2 <= 64) {
+            cand.emplace_back(p, s);
+            if (cand.size() == 3) break;
+        }
     }
+    if (!cand.empty()) { P = cand[0].first; split = cand[0].second; }
     bool wide = false;
     if (P == 0) {
         // wide layout: one template per virtual lane
@@ -340,20 +347,104 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     }
     plan.P = P;
     plan.P4 = (P + 3) & ~3;
-    // last slot whose diagonal input needs the floor (see the slot loop of sd_fast_fill): per virtual lane and
-    // read symbol, the slots q >= 1 where the table value exceeds every earlier one of the lane (slot 0 always
-    // takes the start term / the carry: its candidate KB + tbl[0] is in the chain from there on)
-    plan.floor_slots = 1;
-    for (int j = 0; j < T; ++j) {
-        const std::string& s = tseq[(size_t)j];
-        for (int k0 = 0; k0 < (int)s.size(); k0 += P)
-            for (int b = 0; b < 5; ++b) {
-                int run = code_of(s[(size_t)k0]) == b ? sc.match : sc.mismatch;
-                for (int q = 1; q < P && k0 + q < (int)s.size(); ++q) {
-                    const int val = code_of(s[(size_t)(k0 + q)]) == b ? sc.match : sc.mismatch;
-                    if (val > run) { run = val; plan.floor_slots = std::max(plan.floor_slots, q); }
+    // Lanes of a template: V = ceil(L / P) virtual lanes of at most P cells each.  A lane may hold fewer cells
+    // than P (its tail slots are transparent pads, as the last lane of a template always had), so the first cell
+    // of every lane but the first is a choice: it is taken where the lane meets all four bases early, because the
+    // last slot whose diagonal input needs the floor (see the slot loop of sd_fast_fill) -- per lane and read
+    // symbol, the slots q >= 1 where the table value exceeds every earlier one of the lane; slot 0 always takes
+    // the start term / the carry, its candidate KB + tbl[0] is in the chain from there on -- decides how many
+    // slots keep the three-op form (FastPlan::floor_slots).  A small DP per template minimises the latest such
+    // slot over its lanes; the first lane starts at cell 0 whatever it costs.
+    auto lane_record = [&](const std::string& s, int b0, int b1) {
+        int rec = 0;
+        for (int b = 0; b < 5; ++b) {
+            int run = code_of(s[(size_t)b0]) == b ? sc.match : sc.mismatch;
+            for (int q = 1; b0 + q < b1; ++q) {
+                const int val = code_of(s[(size_t)(b0 + q)]) == b ? sc.match : sc.mismatch;
+                if (val > run) { run = val; rec = std::max(rec, q); }
+            }
+        }
+        return rec;
+    };
+    using Bounds = std::vector<std::vector<int>>;   // [j][u] = first cell of lane u of template j; [j][V] = L
+    auto layout_for = [&](int P, Bounds& bnd) {
+        int fs = 1;
+        bnd.assign((size_t)T, std::vector<int>());
+        for (int j = 0; j < T; ++j) {
+            const std::string& s = tseq[(size_t)j];
+            const int L = (int)s.size(), V = (L + P - 1) / P;
+            std::vector<int>& bj = bnd[(size_t)j];
+            bj.assign((size_t)V + 1, 0);
+            for (int u = 0; u <= V; ++u) bj[(size_t)u] = std::min(L, u * P);
+            if (!wide && V > 1 && !getenv("SD_PLAN_UNIFORM_LANES")) {
+                // start of lane u in [lo(u), hi(u)]: the lanes before hold at most u*P cells, the lanes from u on
+                // at most (V-u)*P
+                // (the first lane keeps at least two cells: cell 0 has no insertion move, its value may fall from one
+                // row to the next, and a pad behind it would keep the old, larger value -- the reason 1-bp templates
+                // are not taken either)
+                auto lo = [&](int u) { return std::max(u + 1, L - (V - u) * P); };
+                auto hi = [&](int u) { return std::min(u * P, L - (V - u)); };
+                const int INF = 1 << 30;
+                std::vector<std::vector<int>> cost((size_t)V), from((size_t)V);
+                cost[0].assign(1, 0);
+                from[0].assign(1, 0);
+                for (int u = 1; u < V; ++u) {
+                    const int n = hi(u) - lo(u) + 1;
+                    cost[(size_t)u].assign((size_t)n, INF);
+                    from[(size_t)u].assign((size_t)n, -1);
+                    for (int x = 0; x < n; ++x) {
+                        const int st = lo(u) + x;
+                        const int pl = u == 1 ? 0 : lo(u - 1), ph = u == 1 ? 0 : hi(u - 1);
+                        for (int pv = ph; pv >= pl; --pv) {    // fullest previous lane first: ties keep the uniform layout
+                            if (pv >= st || st - pv > P) continue;
+                            const int c0 = cost[(size_t)u - 1][(size_t)(pv - pl)];
+                            if (c0 >= INF) continue;
+                            const int c = std::max(c0, lane_record(s, pv, st));
+                            if (c < cost[(size_t)u][(size_t)x]) { cost[(size_t)u][(size_t)x] = c; from[(size_t)u][(size_t)x] = pv; }
+                        }
+                    }
+                }
+                int best = INF, bst = -1;
+                for (int st = hi(V - 1); st >= lo(V - 1); --st) {
+                    const int c0 = cost[(size_t)V - 1][(size_t)(st - lo(V - 1))];
+                    if (c0 >= INF || L - st > P) continue;
+                    const int c = std::max(c0, lane_record(s, st, L));
+                    if (c < best) { best = c; bst = st; }
+                }
+                if (bst >= 0) {
+                    int st = bst;
+                    for (int u = V - 1; u >= 1; --u) {
+                        bj[(size_t)u] = st;
+                        st = from[(size_t)u][(size_t)(st - lo(u))];
+                    }
                 }
             }
+            for (int u = 0; u < V; ++u)
+                fs = std::max(fs, lane_record(s, bj[(size_t)u], bj[(size_t)u + 1]));
+        }
+        return fs;
+    };
+    // cell ops per row of a candidate: 2 per slot + 1 per slot that keeps the start-term maximum (the FL level
+    // the launchers of sd_fast_fl*.hip would pick; 3 per slot where no variant exists)
+    auto cell_ops = [](int P, int fs) {
+        if (P >= 30 && P <= 40) { for (int c : {12, 16, 20, 24, 28}) if (fs <= c && c + 2 < P) return 2 * P + c; }
+        else if (P > 40) { for (int c : {16, 24, 32}) if (fs <= c) return 2 * P + c; }
+        return 3 * P;
+    };
+    Bounds bnd;
+    plan.floor_slots = 1;
+    if (wide || cand.size() <= 1 || getenv("SD_PLAN_UNIFORM_LANES")) {
+        plan.floor_slots = layout_for(P, bnd);
+    } else {
+        int best = 1 << 30;
+        for (const auto& c : cand) {
+            Bounds b2;
+            const int fs = layout_for(c.first, b2);
+            const int ops = cell_ops(c.first, fs);
+            if (ops < best) { best = ops; P = c.first; split = c.second; plan.floor_slots = fs; bnd.swap(b2); }
+        }
+        plan.P = P;
+        plan.P4 = (P + 3) & ~3;
     }
     plan.T = T;
     plan.split = split;
@@ -502,8 +593,10 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     int64_t x = 0;
     for (int j = 0; j < T; ++j) {
         const std::string& s = tseq[(size_t)j];
+        int u = 0;
         for (int k = 0; k < (int)s.size(); ++k, ++x) {
-            const int v = plan.vlane0[(size_t)j] + k / P, slot = k % P;
+            while (k >= bnd[(size_t)j][(size_t)u + 1]) ++u;
+            const int v = plan.vlane0[(size_t)j] + u, slot = k - bnd[(size_t)j][(size_t)u];
             const int plane = v >> 6, lane = v & 63;
             const int cd = code_of(s[(size_t)k]);
             plan.tcodes[(size_t)x] = (uint8_t)cd;

@@ -182,7 +182,10 @@ FUZZ = os.path.join(GOLDEN, "fuzz")
 def test_fuzz_regressions(oracle, case):
     """Inputs on which tools/fuzz_gpu.py once found a mismatch (kept as data: reads, monomers, parameters).
     fuzz_fail_906_791: scoring 0,-4,-4,-1 on 300-480 bp monomers -- the fp16 cells left the exact-integer range
-    because the range bound ignored that B can grow by (smax - del) per row (csrc/sd_fast.hip, fast_plan_build)."""
+    because the range bound ignored that B can grow by (smax - del) per row (csrc/sd_fast.hip, fast_plan_build).
+    fuzz_fail_1301_1135 (found while the plan learned to move lane boundaries, never in a committed build): a 5-bp
+    template whose first lane was cut down to one cell -- cell 0 has no insertion move, so a pad behind it kept a
+    stale value; the first lane now keeps at least two cells."""
     d = os.path.join(FUZZ, case)
     rn, rs, _ = lib.fasta_load(os.path.join(d, "r.fa"))
     mn, ms, _ = lib.fasta_load(os.path.join(d, "m.fa"))
@@ -622,7 +625,7 @@ def test_fill_without_dominated_start_maxima(oracle, name):
     else:
         assert info["cells"] in ("f16/bf8-table", "f16/bf8-codes x waves"), info
     lo, hi = {"synthetic12": (8, 16), "synthetic12_i16": (8, 16), "dxz1": (17, 24), "dxz1_i16_ed": (17, 24),
-              "late_bases": (25, 40), "late_bases_ed": (25, 40),
+              "late_bases": (12, 40), "late_bases_ed": (12, 40),
               "synthetic16": (8, 24), "synthetic20_ed": (8, 32), "wide64": (8, 32), "wide64_ed": (8, 32), "waves140": (8, 48)}[name]
     assert lo <= info["floor_slots"] <= hi, info
     exp = oracle.decompose(rn, rs, mn, ms, threads=8, ed_thr=ed, sc=sc)
@@ -634,6 +637,19 @@ def test_fill_without_dominated_start_maxima(oracle, name):
         del os.environ["SD_FILL_FULLFLOOR"]
     assert full == exp
     assert got == exp
+    if name.startswith("late_bases") or name == "dxz1":
+        # the plan moves lane boundaries to where a lane meets all bases early; with uniform lanes the same sets
+        # need the start term much deeper into the lanes (other FL variants, or the full kernel)
+        os.environ["SD_PLAN_UNIFORM_LANES"] = "1"
+        try:
+            e = lib.Engine(ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc)
+            uinfo = e.info()
+            e.close()
+            uni = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc)
+        finally:
+            del os.environ["SD_PLAN_UNIFORM_LANES"]
+        assert uinfo["floor_slots"] >= info["floor_slots"] and (name == "dxz1" or uinfo["floor_slots"] >= 25), (uinfo, info)
+        assert uni == exp
 
 
 def test_multi_wave_wide_layout_long_reads_vs_generic_and_oracle(oracle):

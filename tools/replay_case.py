@@ -1,0 +1,10 @@
+import sys, os
+sys.path.insert(0, os.getcwd())
+from stringdecomposer_amd import lib
+from oracle import binding as oracle
+d = sys.argv[1]
+rn, rs, _ = lib.fasta_load(d + "/r.fa"); mn, ms, _ = lib.fasta_load(d + "/m.fa")
+sc, part, ov, ed = eval(open(d + "/params.txt").read())
+got = lib.decompose(rn, rs, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed)
+exp = oracle.decompose(rn, rs, mn, ms, threads=4, sc=sc, part=part, overlap=ov, ed_thr=ed)
+print("replay", d, "OK" if got == exp else "MISMATCH")
