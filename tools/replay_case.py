@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Developer tool (needs a GPU): replay one saved fuzz input against the oracle.
+usage: python tools/replay_case.py <dir with r.fa, m.fa, params.txt>"""
 import sys, os
 sys.path.insert(0, os.getcwd())
 from stringdecomposer_amd import lib
