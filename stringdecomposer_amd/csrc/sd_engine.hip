@@ -201,6 +201,12 @@ struct sd_engine {
     DevBuf<unsigned long long> d_peq;
     DevBuf<int32_t> d_endvl, d_endoff, d_dist;
     DevBuf<uint32_t> d_cendoff, d_crank;
+    // --ed_thr with more than 128 templates (compacted fill, sd_fast_wn_ck.hip): per chunk the kept templates in
+    // filtered order [128], every template's place [T], the kept count; the two chunk classes and their sizes
+    DevBuf<uint16_t> d_klist, d_kpos;
+    DevBuf<int32_t> d_nkept;
+    DevBuf<int> d_order12, d_cls;
+    bool compact_edthr = false;
     DevBuf<int> d_queue;             // work-queue heads of the persistent kernels: a fresh zeroed (fill, trace) pair per run
     int q_run = 0;                   // pairs handed out since the array was last zeroed
     static constexpr int QN = 2048;
@@ -406,8 +412,8 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
             hipDeviceProp_t prop;
             SD_HIP(hipGetDeviceProperties(&prop, p->device));
             e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            e->d_queue.alloc(2 * (size_t)sd_engine::QN);
-            SD_HIP(hipMemset(e->d_queue.p, 0, sizeof(int) * 2 * (size_t)sd_engine::QN));
+            e->d_queue.alloc(4 * (size_t)sd_engine::QN);
+            SD_HIP(hipMemset(e->d_queue.p, 0, sizeof(int) * 4 * (size_t)sd_engine::QN));
         }
         // kernel family
         int family = p->kernel;
@@ -598,6 +604,15 @@ static int load_chunks_impl(sd_engine* e, const std::vector<const char*>& cptr,
                 e->d_dist.alloc(C * (size_t)e->T);
                 e->d_cendoff.alloc(C * 64 * (size_t)e->fplan.waves);
                 e->d_crank.alloc(C * 64 * (size_t)e->fplan.waves);
+                const char* ck = getenv("SD_EDTHR_COMPACT");   // "0": every chunk on the W-wave ranked kernel (A/B, tests)
+                e->compact_edthr = e->fplan.wide && e->fplan.waves > 1 && !(ck && ck[0] == '0');
+                if (e->compact_edthr) {
+                    e->d_klist.alloc(C * 128);
+                    e->d_kpos.alloc(C * (size_t)e->T);
+                    e->d_nkept.alloc(C);
+                    e->d_order12.alloc(2 * C);
+                    e->d_cls.alloc(2);
+                }
             }
             e->d_fckpt.alloc((size_t)nck * (size_t)e->fplan.P * 64 * (size_t)e->fplan.waves);
             e->d_fckbase.alloc((size_t)nck + 1);
@@ -686,18 +701,36 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
             } else {
                 const bool ranked = e->p.ed_thr > -1;
                 if (e->q_run == sd_engine::QN) {  // every queue head used once: zero them again (no kernel of this
-                    SD_HIP(hipMemsetAsync(e->d_queue.p, 0, sizeof(int) * 2 * (size_t)sd_engine::QN, st));  // engine is running)
+                    SD_HIP(hipMemsetAsync(e->d_queue.p, 0, sizeof(int) * 4 * (size_t)sd_engine::QN, st));  // engine is running)
                     e->q_run = 0;
                 }
-                int* qfill = e->d_queue.p + 2 * e->q_run;
+                int* qfill = e->d_queue.p + 4 * e->q_run;   // heads of this run: fill, traceback, second fill class
                 int* qtrace = qfill + 1;
+                int* qfill2 = qfill + 2;
                 ++e->q_run;
+                const bool compact = ranked && e->compact_edthr;
                 if (ranked)  // main.cpp:91-93: per-chunk template prefilter
                     sd::launch_edthr_filter(st, e->dp_chunks, C, e->T, e->Lmax, e->p.ed_thr, e->dp_bases2,
                                             e->dp_nmask, e->d_peq.p, e->d_tlen.p, e->d_endvl.p,
                                             e->d_endoff.p, e->d_dist.p, e->d_cendoff.p, e->d_crank.p, nullptr,
-                                            e->fplan.waves);
+                                            e->fplan.waves, compact ? e->d_kpos.p : nullptr,
+                                            compact ? e->d_klist.p : nullptr, compact ? e->d_nkept.p : nullptr);
                 SD_HIP(hipEventRecord(e->ev_fill[0], st));
+                if (compact) {
+                    // more than 128 templates: the chunks whose kept templates fit one wave are filled by one wave
+                    // holding exactly those (the point of the reference's prefilter, main.cpp:128-149: less DP
+                    // work); the others by the W-wave ranked kernel.  The class sizes stay on the device.
+                    int* o1 = e->d_order12.p;
+                    int* o2 = o1 + C;
+                    sd::launch_split_order(st, e->dp_order, C, e->d_nkept.p, o1, o2, e->d_cls.p);
+                    sd::launch_fast_fill_wn_compact(e->fplan, st, e->dp_chunks, e->dp_bases2, e->dp_nmask, e->d_flane.p,
+                                                    e->sc, e->d_B.p, e->d_fckpt.p, e->d_fckbase.p, qfill, o1,
+                                                    e->d_cls.p, e->n_cu, e->d_klist.p, e->d_ftcodes.p, e->d_toff.p,
+                                                    e->d_tlen.p);
+                    sd::launch_fast_fill_wn(e->fplan, st, e->dp_chunks, C, e->dp_bases2, e->dp_nmask, e->d_ftable.p,
+                                            e->d_flane.p, e->sc, e->d_B.p, e->d_fckpt.p, e->d_fckbase.p, qfill2, o2,
+                                            e->n_cu, e->d_cendoff.p, e->d_crank.p, e->d_cls.p + 1);
+                } else
                 sd::launch_fast_fill(e->fplan, st, e->dp_chunks, C, e->dp_bases2, e->dp_nmask,
                                      e->d_ftable.p, e->d_flane.p, e->sc, e->d_B.p, e->d_argB.p,
                                      e->d_fckpt.p, e->d_fckbase.p, qfill, e->dp_order, e->n_cu,
@@ -710,7 +743,8 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                                       e->d_fslot.p, e->d_ftcodes.p, e->d_flane.p, e->d_toff.p,
                                       e->d_tlen.p, e->sc, e->d_B.p, e->d_argB.p, e->d_fckpt.p,
                                       e->d_fckbase.p, e->d_recs.p, e->d_cnt.p, qtrace, e->dp_order,
-                                      e->n_cu);
+                                      e->n_cu, compact ? e->d_klist.p : nullptr, compact ? e->d_kpos.p : nullptr,
+                                      compact ? e->d_nkept.p : nullptr);
                 SD_HIP(hipEventRecord(e->ev_trace[1], ts));
                 e->fill_launches = 1;
             }

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
     const int32_t* __restrict__ B, const int32_t* __restrict__ argV,
     const uint32_t* __restrict__ ckpt, const int32_t* __restrict__ ckbase,
     DevRec* __restrict__ recs, int32_t* __restrict__ rec_cnt, int* __restrict__ queue,
-    const int* __restrict__ order, int ckf16, int bshift, int W) {
+    const int* __restrict__ order, int ckf16, int bshift, int W, const uint16_t* __restrict__ klist,
+    const uint16_t* __restrict__ kpos, const int32_t* __restrict__ nkept, int T) {
     constexpr int QP = QK <= 4 ? 4 : 8;       // cells per lane rounded up to whole int4 loads
     using pt_t = std::conditional_t<(QK <= 4), uint8_t, uint16_t>;
     __shared__ pt_t pt_all[4][FAST_R][64];      // 2-bit moves of the lane's cells
@@ -73,7 +74,13 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
     const int ins = sc.ins, del = sc.del;
     const int mD = sc.match - sc.del, xD = sc.mismatch - sc.del;
 
+    // --ed_thr with more than 128 templates: a chunk filled in the compacted form (sd_fast_wn_ck.hip) has its kept
+    // templates, in their filtered order, in the virtual lanes of wave 0
+    const bool cmp = klist != nullptr && nkept[c] <= 128;
+    const uint16_t* klc = cmp ? klist + (size_t)c * 128 : nullptr;
+    const uint16_t* kpc = cmp ? kpos + (size_t)c * (size_t)T : nullptr;
     auto tmpl_of = [&](int v) {
+        if (cmp) return (int)klc[v & 127];
         const uint32_t t = lane_consts[(((v >> 7) << 6) | (v & 63)) * FAST_LANE_WORDS + FLC_TMPL];
         return (int)(((v >> 6) & 1) ? (t >> 16) : (t & 0xffffu));
     };
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
             for (int q = 0; q < QQ; ++q) {
                 const int kk = lane * QQ + q;
                 cl.code[q] = kk < Lj ? (int)tcodes[x0 + kk] : 7;
-                cl.slot[q] = kk < Lj ? (int)slot_of[x0 + kk] : 0;
+                cl.slot[q] = kk < Lj ? (cmp ? ((kk << 7) | (int)kpc[j]) : (int)slot_of[x0 + kk]) : 0;
 #pragma unroll
                 for (int b = 0; b < 5; ++b) mt[b][lane][q] = (int16_t)(4 * ((cl.code[q] == b ? mD : xD) - ins) - 1);
             }
@@ -690,14 +697,16 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
                        const uint8_t* tcodes, const uint32_t* lane_consts, const int32_t* toff,
                        const int32_t* tlen, ScoreArgs sc, const int32_t* B, const int32_t* argV,
                        const uint32_t* ckpt, const int32_t* ckbase, DevRec* recs,
-                       int32_t* rec_cnt, int* queue, const int* order, int n_cu) {
+                       int32_t* rec_cnt, int* queue, const int* order, int n_cu, const uint16_t* klist,
+                       const uint16_t* kpos, const int32_t* nkept) {
     int bpc = 8;
     if (const char* ev = getenv("SD_TRACE_BPC")) bpc = std::max(1, atoi(ev));  // developer knob
     const int grid = std::min((n_chunks + 3) / 4, bpc * n_cu);  // persistent: 8 workgroups of 4 waves per CU
 #define SD_TRACE(QQ)                                                                              \
     hipLaunchKernelGGL(sd_fast_trace<QQ>, dim3(grid), dim3(256), 0, st, chunks, n_chunks, bases2, \
                        nmask, slot_of, tcodes, lane_consts, toff, tlen, sc, plan.P, B, argV, ckpt, \
-                       ckbase, recs, rec_cnt, queue, order, plan.f16 ? 1 : 0, plan.bshift, plan.waves)
+                       ckbase, recs, rec_cnt, queue, order, plan.f16 ? 1 : 0, plan.bshift, plan.waves, klist, kpos, \
+                       nkept, plan.T)
     switch (plan.Qk) {
         case 1: SD_TRACE(1); break;
         case 2: SD_TRACE(2); break;

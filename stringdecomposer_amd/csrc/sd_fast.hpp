@@ -76,7 +76,11 @@ void build_peq(const std::vector<std::string>& tseq, std::vector<unsigned long l
 void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, int T, int Lmax, int ed_thr,
                          const uint32_t* bases2, const uint32_t* nmask, const unsigned long long* peq,
                          const int32_t* tlen, const int32_t* end_vlane, const int32_t* end_off,
-                         int32_t* dist, uint32_t* cendoff, uint32_t* crank, uint16_t* grank, int waves = 1);
+                         int32_t* dist, uint32_t* cendoff, uint32_t* crank, uint16_t* grank, int waves = 1,
+                         uint16_t* kpos = nullptr, uint16_t* klist = nullptr, int32_t* nkept = nullptr);
+// --ed_thr with more than 128 templates: chunks whose kept templates fit one wave (order1) / the rest (order2)
+void launch_split_order(hipStream_t st, const int* order, int n, const int32_t* nkept, int* order1, int* order2,
+                        int* counts);
 
 // number of checkpoint rows of the batch; fills ChunkDesc::pad with each chunk's first checkpoint
 int64_t fast_ckpt_rows_total(const FastPlan& plan, std::vector<ChunkDesc>& chunks);
@@ -121,18 +125,27 @@ bool launch_fast_fill_wide_fl(const FastPlan& plan, hipStream_t st, int grid, si
 void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                          const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                          const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
-                         int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank);
+                         int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank,
+                         const int* n_ptr = nullptr);   // n_ptr: the number of chunks lives on the device (order = a class list)
+// --ed_thr, more than 128 templates: the chunks whose kept templates fit one wave (sd_fast_wn_ck.hip)
+void launch_fast_fill_wn_compact(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, const uint32_t* bases2,
+                                 const uint32_t* nmask, const uint32_t* lane_consts, ScoreArgs sc, int32_t* B,
+                                 uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order1, const int* n_ptr,
+                                 int n_cu, const uint16_t* klist, const uint8_t* tcodes, const int32_t* toff,
+                                 const int32_t* tlen);
 
 bool launch_fast_fill_wn_fl(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks,
                             int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                             const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
-                            int* queue, const int* order, const uint32_t* cendoff, const uint32_t* crank);
+                            int* queue, const int* order, const uint32_t* cendoff, const uint32_t* crank,
+                            const int* n_ptr = nullptr);
 
 void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                        const uint32_t* bases2, const uint32_t* nmask, const uint32_t* slot_of,
                        const uint8_t* tcodes, const uint32_t* lane_consts, const int32_t* toff,
                        const int32_t* tlen, ScoreArgs sc, const int32_t* B, const int32_t* argV,
                        const uint32_t* ckpt, const int32_t* ckbase, DevRec* recs,
-                       int32_t* rec_cnt, int* queue, const int* order, int n_cu);
+                       int32_t* rec_cnt, int* queue, const int* order, int n_cu,
+                       const uint16_t* klist = nullptr, const uint16_t* kpos = nullptr, const int32_t* nkept = nullptr);
 
 }  // namespace sd

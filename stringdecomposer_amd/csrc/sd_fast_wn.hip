@@ -24,7 +24,8 @@ namespace sd {
 void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                          const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                          const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
-                         int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank) {
+                         int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank,
+                         const int* n_ptr) {
     const int W = plan.waves;
     const int per_cu = std::max(1, 8 / W);          // 213 VGPRs: two waves per SIMD, eight per CU
     const int grid = std::min(n_chunks, per_cu * n_cu);
@@ -32,7 +33,7 @@ void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* 
     const bool ranked = cendoff != nullptr;
     if (!getenv("SD_FILL_FULLFLOOR") &&
         launch_fast_fill_wn_fl(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt,
-                               ckbase, queue, order, cendoff, crank))
+                               ckbase, queue, order, cendoff, crank, n_ptr))
         return;
 #define SD_FILLWN_K(PP, RK)                                                                                      \
     {                                                                                                            \
@@ -40,7 +41,7 @@ void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
         hipLaunchKernelGGL((sd_fast_fill_wn<PP, RK>), dim3(grid), dim3(W * 64), lds, st, chunks, n_chunks, bases2, \
                            nmask, table, lane_consts, sc, W, plan.bf8_match, plan.bf8_mismatch, B, ckpt, ckbase,  \
-                           queue, order, cendoff, crank);                                                        \
+                           queue, order, cendoff, crank, n_ptr, nullptr, nullptr, nullptr, nullptr);             \
     }
 #define SD_FILLWN(PP)                                                   \
     case PP:                                                            \

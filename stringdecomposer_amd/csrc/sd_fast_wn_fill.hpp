@@ -21,18 +21,28 @@ __device__ __forceinline__ uint32_t cvt_bf8_pair(uint32_t tb, int pair, uint32_t
 }
 }  // namespace
 
-template <int P, bool RANKED, int FL = P>
+// COMPACT (--ed_thr with more than 128 templates, sd_fast_wn_ck.hip): ONE wave per chunk, whose 128 virtual lanes
+// hold the chunk's kept templates in their filtered order (klist, written by sd_rank_keep) -- the reference's
+// prefilter exists to cut the DP work of large monomer sets (main.cpp:128-149), and here it turns a chunk of W
+// waves into a chunk of one.  The wave gathers the codes of its templates into LDS when it takes the chunk;
+// lane order = filtered order, so "smallest virtual lane among equal ends" is already the reference's tie-break
+// and the unranked reduction applies.  Same B words and checkpoints (wave 0 of the W-wave layout).
+template <int P, bool RANKED, int FL = P, bool COMPACT = false>
 __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ codes,
     const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int W, uint32_t mb, uint32_t xb,
     int32_t* __restrict__ Bout, uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase,
     int* __restrict__ queue, const int* __restrict__ order, const uint32_t* __restrict__ cendoff,
-    const uint32_t* __restrict__ crank) {
+    const uint32_t* __restrict__ crank, const int* __restrict__ n_ptr, const uint16_t* __restrict__ klist,
+    const uint8_t* __restrict__ tcodes, const int32_t* __restrict__ toff, const int32_t* __restrict__ tlen) {
     static_assert(P % 16 == 0, "the code table is streamed 16 slots at a time");
+    static_assert(!(COMPACT && RANKED), "the compacted form needs no ranks");
     constexpr int G = P / 16;
     extern __shared__ uint32_t lds[];  // [W][G][2 halves][64 lanes][4 dwords] codes, then the exchange area
-    const int TBL = W * G * 512;
+    if (n_ptr) n_chunks = *n_ptr;      // the size of a chunk class is known on the device only
+    const int TBL = (COMPACT ? 1 : W) * G * 512;
+    if constexpr (!COMPACT)
     for (int idx = threadIdx.x * 4; idx < TBL; idx += blockDim.x * 4)
         *reinterpret_cast<uint4*>(&lds[idx]) = *reinterpret_cast<const uint4*>(&codes[idx]);
     int32_t* xv = reinterpret_cast<int32_t*>(lds + TBL);   // [2 parities][8 waves] wave maxima
@@ -44,20 +54,28 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     using CO = CellOps<true>;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const uint32_t* myc = lds + wave * (G * 512);
+    uint32_t* myc = lds + wave * (G * 512);
     const uint32_t* lc = lane_consts + (size_t)(wave * 64 + lane) * FAST_LANE_WORDS;
     const uint32_t endOffPlan = lc[FLC_ENDOFF];
     const uint32_t row0adj = CO::from_i16x2(lc[FLC_ROW0]);
     const uint32_t ins2 = CO::splat(sc.ins);
 
     for (;;) {
-        if (threadIdx.x == 0) {
-            const int q = atomicAdd(queue, 1);
-            xc[0] = q < n_chunks ? order[q] : -1;
+        int c;
+        if constexpr (COMPACT) {
+            int q = 0;
+            if (lane == 0) q = atomicAdd(queue, 1);
+            q = __builtin_amdgcn_readfirstlane(q);
+            c = q < n_chunks ? __builtin_amdgcn_readfirstlane(order[q]) : -1;
+        } else {
+            if (threadIdx.x == 0) {
+                const int q = atomicAdd(queue, 1);
+                xc[0] = q < n_chunks ? order[q] : -1;
+            }
+            __syncthreads();
+            c = __builtin_amdgcn_readfirstlane(xc[0]);
+            __syncthreads();
         }
-        __syncthreads();
-        const int c = __builtin_amdgcn_readfirstlane(xc[0]);
-        __syncthreads();
         if (c < 0) break;
         const ChunkDesc cd = chunks[c];
         const int n = cd.n;
@@ -65,7 +83,24 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
         rs.init(bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr, n);
         // --ed_thr: per-chunk end offsets (-inf for dropped templates) and tie-break ranks (main.cpp:141-147)
         const size_t cl = ((size_t)c * (size_t)W + (size_t)wave) * 64 + (size_t)lane;
-        const uint32_t endOff = CO::from_i16x2(RANKED ? cendoff[cl] : endOffPlan);
+        uint32_t endOffC = 0;
+        if constexpr (COMPACT) {
+            // this lane's two templates (lo plane: place `lane` of the filtered order, hi plane: place 64 + lane)
+            const uint16_t* kl = klist + (size_t)c * 128;
+            const int tlo = kl[lane], thi = kl[64 + lane];
+            const int Llo = tlo != 0xffff ? tlen[tlo] : 0, Lhi = thi != 0xffff ? tlen[thi] : 0;
+            const uint8_t* clo = tcodes + (tlo != 0xffff ? toff[tlo] : 0);
+            const uint8_t* chi = tcodes + (thi != 0xffff ? toff[thi] : 0);
+            for (int dw = 0; dw < G * 8; ++dw) {       // dword dw of the lane: slots 2 dw, 2 dw + 1 as {lo, hi, lo, hi}
+                const int a = 2 * dw;
+                const uint32_t b0 = a < Llo ? clo[a] : 7u, b1 = a < Lhi ? chi[a] : 7u;
+                const uint32_t b2 = a + 1 < Llo ? clo[a + 1] : 7u, b3 = a + 1 < Lhi ? chi[a + 1] : 7u;
+                myc[(dw >> 2) * 256 + lane * 4 + (dw & 3)] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            }
+            const int elo = Llo ? (Llo - 1) * sc.del : -32768, ehi = Lhi ? (Lhi - 1) * sc.del : -32768;
+            endOffC = ((uint32_t)elo & 0xffffu) | ((uint32_t)ehi << 16);
+        }
+        const uint32_t endOff = CO::from_i16x2(COMPACT ? endOffC : RANKED ? cendoff[cl] : endOffPlan);
         const uint32_t rank2 = RANKED ? crank[cl] : 0u;
         int32_t* Bc = Bout + cd.row0 + (uint64_t)c;
         uint32_t* ck = ckpt + ((uint64_t)cd.pad * (uint64_t)W + (uint64_t)wave) * (uint64_t)(P * 64) + lane;
@@ -112,13 +147,18 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
                 mhi = __ballot(hi == bw);
             }
             const int vw = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
-            const int par = (row & 1) * 8;
-            if (lane == 0) { xv[par + wave] = bw; xa[par + wave] = vw; xr[par + wave] = kw; }
-            __syncthreads();
-            int b = xv[par], arg = xa[par], rk = xr[par];
-            for (int w2 = 1; w2 < W; ++w2) {
-                const int b2 = xv[par + w2], r2 = xr[par + w2];
-                if (b2 > b || (RANKED && b2 == b && r2 < rk)) { b = b2; rk = r2; arg = (w2 << 7) | xa[par + w2]; }
+            int b = bw, arg = vw;
+            if constexpr (!COMPACT) {
+                const int par = (row & 1) * 8;
+                if (lane == 0) { xv[par + wave] = bw; xa[par + wave] = vw; xr[par + wave] = kw; }
+                __syncthreads();
+                int rk = xr[par];
+                b = xv[par];
+                arg = xa[par];
+                for (int w2 = 1; w2 < W; ++w2) {
+                    const int b2 = xv[par + w2], r2 = xr[par + w2];
+                    if (b2 > b || (RANKED && b2 == b && r2 < rk)) { b = b2; rk = r2; arg = (w2 << 7) | xa[par + w2]; }
+                }
             }
             b = __builtin_amdgcn_readfirstlane(b);
             arg = __builtin_amdgcn_readfirstlane(arg);
@@ -216,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
             ++tp;
             reduce_ends(L[P - 1], i + 1);
         }
-        __syncthreads();   // the exchange area and xc are rewritten for the next chunk
+        if constexpr (!COMPACT) __syncthreads();   // the exchange area and xc are rewritten for the next chunk
     }
 }
 

@@ -8,7 +8,8 @@ namespace sd {
 bool launch_fast_fill_wn_fl(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks,
                             int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                             const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
-                            int* queue, const int* order, const uint32_t* cendoff, const uint32_t* crank) {
+                            int* queue, const int* order, const uint32_t* cendoff, const uint32_t* crank,
+                            const int* n_ptr) {
     if (!plan.wide || plan.waves < 2 || plan.floor_slots < 1 || plan.floor_slots > 48) return false;
     const int W = plan.waves;
     const bool ranked = cendoff != nullptr;
@@ -18,7 +19,7 @@ bool launch_fast_fill_wn_fl(const FastPlan& plan, hipStream_t st, int grid, size
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
         hipLaunchKernelGGL((sd_fast_fill_wn<PP, RK, 48>), dim3(grid), dim3(W * 64), lds, st, chunks, n_chunks,      \
                            bases2, nmask, table, lane_consts, sc, W, plan.bf8_match, plan.bf8_mismatch, B, ckpt,   \
-                           ckbase, queue, order, cendoff, crank);                                                  \
+                           ckbase, queue, order, cendoff, crank, n_ptr, nullptr, nullptr, nullptr, nullptr);       \
         return true;                                                                                               \
     }
 #define SD_WNFL(PP)                                                 \

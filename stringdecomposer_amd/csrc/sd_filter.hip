@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void sd_hw_dist(const ChunkDesc* __restrict__ 
 __global__ void sd_rank_keep(int n_chunks, int T, int ed_thr, const int32_t* __restrict__ dist,
                              const int32_t* __restrict__ end_vlane, const int32_t* __restrict__ end_off,
                              uint16_t* __restrict__ cendoff, uint16_t* __restrict__ crank,
-                             uint16_t* __restrict__ grank, int W) {
+                             uint16_t* __restrict__ grank, int W, uint16_t* __restrict__ kpos,
+                             uint16_t* __restrict__ klist, int32_t* __restrict__ nkept) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long long)n_chunks * T) return;
     const int c = (int)(g / T), j = (int)(g % T);
@@ -115,10 +116,18 @@ __global__ void sd_rank_keep(int n_chunks, int T, int ed_thr, const int32_t* __r
     for (int i = 1; i < T; ++i)
         if (d[i] < d[first]) first = i;
     const bool kept = j == first || dj <= ed_thr;
-    int rank = 0;
+    int rank = 0, total = 0;
     for (int i = 0; i < T; ++i) {
         const bool ki = i == first || d[i] <= ed_thr;
+        total += ki ? 1 : 0;
         if (ki && (d[i] < dj || (d[i] == dj && i < j))) ++rank;
+    }
+    if (kpos) {
+        // compacted form for large template sets (sd_fast_wn_ck.hip): the kept templates of the chunk in their
+        // filtered order (klist: [chunk][128], filled with 0xffff before), every template's place in it, the count
+        kpos[(size_t)c * T + j] = (uint16_t)(kept ? rank : 0xffff);
+        if (kept && rank < 128) klist[(size_t)c * 128 + rank] = (uint16_t)j;
+        if (j == 0) nkept[c] = total;
     }
     if (grank) {
         grank[(size_t)c * T + j] = (uint16_t)(kept ? rank : 0xffff);
@@ -151,16 +160,48 @@ void build_peq(const std::vector<std::string>& tseq, std::vector<unsigned long l
         }
 }
 
+// Splits the chunk order (longest first) of a batch into the chunks whose kept templates fit one wave (<= 128)
+// and the rest, both in the original order; counts[0], counts[1] = sizes.  One wave.
+__global__ __launch_bounds__(64) void sd_split_order(const int* __restrict__ order, int n, const int32_t* __restrict__ nkept,
+                                                     int* __restrict__ order1, int* __restrict__ order2,
+                                                     int* __restrict__ counts) {
+    const int lane = threadIdx.x;
+    int n1 = 0, n2 = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int x = base + lane;
+        const int c = x < n ? order[x] : -1;
+        const bool small = c >= 0 && nkept[c] <= 128;
+        const unsigned long long m1 = __ballot(small), m2 = __ballot(c >= 0 && !small);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (small) order1[n1 + __popcll(m1 & below)] = c;
+        else if (c >= 0) order2[n2 + __popcll(m2 & below)] = c;
+        n1 += __popcll(m1);
+        n2 += __popcll(m2);
+    }
+    if (lane == 0) { counts[0] = n1; counts[1] = n2; }
+}
+
+void launch_split_order(hipStream_t st, const int* order, int n, const int32_t* nkept, int* order1, int* order2,
+                        int* counts) {
+    hipLaunchKernelGGL(sd_split_order, dim3(1), dim3(64), 0, st, order, n, nkept, order1, order2, counts);
+}
+
 void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, int T, int Lmax, int ed_thr,
                          const uint32_t* bases2, const uint32_t* nmask, const unsigned long long* peq,
                          const int32_t* tlen, const int32_t* end_vlane, const int32_t* end_off,
-                         int32_t* dist, uint32_t* cendoff, uint32_t* crank, uint16_t* grank, int waves) {
+                         int32_t* dist, uint32_t* cendoff, uint32_t* crank, uint16_t* grank, int waves,
+                         uint16_t* kpos, uint16_t* klist, int32_t* nkept) {
     const long long total = (long long)n_chunks * T;
     const int grid = (int)((total + 255) / 256);
     if (!grank) {
         const size_t words = (size_t)n_chunks * 64 * (size_t)waves;
         hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, cendoff, words, 0x80008000u);
         hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, crank, words, 0x7fff7fffu);
+    }
+    if (klist) {
+        const size_t words = (size_t)n_chunks * 64;   // [chunk][128] uint16
+        hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<uint32_t*>(klist), words, 0xffffffffu);
     }
     const int W = std::max(1, (Lmax + 63) / 64);
     // match masks in LDS: as many templates as fit in 64 KB (all of them up to ~540 at 3 words)
@@ -173,7 +214,8 @@ void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, 
     if (W <= 1) SD_HW(1) else if (W == 2) SD_HW(2) else if (W == 3) SD_HW(3) else if (W == 4) SD_HW(4) else SD_HW(8)
 #undef SD_HW
     hipLaunchKernelGGL(sd_rank_keep, dim3(grid), dim3(256), 0, st, n_chunks, T, ed_thr, dist, end_vlane, end_off,
-                       reinterpret_cast<uint16_t*>(cendoff), reinterpret_cast<uint16_t*>(crank), grank, waves);
+                       reinterpret_cast<uint16_t*>(cendoff), reinterpret_cast<uint16_t*>(crank), grank, waves, kpos, klist,
+                       nkept);
 }
 
 }  // namespace sd

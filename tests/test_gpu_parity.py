@@ -652,6 +652,29 @@ def test_fill_without_dominated_start_maxima(oracle, name):
         assert uni == exp
 
 
+@pytest.mark.parametrize("thr", [0, 25, 48, 60, 200])
+def test_ed_thr_compacts_large_template_sets(oracle, thr):
+    """--ed_thr with more than 128 templates (csrc/sd_fast_wn_ck.hip): a chunk whose kept templates number at
+    most 128 is filled by one wave holding exactly those, in their filtered order; chunks that keep more stay on
+    the W-wave ranked kernel.  Thresholds from "only the nearest template" to "everything kept" (both classes,
+    and mixes of them), against the oracle and against the same job with the compaction switched off."""
+    mn, ms = synth.make_monomers(150, seed=12)          # 300 templates: three waves per chunk
+    rn, rs = synth.make_reads(ms, 4, read_len=3200, seed=5)
+    st = synth.Stream(8, 2)
+    rs = list(rs) + [synth._ACGT[st.below(1500, 4)].tobytes(), (ms[3] * 9)[:1400] + b"N" * 2 + ms[77] * 3]
+    rn = ["r%d" % i for i in range(len(rs))]
+    kw = dict(part_size=700, overlap=100, ed_thr=thr)
+    exp = oracle.decompose(rn, rs, mn, ms, threads=8, part=700, overlap=100, ed_thr=thr)
+    got = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, **kw)
+    os.environ["SD_EDTHR_COMPACT"] = "0"
+    try:
+        full = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, **kw)
+    finally:
+        del os.environ["SD_EDTHR_COMPACT"]
+    assert full == exp
+    assert got == exp
+
+
 def test_multi_wave_wide_layout_long_reads_vs_generic_and_oracle(oracle):
     """More than 128 templates on the fast path (sd_fast_fill_wn: W waves per chunk, template codes in LDS,
     one workgroup barrier per row): 150 monomers = 300 templates = 3 waves, reads of 50 kb (checkpoints,
