@@ -15,9 +15,11 @@
 // HBM, and the walk reads one such pair per step.  The walk only counts: with nL = number of "left"
 // moves, an optimal path has  matches = qlen - dist + nL  ('=' columns) and dist + matches columns.
 //
-// History: [lane][column][K] x 16 B, lane-major, so that the walk of a lane -- which moves to the same or
-// the previous column every step -- stays inside a few 64-B sectors.  ~8 KB per 171 x 171 pair, written
-// once and read once: the kernel is HBM-bound (about 16 KB per pair), not ALU-bound.
+// History: [workgroup][column][K][thread] x 16 B: the 64 lanes of a wave write one contiguous KB per (column,
+// word), and lanes that walk near the same column read neighbouring pieces of the same sectors.  ~8 KB per
+// 171 x 171 pair, written once and read about once: the kernel is HBM-bound, not ALU-bound.  (A lane-major
+// history -- every lane its own 8-KB region -- wrote 16-B pieces of 64 different sectors per instruction:
+// 2.4x the bytes at the memory, 73 M instead of 141 M pairs/s end to end.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -53,7 +55,10 @@ __global__ __launch_bounds__(256) void sd_nw_pairs(const uint8_t* __restrict__ s
     const int64_t n_pairs = pair_tmpl ? n_seg : n_seg * (int64_t)T;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    uint4* H = hist + (size_t)gid * (size_t)qmax * K;
+    // history of this lane: [column][word][thread of the workgroup] -- the 64 lanes of a wave write one
+    // contiguous KB per (column, word), whole sectors (a lane-major layout wrote 16-B pieces of 64 different
+    // sectors per instruction: 2.4x the bytes at the memory)
+    uint4* H = hist + (size_t)blockIdx.x * 256 * (size_t)qmax * K + threadIdx.x;
     for (int64_t p = gid; p < n_pairs; p += stride) {
         const int64_t s = pair_tmpl ? p : p / T;
         const int t = pair_tmpl ? pair_tmpl[p] : (int)(p - s * T);
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(256) void sd_nw_pairs(const uint8_t* __restrict__ s
             prev = ch;
             const u64* eqp = pq + base_code_dev(ch) * K;
             int hin = 1;  // global alignment: D[c][0] - D[c-1][0] = 1
-            uint4* hc = H + (size_t)c * K;
+            uint4* hc = H + (size_t)c * K * 256;
 #pragma unroll
             for (int w = 0; w < K; ++w) {
                 if (w <= lastW) {
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256) void sd_nw_pairs(const uint8_t* __restrict__ s
                     Pv[w] = npv;
                     Mv[w] = Ph & Xv;
                     hin = hout;
-                    hc[w] = make_uint4((uint32_t)PhU, (uint32_t)(PhU >> 32), (uint32_t)npv, (uint32_t)(npv >> 32));
+                    hc[w * 256] = make_uint4((uint32_t)PhU, (uint32_t)(PhU >> 32), (uint32_t)npv, (uint32_t)(npv >> 32));
                 }
             }
             score += hin;  // vertical... the last word's carry is the horizontal delta of row tl
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void sd_nw_pairs(const uint8_t* __restrict__ s
         // walk (edlib priority: up > left > diagonal), counting the "left" moves
         int ci = c, r = tl, nL = 0;
         while (ci > 0 && r > 0) {
-            const uint4 h = H[(size_t)(ci - 1) * K + ((r - 1) >> 6)];
+            const uint4 h = H[((size_t)(ci - 1) * K + ((r - 1) >> 6)) * 256];
             const int b = (r - 1) & 63;
             const u64 ph = ((u64)h.y << 32) | h.x, pv = ((u64)h.w << 32) | h.z;
             if ((ph >> b) & 1ull) { --ci; }
