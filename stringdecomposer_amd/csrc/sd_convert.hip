@@ -119,8 +119,10 @@ inline double now_seconds() {
 inline void put_f2(std::string& o, double v) { put_fixed2(o, v); }   // == Python "{:.2f}".format(v)
 }  // namespace
 
-int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off, std::string& fin,
-                           std::string& alt, std::string& err) {
+int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off, TextBuf& fin,
+                           TextBuf& alt, std::string& err) {
+    fin.clear();
+    alt.clear();
     const int64_t nB = row_off[n_reads];
     if (nB == 0) return SD_OK;
     const double t_0 = now_seconds();
@@ -238,13 +240,8 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
         }
     });
     const double t_c = now_seconds();
-    size_t tf = fin.size(), ta = alt.size();
-    for (const std::string& p : pf) tf += p.size();
-    for (const std::string& p : pa) ta += p.size();
-    fin.reserve(tf);
-    alt.reserve(ta);
-    for (const std::string& p : pf) fin += p;
-    for (const std::string& p : pa) alt += p;
+    gather_text(pf, threads, fin);
+    gather_text(pa, threads, alt);
     t_prepare += t_a - t_0;
     t_identity += t_b - t_a;
     t_format += t_c - t_b;
@@ -306,11 +303,9 @@ extern "C" int sd_convert_raw_tsv(const char* raw_tsv, const char* reads_fa, con
     std::vector<sd::PostRead> reads;      // reads of the current batch, in file order of the raw TSV
     std::vector<sd_rec> rows;
     std::vector<int64_t> row_off(1, 0);
-    std::string fin, alt;
+    sd::TextBuf fin, alt;
     auto flush = [&]() -> int {
         if (reads.empty()) return SD_OK;
-        fin.clear();
-        alt.clear();
         const int r2 = pp.process(reads.data(), reads.size(), rows.data(), row_off.data(), fin, alt, err);
         if (r2) return r2;
         if (std::fwrite(fin.data(), 1, fin.size(), ff) != fin.size() || std::fwrite(alt.data(), 1, alt.size(), fa) != alt.size()) {

@@ -25,8 +25,8 @@ class PostProcessor {
     // rows[row_off[r] .. row_off[r+1]) = blocks of reads[r] (sd_rec.tmpl in the DP's template order: monomers,
     // then their reverse complements; read-global inclusive coordinates).  Appends the text of the final TSV
     // rows (main.py:157-160) and, with second_best, of the _alt rows (:161-165).
-    int process(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off, std::string& fin,
-                std::string& alt, std::string& err);
+    int process(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off, TextBuf& fin,
+                TextBuf& alt, std::string& err);   // fin / alt are REPLACED by the text of this batch
     int tmpl_of_name(const std::string& nm) const;   // first template of that name in the DP's order, -1 if none
     std::vector<std::string> tname;                  // the DP's template names: m, ..., m', ...
     double t_prepare = 0, t_identity = 0, t_format = 0, t_concat = 0;   // seconds spent in process(), by stage

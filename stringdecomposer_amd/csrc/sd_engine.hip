@@ -1939,7 +1939,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     std::string sink_err;
     double t_fmt = 0, t_post = 0, t_io = 0;
     auto sink_loop = [&]() {
-        std::string raw, fin, alt;
+        sd::TextBuf raw, fin, alt;
         std::vector<sd::PostRead> preads;
         for (;;) {
             Work w;
@@ -1967,15 +1967,12 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
                     sd::format_rows(parts[(size_t)x], reads[sl.r].name, reads[sl.r].name_len, ts.tnames, w.rows + sl.a,
                                     (size_t)(sl.b - sl.a), sl.a > off[sl.r - w.r0] ? w.rows[sl.a - 1].end : 0);
                 });
-                raw.clear();
-                for (const std::string& q : parts) raw += q;
+                sd::gather_text(parts, p->threads, raw);
                 t_fmt += now_s() - t0;
                 t0 = now_s();
                 preads.clear();
                 for (size_t r = w.r0; r < w.r1; ++r)
                     preads.push_back(sd::PostRead{reads[r].name, reads[r].name_len, reads[r].seq, reads[r].len});
-                fin.clear();
-                alt.clear();
                 std::string e2;
                 const int r2 = pp.process(preads.data(), preads.size(), w.rows, off, fin, alt, e2);
                 t_post += now_s() - t0;

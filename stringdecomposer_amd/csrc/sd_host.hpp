@@ -11,6 +11,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -110,6 +111,19 @@ inline size_t seam_merge_inplace(sd_rec* b, size_t N) {
     return w;
 }
 inline void seam_merge(std::vector<sd_rec>& b) { b.resize(seam_merge_inplace(b.data(), b.size())); }
+
+// Text of a batch: a byte vector whose resize() does not zero-fill (the parts of a batch are copied into it by
+// all threads; a std::string would first write 200 MB of zeros for the _alt rows of a --second-best batch).
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new (static_cast<void*>(p)) U;
+        else ::new (static_cast<void*>(p)) U(std::forward<A>(a)...);
+    }
+};
+using TextBuf = std::vector<char, NoInitAlloc<char>>;
 
 // decimal text of an int, appended (std::to_string(int), main.cpp:277-281)
 inline void put_int(std::string& o, int64_t v) {
@@ -273,6 +287,16 @@ inline void parallel_for(int64_t n, int threads, int64_t grain, F&& body) {
     const int64_t blocks = (n + grain - 1) / grain;
     const int nt = (int)(blocks < threads ? blocks : threads);
     HostPool::get().run(nt - 1, work);
+}
+
+// out = concatenation of parts, copied by up to `threads` threads (parts are typically 0.1-1 MB each)
+inline void gather_text(const std::vector<std::string>& parts, int threads, TextBuf& out) {
+    std::vector<size_t> off(parts.size() + 1, 0);
+    for (size_t i = 0; i < parts.size(); ++i) off[i + 1] = off[i] + parts[i].size();
+    out.resize(off[parts.size()]);
+    parallel_for((int64_t)parts.size(), threads, 4, [&](int64_t i) {
+        if (!parts[(size_t)i].empty()) std::memcpy(out.data() + off[(size_t)i], parts[(size_t)i].data(), parts[(size_t)i].size());
+    });
 }
 
 // 2-bit packing of one chunk (16 bases per dword, base i at bits 2*(i&15)); returns true if the chunk
