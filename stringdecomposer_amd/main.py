@@ -23,7 +23,20 @@ import os
 import pathlib
 import sys
 
-import numpy as np
+
+
+class _LazyNumpy:
+    """numpy is only needed by the module-level convert_* API (the Python implementation of the post-processing,
+    kept for the tests and for callers of the reference's functions); the command line runs natively and should
+    not pay ~0.1-0.2 s of import time for it."""
+
+    def __getattr__(self, name):
+        import numpy
+        globals()["np"] = numpy
+        return getattr(numpy, name)
+
+
+np = _LazyNumpy()
 
 from . import lib
 from . import shard
