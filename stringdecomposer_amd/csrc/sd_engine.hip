@@ -21,6 +21,7 @@
 
 #include "../../include/sd_hip.h"
 #include "sd_convert.hpp"
+#include "sd_nw.hpp"
 #include "sd_device.hpp"
 #include "sd_fast.hpp"
 #include "sd_host.hpp"
@@ -2048,6 +2049,12 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     if (timing)
         std::fprintf(stderr, "[sd timing] post-processing: segments %.1f ms, identities %.1f ms, text %.1f ms, concatenation %.1f ms\n",
                      pp.t_prepare * 1e3, pp.t_identity * 1e3, pp.t_format * 1e3, pp.t_concat * 1e3);
+    if (timing) {
+        double nw[4];
+        sd::nw_stage_seconds(nw);
+        std::fprintf(stderr, "[sd timing] identities on the device: preparation + staging %.1f ms, uploads %.1f ms, launch %.1f ms, "
+                     "kernel + downloads %.1f ms\n", nw[0] * 1e3, nw[1] * 1e3, nw[2] * 1e3, nw[3] * 1e3);
+    }
     if (rc) { set_err(errbuf, errlen, err); return rc; }
     return SD_OK;
 }

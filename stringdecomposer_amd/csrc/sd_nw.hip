@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <mutex>
@@ -211,6 +213,23 @@ namespace sd {
 // text[seg_start[s] .. seg_start[s] + seg_len[s]).  Templates as given (the caller compresses them for the
 // homopolymer form).  Outputs per pair (all-vs-all: s * T + t; pair_tmpl: s).  SD_ERR_UNSUPPORTED for input
 // the kernel does not take; nothing is written then.
+// stage times of the device identity calls of this process (seconds): host preparation + staging copy, uploads,
+// kernel (launch to completion), downloads -- printed with SD_TIMING by the command-line entry points
+static std::atomic<long long> g_nw_ns[4];
+void nw_stage_seconds(double out[4]) {
+    for (int i = 0; i < 4; ++i) out[i] = (double)g_nw_ns[i].load() / 1e9;
+}
+namespace {
+struct NwLap {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void to(int i) {
+        const auto n = std::chrono::steady_clock::now();
+        g_nw_ns[i] += std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count();
+        t = n;
+    }
+};
+}  // namespace
+
 int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans, const int64_t* seg_start,
                        const int32_t* seg_len, int64_t n_seg, const std::vector<std::string>& tmpl,
                        const int32_t* pair_tmpl, bool homo, int device, int threads, int32_t* dist,
@@ -218,6 +237,7 @@ int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans
     const int T = (int)tmpl.size();
     const int64_t n_pairs = pair_tmpl ? n_seg : n_seg * (int64_t)T;
     if (n_pairs == 0) return SD_OK;
+    NwLap lap;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return SD_ERR_NO_DEVICE; }
     if (device < 0 || device >= ndev) return SD_ERR_PARAM;
@@ -311,6 +331,7 @@ int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans
               g_nw.dist.need(sizeof(int32_t) * (size_t)n_pairs) && g_nw.matches.need(sizeof(int32_t) * (size_t)n_pairs) &&
               (!pair_tmpl || g_nw.pair.need(sizeof(int32_t) * (size_t)n_seg));
     if (!ok) return SD_ERR_HIP;
+    lap.to(0);
     auto up = [](void* d, const void* h, size_t n) { return n == 0 || hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; };
     ok = up(g_nw.seq.p, g_nw.stage, (size_t)text) && up(g_nw.starts.p, seg_start, sizeof(int64_t) * (size_t)n_seg) &&
          up(g_nw.lens.p, seg_len, sizeof(int32_t) * (size_t)n_seg) &&
@@ -318,6 +339,7 @@ int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans
          up(g_nw.tlen.p, tl.data(), sizeof(int32_t) * (size_t)T) &&
          (!pair_tmpl || up(g_nw.pair.p, pair_tmpl, sizeof(int32_t) * (size_t)n_seg));
     if (!ok) return SD_ERR_HIP;
+    lap.to(1);
     sd::launch_nw_pairs(K, nullptr, grid, static_cast<const uint8_t*>(g_nw.seq.p), static_cast<const int64_t*>(g_nw.starts.p),
                         static_cast<const int32_t*>(g_nw.lens.p), n_seg, T,
                         pair_tmpl ? static_cast<const int32_t*>(g_nw.pair.p) : nullptr,
@@ -325,9 +347,11 @@ int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans
                         homo ? 1 : 0, qmax, g_nw.hist.p, static_cast<int32_t*>(g_nw.dist.p),
                         static_cast<int32_t*>(g_nw.matches.p));
     if (hipGetLastError() != hipSuccess) return SD_ERR_HIP;
+    lap.to(2);
     if (hipMemcpy(dist, g_nw.dist.p, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(matches, g_nw.matches.p, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost) != hipSuccess)
         return SD_ERR_HIP;
+    lap.to(3);
     return SD_OK;
 }
 }  // namespace sd

@@ -23,5 +23,7 @@ int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans
                        const int32_t* seg_len, int64_t n_seg, const std::vector<std::string>& tmpl,
                        const int32_t* pair_tmpl, bool homo, int device, int threads, int32_t* dist,
                        int32_t* matches);
+// accumulated over the device identity calls of the process: preparation + staging, uploads, kernel, downloads
+void nw_stage_seconds(double out[4]);
 
 }  // namespace sd
