@@ -185,6 +185,14 @@ int sd_engine_timings(sd_engine* e, float ms[4]);
  * [6] bytes of HBM workspace allocated [7] number of fill launches per run */
 int sd_engine_info(sd_engine* e, int64_t info[8]);
 
+/* Host only (no device needed): the layout sd_engine_create would choose for this monomer set and scoring.
+ * info: [0] kernel family of "auto" (2 fast, 1 generic; generic: the reason is in errbuf, rc is still SD_OK)
+ * [1] slots per lane P [2] cell arithmetic code (as sd_engine_info [4] >> 8) [3] last slot of a lane that needs
+ * the maximum with the start term [4] waves per chunk [5] cells in the shortest first lane of a template
+ * [6] cells in the fullest lane [7] common factor divided out of the four scores. */
+int sd_plan_info(const sd_params* p, const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono,
+                 int64_t info[8], char* errbuf, size_t errlen);
+
 /* ---- streaming form: sequences in host memory -> rows in host memory ------------------------
  * AlignReadsSet (main.cpp:67-122) without the text: chunk table (:70-81), DP + traceback per chunk
  * (:84-102), per-read flush with chunk offsets and seam merge (:104-117).  A stream keeps two device

@@ -349,6 +349,62 @@ int sd_device_count(void) { return device_count_checked(); }
 
 void sd_free(void* p) { std::free(p); }
 
+// Host only: the layout the fast kernel family would use for a monomer set and scoring -- what sd_engine_create
+// decides before it touches the device.  For tests without a GPU and for users who want to know which kernels a
+// set will run on.
+int sd_plan_info(const sd_params* p, const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono,
+                 int64_t info[8], char* errbuf, size_t errlen) {
+    std::string err;
+    int rc = validate_params(p, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    if (n_mono <= 0 || !mono_seqs || !mono_lens || !info) { set_err(errbuf, errlen, "no monomers"); return SD_ERR_PARAM; }
+    auto gcd = [](int a, int b) { a = a < 0 ? -a : a; b = b < 0 ? -b : b; while (b) { const int t = a % b; a = b; b = t; } return a; };
+    int g = gcd(gcd(p->ins, p->del), gcd(p->mismatch, p->match));
+    if (g < 1) g = 1;
+    const sd::ScoreArgs sc{p->ins / g, p->del / g, p->mismatch / g, p->match / g};
+    std::vector<std::string> tseq((size_t)2 * n_mono);
+    for (int j = 0; j < n_mono; ++j) {
+        if (mono_lens[j] <= 0) { set_err(errbuf, errlen, "ERROR: empty monomer sequence"); return SD_ERR_EMPTY; }
+        tseq[(size_t)j].assign(mono_seqs[j], (size_t)mono_lens[j]);
+        rc = sd::check_alphabet("<monomer>", mono_seqs[j], mono_lens[j], err);
+        if (rc) { set_err(errbuf, errlen, err); return rc; }
+        if (!sd::reverse_complement(tseq[(size_t)j], tseq[(size_t)n_mono + j])) { set_err(errbuf, errlen, "map::at"); return SD_ERR_SYMBOL; }
+    }
+    sd::FastPlan plan;
+    std::string why;
+    const bool ok = sd::fast_plan_build(tseq, sc, p->part_size + p->overlap, plan, why);
+    for (int i = 0; i < 8; ++i) info[i] = 0;
+    info[0] = ok ? 2 : 1;                       // kernel family "auto" would take: 2 fast, 1 generic
+    if (!ok) { set_err(errbuf, errlen, why); return SD_OK; }
+    info[1] = plan.P;
+    info[2] = plan.waves > 1 ? 5 : plan.wide ? (plan.f16 ? 4 : 3) : plan.f16 ? 2 : 1;   // as sd_engine_info [4] >> 8
+    info[3] = plan.floor_slots;
+    info[4] = plan.waves;
+    // narrow layout: cells in the shortest first lane of a template and in the fullest lane (from slot_of)
+    int64_t min_first = 1 << 30, max_lane = 0, x = 0;
+    for (size_t j = 0; j < tseq.size(); ++j) {
+        const int64_t L = (int64_t)tseq[j].size();
+        int64_t run = 0, lanes_seen = 0;
+        for (int64_t k = 0; k < L; ++k, ++x) {
+            const uint32_t so = plan.slot_of[(size_t)x];
+            const bool new_lane = k == 0 || (so & 127u) != (plan.slot_of[(size_t)x - 1] & 127u) || (so >> 16) != (plan.slot_of[(size_t)x - 1] >> 16);
+            if (new_lane && k > 0) {
+                if (lanes_seen == 0) min_first = std::min(min_first, run);
+                max_lane = std::max(max_lane, run);
+                ++lanes_seen;
+                run = 0;
+            }
+            ++run;
+        }
+        if (lanes_seen == 0) min_first = std::min(min_first, run);
+        max_lane = std::max(max_lane, run);
+    }
+    info[5] = min_first;
+    info[6] = max_lane;
+    info[7] = g;
+    return SD_OK;
+}
+
 int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mono_seqs,
                      const int32_t* mono_lens, int32_t n_mono, char* errbuf, size_t errlen) {
     if (!out) return SD_ERR_PARAM;

@@ -34,7 +34,7 @@ EXPORTS = [
     "sd_stream_create", "sd_stream_destroy", "sd_stream_submit", "sd_stream_collect", "sd_stream_stats",
     "sd_stream_info", "sd_pack_bases", "sd_identity_segments_dev", "sd_nw_release_cache",
     "sd_run_files", "sd_convert_raw_tsv", "sd_decompose_files_range", "sd_assemble_files_tsv",
-    "sd_host_stage_rates", "sd_run_files_range",
+    "sd_host_stage_rates", "sd_run_files_range", "sd_plan_info",
 ]
 
 
@@ -96,6 +96,7 @@ def load():
                                      C.c_char_p, C.c_size_t]
     L.sd_engine_timings.argtypes = [C.c_void_p, P(C.c_float)]
     L.sd_engine_info.argtypes = [C.c_void_p, P(C.c_int64)]
+    L.sd_plan_info.argtypes = [P(Params), P(C.c_char_p), P(C.c_int32), C.c_int32, P(C.c_int64), C.c_char_p, C.c_size_t]
     L.sd_chunk_plan.restype = C.c_int32
     L.sd_chunk_plan.argtypes = [C.c_int64, C.c_int32, C.c_int32, P(C.c_int64), P(C.c_int32), C.c_int32]
     L.sd_seam_merge.restype = C.c_int32
@@ -168,6 +169,25 @@ def make_params(scoring=(-1, -1, -1, 1), part_size=5000, overlap=500, ed_thr=-1,
     p.threads, p.device, p.kernel = int(threads), int(device), int(kernel)
     p.max_batch_rows = int(max_batch_rows)
     return p
+
+
+def plan_info(mono_seqs, **kw):
+    """The layout the fast kernel family would use for this monomer set and scoring (host only, no GPU needed):
+    {"family", "cells_per_lane", "cells", "floor_slots", "waves", "min_first_lane_cells", "max_lane_cells",
+    "score_factor", "why"} -- family "generic" carries the reason in "why"."""
+    L = load()
+    p = make_params(**kw)
+    ms = [_b(s) for s in mono_seqs]
+    ml = (C.c_int32 * max(len(ms), 1))(*[len(s) for s in ms])
+    v = (C.c_int64 * 8)()
+    err = C.create_string_buffer(4096)
+    rc = L.sd_plan_info(C.byref(p), _strs(ms), ml, len(ms), v, err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+    cells = {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table", 4: "f16/bf8-table", 5: "f16/bf8-codes x waves"}
+    return {"family": {1: "generic", 2: "fast"}[v[0]], "cells_per_lane": v[1], "cells": cells.get(v[2], "?") if v[0] == 2 else "int32",
+            "floor_slots": v[3], "waves": v[4], "min_first_lane_cells": v[5], "max_lane_cells": v[6],
+            "score_factor": v[7], "why": err.value.decode(errors="replace") if v[0] == 1 else ""}
 
 
 def release_cache():

@@ -494,3 +494,59 @@ def test_two_decimal_text_equals_python_format():
     assert len(got) == n
     bad = [(x, g) for x, g in zip(v[:, 0].tolist(), got) if "{:.2f}".format(x) != g]
     assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("sc,cells", [((-2, -1, -3, 6), "f16"), ((-2, -2, -3, 8), "f16"), ((-2, -2, -3, 9), "int16"),
+                                      ((-1, -1, -1, 1), "f16"), ((0, 0, -1, 14), "f16"), ((0, 0, -1, 15), "int16"),
+                                      ((0, -6, -4, -1), "f16"), ((0, -7, -4, -1), "int16"), ((-1, -5, -2, 1), "f16"),
+                                      ((-10, -10, -10, 10), "f16"), ((-4, -6, -8, 4), "f16"), ((0, 0, -3, 45), "int16")])
+def test_plan_cell_format_switch(sc, cells):
+    """sd_plan_info (host only): the fp16 / int16 decision of fast_plan_build for scorings on both sides of the
+    exact-integer range of fp16 -- the same cases the GPU test runs against the oracle."""
+    mn, ms = synth.make_monomers(12, seed=3)
+    info = lib.plan_info(ms, scoring=sc)
+    assert info["family"] == "fast" and info["cells"] == cells, info
+
+
+def test_plan_layouts_of_the_baseline_sets_and_fuzz_fixtures():
+    mn, ms = synth.make_monomers(12, seed=1)
+    c2 = lib.plan_info(ms)
+    assert (c2["cells_per_lane"], c2["cells"], c2["waves"]) == (35, "f16", 1) and c2["floor_slots"] <= 16, c2
+    mn, ms = synth.make_monomers(64, seed=1)
+    c4 = lib.plan_info(ms)
+    assert c4["cells"] == "f16/bf8-table" and c4["cells_per_lane"] == 176 and c4["floor_slots"] <= 32, c4
+    mn, ms = synth.make_monomers(150, seed=1)
+    big = lib.plan_info(ms)
+    assert big["cells"] == "f16/bf8-codes x waves" and big["waves"] == 3, big
+    assert lib.plan_info([b"A", b"ACGTACGT"])["family"] == "generic"          # a 1-bp monomer
+    assert lib.plan_info([b"ACGTACGT"], scoring=(1, -1, -1, 1))["family"] == "generic"   # positive gap score
+    fz = os.path.join(GOLDEN, "fuzz")
+    # the scoring that overran fp16 before the range bound charged B's growth (seed 906)
+    mn, ms, _ = lib.fasta_load(os.path.join(fz, "fuzz_fail_906_791", "m.fa"))
+    assert lib.plan_info(ms, scoring=(0, -4, -4, -1))["cells"] == "int16"
+    # the 5-bp template whose first lane must keep two cells (seed 1301)
+    mn, ms, _ = lib.fasta_load(os.path.join(fz, "fuzz_fail_1301_1135", "m.fa"))
+    assert lib.plan_info(ms, scoring=(-9, -7, -8, 9))["min_first_lane_cells"] >= 2
+
+
+def test_plan_lane_boundaries_properties():
+    """The plan may give a lane fewer than P cells to keep the start-term maxima in few slots: lanes never exceed P,
+    the first lane of a template keeps at least two cells, and the chosen layout never costs more cell ops per row
+    (2 P + floor_slots) than the uniform one."""
+    st = synth.Stream(11, 4)
+    for trial in range(40):
+        n = 1 + int(st.below(1, 22)[0])
+        lo = [8, 40, 120, 160, 300][int(st.below(1, 5)[0])]
+        ms = [synth._ACGT[st.below(lo + int(st.below(1, 40)[0]), [4, 2, 3][int(st.below(1, 3)[0])])].tobytes() for _ in range(n)]
+        info = lib.plan_info(ms)
+        if info["family"] != "fast" or info["cells_per_lane"] > 64:
+            continue
+        P = info["cells_per_lane"]
+        assert 2 <= info["min_first_lane_cells"] and info["max_lane_cells"] <= P and 1 <= info["floor_slots"] < max(P, 2), info
+        os.environ["SD_PLAN_UNIFORM_LANES"] = "1"
+        try:
+            uni = lib.plan_info(ms)
+        finally:
+            del os.environ["SD_PLAN_UNIFORM_LANES"]
+        assert 2 * P + info["floor_slots"] <= 2 * uni["cells_per_lane"] + uni["floor_slots"] + 16, (info, uni)
+        assert uni["max_lane_cells"] <= uni["cells_per_lane"]
