@@ -208,6 +208,7 @@ struct sd_engine {
     DevBuf<int32_t> d_nkept;
     DevBuf<int> d_order12, d_cls;
     bool compact_edthr = false;
+    int filter_uniform = -1;         // prefilter: -1 general kernel; 0 / 1 every template ends in the low / high half of the same word
     DevBuf<int> d_queue;             // work-queue heads of the persistent kernels: a fresh zeroed (fill, trace) pair per run
     int q_run = 0;                   // pairs handed out since the array was last zeroed
     static constexpr int QN = 2048;
@@ -446,6 +447,12 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
         e->Lmax = std::max(e->Lmax, (int)e->tlen[j]);
     }
     e->sumL = e->toff[e->T];
+    {
+        const int w0 = (e->tlen[0] - 1) >> 6, h0 = ((e->tlen[0] - 1) >> 5) & 1;
+        bool same = true;
+        for (int j = 1; j < e->T; ++j) same = same && ((e->tlen[j] - 1) >> 6) == w0 && (((e->tlen[j] - 1) >> 5) & 1) == h0;
+        e->filter_uniform = same && w0 == ((e->Lmax + 63) / 64) - 1 ? h0 : -1;
+    }
     rc = check_score_range(*p, e->Lmax, err);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
 
@@ -737,7 +744,7 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                 if (ranked)  // main.cpp:91-93: per-chunk template prefilter -> rank table
                     sd::launch_edthr_filter(st, e->dp_chunks, C, e->T, e->Lmax, e->p.ed_thr, e->dp_bases2, e->dp_nmask,
                                             e->d_peq.p, e->d_tlen.p, nullptr, nullptr, e->d_dist.p, nullptr, nullptr,
-                                            e->d_grank.p);
+                                            e->d_grank.p, 1, nullptr, nullptr, nullptr, e->filter_uniform);
                 for (size_t s = 0; s < e->subs.size(); ++s) {
                     const int b = e->subs[s].first, n_sub = e->subs[s].second - b;
                     const uint64_t row0_base = e->chunks[(size_t)b].row0;
@@ -771,7 +778,8 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                                             e->dp_nmask, e->d_peq.p, e->d_tlen.p, e->d_endvl.p,
                                             e->d_endoff.p, e->d_dist.p, e->d_cendoff.p, e->d_crank.p, nullptr,
                                             e->fplan.waves, compact ? e->d_kpos.p : nullptr,
-                                            compact ? e->d_klist.p : nullptr, compact ? e->d_nkept.p : nullptr);
+                                            compact ? e->d_klist.p : nullptr, compact ? e->d_nkept.p : nullptr,
+                                            e->filter_uniform);
                 SD_HIP(hipEventRecord(e->ev_fill[0], st));
                 if (compact) {
                     // more than 128 templates: the chunks whose kept templates fit one wave are filled by one wave

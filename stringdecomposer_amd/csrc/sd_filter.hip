@@ -98,6 +98,98 @@ __global__ __launch_bounds__(256) void sd_hw_dist(const ChunkDesc* __restrict__ 
     dist[(size_t)c * T + j] = best;
 }
 
+// The common case made cheap: every template occupies the same number of 64-bit words, the end of every template
+// falls into the same 32-bit half of its last word (true for any set of monomers of similar length, e.g. 161..192
+// bp), and all match masks fit LDS.  Then nothing in the word loop depends on the lane but the data: the bit
+// vectors live as 32-bit halves, the three-input boolean steps are single v_bitop3_b32 instructions (truth table
+// over a = 0xF0, b = 0xCC, c = 0xAA), the carries between words are plain 0/1 values, and the masks come straight
+// from LDS -- about 80 VALU instructions per column at three words instead of 136.  Same result as sd_hw_dist.
+template <int W, bool HI>
+__global__ __launch_bounds__(256) void sd_hw_dist_u(const ChunkDesc* __restrict__ chunks, int n_chunks, int T,
+                                                    const uint32_t* __restrict__ bases2,
+                                                    const uint32_t* __restrict__ nmask,
+                                                    const unsigned long long* __restrict__ peq,
+                                                    const int32_t* __restrict__ tlen, int32_t* __restrict__ dist) {
+    // the 256 pairs of a workgroup are consecutive templates (of one or two chunks): only their masks are staged,
+    // min(T, 256) x 5 x W words, whatever the size of the set
+    extern __shared__ unsigned long long speq[];
+    const long long g0 = (long long)blockIdx.x * blockDim.x;
+    const int nl = T < 256 ? T : 256;
+    const int j0 = T < 256 ? 0 : (int)(g0 % T);
+    for (int idx = threadIdx.x; idx < nl * 5 * W; idx += blockDim.x) {
+        const int jl = idx / (5 * W), rem = idx % (5 * W);
+        int j = j0 + jl;
+        if (j >= T) j -= T;
+        speq[idx] = peq[(size_t)j * 40 + (size_t)(rem / W) * 8 + (rem % W)];
+    }
+    __syncthreads();
+    const long long g = g0 + threadIdx.x;
+    if (g >= (long long)n_chunks * T) return;
+    const int c = (int)(g / T), j = (int)(g % T);
+    const ChunkDesc cd = chunks[c];
+    const int m = tlen[j];
+    const uint32_t sh = (uint32_t)((m - 1) & 31);           // end of the template inside its half
+    int jl = j - j0;
+    if (jl < 0) jl += T;
+    const unsigned long long* pq = speq + (size_t)jl * 5 * W;
+    constexpr uint32_t TT_XH = (0xF0 ^ 0xCC) | 0xAA;        // (a ^ b) | c
+    constexpr uint32_t TT_ORN = 0xF0 | (~(0xCC | 0xAA) & 0xFF);   // a | ~(b | c)
+    uint32_t PvL[W], PvH[W], MvL[W], MvH[W];
+#pragma unroll
+    for (int b = 0; b < W; ++b) { PvL[b] = PvH[b] = ~0u; MvL[b] = MvH[b] = 0u; }
+    int score = m, best = m;
+    const uint32_t* w = bases2 + cd.woff;
+    const uint32_t* nm = cd.noff >= 0 ? nmask + cd.noff : nullptr;
+    uint32_t wb = 0, nb = 0;
+    for (int i = 0; i < cd.n; ++i) {
+        if ((i & 15) == 0) wb = w[i >> 4];
+        int r = (wb >> (2 * (i & 15))) & 3;
+        if (nm) {
+            if ((i & 31) == 0) nb = nm[i >> 5];
+            if ((nb >> (i & 31)) & 1) r = 4;
+        }
+        const unsigned long long* eqp = pq + r * W;
+        uint32_t cP = 0, cM = 0;   // horizontal delta entering the word: +1 / -1 (search variant: 0 above the pattern)
+#pragma unroll
+        for (int b = 0; b < W; ++b) {
+            const unsigned long long Eq64 = eqp[b];
+            uint32_t EqL = (uint32_t)Eq64;
+            const uint32_t EqH = (uint32_t)(Eq64 >> 32);
+            const uint32_t pvL = PvL[b], pvH = PvH[b], mvL = MvL[b], mvH = MvH[b];
+            const uint32_t XvL = EqL | mvL, XvH = EqH | mvH;
+            EqL |= cM;
+            const unsigned long long sum = (((unsigned long long)(EqH & pvH) << 32) | (EqL & pvL)) +
+                                           (((unsigned long long)pvH << 32) | pvL);
+            const uint32_t XhL = __builtin_amdgcn_bitop3_b32((uint32_t)sum, pvL, EqL, TT_XH);
+            const uint32_t XhH = __builtin_amdgcn_bitop3_b32((uint32_t)(sum >> 32), pvH, EqH, TT_XH);
+            uint32_t PhL = __builtin_amdgcn_bitop3_b32(mvL, XhL, pvL, TT_ORN);
+            uint32_t PhH = __builtin_amdgcn_bitop3_b32(mvH, XhH, pvH, TT_ORN);
+            uint32_t MhL = pvL & XhL, MhH = pvH & XhH;
+            uint32_t oP, oM;   // horizontal delta leaving the word (of the template's last row in the last word)
+            if (b == W - 1) {
+                oP = ((HI ? PhH : PhL) >> sh) & 1u;
+                oM = ((HI ? MhH : MhL) >> sh) & 1u;
+            } else {
+                oP = PhH >> 31;
+                oM = MhH >> 31;
+            }
+            PhH = __builtin_amdgcn_alignbit(PhH, PhL, 31);
+            MhH = __builtin_amdgcn_alignbit(MhH, MhL, 31);
+            PhL = (PhL << 1) | cP;
+            MhL = (MhL << 1) | cM;
+            PvL[b] = __builtin_amdgcn_bitop3_b32(MhL, XvL, PhL, TT_ORN);
+            PvH[b] = __builtin_amdgcn_bitop3_b32(MhH, XvH, PhH, TT_ORN);
+            MvL[b] = PhL & XvL;
+            MvH[b] = PhH & XvH;
+            cP = oP;
+            cM = oM;
+        }
+        score += (int)cP - (int)cM;  // vertical delta of the pattern's last row
+        best = min(best, score);
+    }
+    dist[(size_t)c * T + j] = best;
+}
+
 // Kept set and order of a chunk (main.cpp:141-147): first = smallest (distance, index); kept = first or
 // distance <= ed_thr; rank = position in the (distance, index) order among the kept.  Written as the
 // per-chunk lane constants of the ranked fast fills (end offsets / ranks, [chunk][wave][64 lanes] dwords, packed
@@ -190,7 +282,7 @@ void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, 
                          const uint32_t* bases2, const uint32_t* nmask, const unsigned long long* peq,
                          const int32_t* tlen, const int32_t* end_vlane, const int32_t* end_off,
                          int32_t* dist, uint32_t* cendoff, uint32_t* crank, uint16_t* grank, int waves,
-                         uint16_t* kpos, uint16_t* klist, int32_t* nkept) {
+                         uint16_t* kpos, uint16_t* klist, int32_t* nkept, int uniform_half) {
     const long long total = (long long)n_chunks * T;
     const int grid = (int)((total + 255) / 256);
     if (!grank) {
@@ -211,7 +303,22 @@ void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, 
         hipLaunchKernelGGL(sd_hw_dist<WW>, dim3(grid), dim3(256), (size_t)lt * 5 * WW * sizeof(unsigned long long), st, \
                            chunks, n_chunks, T, bases2, nmask, peq, tlen, dist, lt);                           \
     }
+    // uniform variant (sd_hw_dist_u): same word count and same half of the last word for every template, masks in LDS
+    bool done = false;
+    if (uniform_half >= 0 && W >= 1 && W <= 4 && !getenv("SD_FILTER_GENERAL")) {
+        const size_t lds = (size_t)std::min(T, 256) * 5 * W * sizeof(unsigned long long);   // <= 40 KB
+#define SD_HWU(WW)                                                                                             \
+        {                                                                                                      \
+            if (uniform_half) hipLaunchKernelGGL((sd_hw_dist_u<WW, true>), dim3(grid), dim3(256), lds, st, chunks, n_chunks, T, bases2, nmask, peq, tlen, dist); \
+            else hipLaunchKernelGGL((sd_hw_dist_u<WW, false>), dim3(grid), dim3(256), lds, st, chunks, n_chunks, T, bases2, nmask, peq, tlen, dist); \
+            done = true;                                                                                       \
+        }
+        if (W == 1) SD_HWU(1) else if (W == 2) SD_HWU(2) else if (W == 3) SD_HWU(3) else SD_HWU(4)
+#undef SD_HWU
+    }
+    if (!done) {
     if (W <= 1) SD_HW(1) else if (W == 2) SD_HW(2) else if (W == 3) SD_HW(3) else if (W == 4) SD_HW(4) else SD_HW(8)
+    }
 #undef SD_HW
     hipLaunchKernelGGL(sd_rank_keep, dim3(grid), dim3(256), 0, st, n_chunks, T, ed_thr, dist, end_vlane, end_off,
                        reinterpret_cast<uint16_t*>(cendoff), reinterpret_cast<uint16_t*>(crank), grank, waves, kpos, klist,
