@@ -2004,6 +2004,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     std::string sink_err;
     double t_fmt = 0, t_post = 0, t_io = 0;
     auto sink_loop = [&]() {
+        sd::HostPool::lane() = 1;   // this thread's parallel loops run on the second pool, beside the driver's
         sd::TextBuf raw, fin, alt;
         std::vector<sd::PostRead> preads;
         for (;;) {

@@ -203,9 +203,13 @@ inline void format_rows(std::string& o, const char* read_name, size_t read_name_
 // time (a second caller waits its turn); a loop started from inside a pool worker runs serially.
 class HostPool {
   public:
+    // Two pools: a loop runs on the pool of the calling thread's lane.  Lane 1 is the sink thread of sd_run_files
+    // (text + post-processing of batch b), lane 0 everything else (the driver packing batch b+1): with one pool
+    // the two took turns -- "one loop at a time" -- and each waited for the other's loops.
+    static int& lane() { static thread_local int l = 0; return l; }
     static HostPool& get() {
-        static HostPool* p = new HostPool;  // never destroyed: workers may outlive static destructors
-        return *p;
+        static HostPool* p[2] = {new HostPool, new HostPool};  // never destroyed: workers may outlive static destructors
+        return *p[lane() & 1];
     }
     // runs `work()` on the calling thread and on up to helpers pool threads; returns when all are back
     template <class F>
