@@ -103,12 +103,16 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
         const int b = wave_max(max(lo, hi));
         unsigned long long mlo, mhi;
         if (RANKED) {
-            // ties go to the first template of the chunk's filtered order (main.cpp:141-147)
-            const int klo = lo == b ? (int)(rank2 & 0xffffu) : 0x7fff;
-            const int khi = hi == b ? (int)(rank2 >> 16) : 0x7fff;
-            const int kmin = -wave_max(-min(klo, khi));
-            mlo = __ballot(klo == kmin);
-            mhi = __ballot(khi == kmin);
+            mlo = __ballot(lo == b);
+            mhi = __ballot(hi == b);
+            if (__popcll(mlo) + __popcll(mhi) > 1) {   // wave-uniform, the rarer case: several ends tie
+                // ties go to the first template of the chunk's filtered order (main.cpp:141-147)
+                const int klo = lo == b ? (int)(rank2 & 0xffffu) : 0x7fff;
+                const int khi = hi == b ? (int)(rank2 >> 16) : 0x7fff;
+                const int kmin = -wave_max(-min(klo, khi));
+                mlo = __ballot(klo == kmin);
+                mhi = __ballot(khi == kmin);
+            }
         } else {
             mlo = __ballot(lo == b);
             mhi = __ballot(hi == b);
