@@ -9,7 +9,7 @@ O=$R/gpurun_out/$V
 mkdir -p $O
 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err
 tail -c 300 $O/bench_c2.json
-python bench.py --monomers 64 --reads 256 --steps 5 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
+python bench.py --monomers 64 --reads 256 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
 python bench.py --ed-thr 20 --steps 5 --no-cpu-baseline > $O/bench_c2_edthr20.json 2> $O/bench_c2_edthr20.err
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c2 -o c2 -- python3 $R/bench.py --no-cpu-baseline --timed-only > $O/stats_c2.log 2>&1)
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4 -o c4 -- python3 $R/bench.py --monomers 64 --reads 256 --steps 5 --no-cpu-baseline --timed-only > $O/stats_c4.log 2>&1)
