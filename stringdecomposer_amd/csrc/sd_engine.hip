@@ -202,6 +202,7 @@ struct sd_engine {
     DevBuf<unsigned long long> d_peq;
     DevBuf<int32_t> d_endvl, d_endoff, d_dist;
     DevBuf<uint32_t> d_cendoff, d_crank;
+    DevBuf<int32_t> d_vlane0;        // --ed_thr, fast family: first virtual lane of each template
     // --ed_thr with more than 128 templates (compacted fill, sd_fast_wn_ck.hip): per chunk the kept templates in
     // filtered order [128], every template's place [T], the kept count; the two chunk classes and their sizes
     DevBuf<uint16_t> d_klist, d_kpos;
@@ -509,6 +510,7 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
             if (p->ed_thr > -1) {
                 e->d_endvl.upload(e->fplan.end_vlane);
                 e->d_endoff.upload(e->fplan.end_off);
+                e->d_vlane0.upload(e->fplan.vlane0);
             }
         }
         if (p->ed_thr > -1) {
@@ -779,7 +781,7 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                                             e->d_endoff.p, e->d_dist.p, e->d_cendoff.p, e->d_crank.p, nullptr,
                                             e->fplan.waves, compact ? e->d_kpos.p : nullptr,
                                             compact ? e->d_klist.p : nullptr, compact ? e->d_nkept.p : nullptr,
-                                            e->filter_uniform);
+                                            e->filter_uniform, e->d_vlane0.p);
                 SD_HIP(hipEventRecord(e->ev_fill[0], st));
                 if (compact) {
                     // more than 128 templates: the chunks whose kept templates fit one wave are filled by one wave

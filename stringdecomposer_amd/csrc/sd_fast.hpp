@@ -78,8 +78,9 @@ void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, 
                          const int32_t* tlen, const int32_t* end_vlane, const int32_t* end_off,
                          int32_t* dist, uint32_t* cendoff, uint32_t* crank, uint16_t* grank, int waves = 1,
                          uint16_t* kpos = nullptr, uint16_t* klist = nullptr, int32_t* nkept = nullptr,
-                         int uniform_half = -1);   // 0 / 1: every template ends in the low / high half of word ceil(L/64)-1
+                         int uniform_half = -1,    // 0 / 1: every template ends in the low / high half of word ceil(L/64)-1
                                                    // and all have that many words (sd_hw_dist_u); -1: general kernel
+                         const int32_t* vlane0 = nullptr);   // first virtual lane of each template (narrow layout)
 // --ed_thr with more than 128 templates: chunks whose kept templates fit one wave (order1) / the rest (order2)
 void launch_split_order(hipStream_t st, const int* order, int n, const int32_t* nkept, int* order1, int* order2,
                         int* counts);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     // --ed_thr: per-chunk end offsets (-inf for dropped templates) and tie-break ranks
     // fp16, unranked: the whole B reduction stays in fp16 (no per-row int conversions); `del` is folded
     // into the end offsets so that the wave maximum is directly the start term B_i + del of the next row
-    constexpr bool HRED = F16 && !RANKED;
+    constexpr bool HRED = F16;   // (ranked too: sd_rank_keep writes the per-chunk end offsets on every lane of a template)
     // HRED row tail.  With a_l = max(last slot, K_l) the total of virtual lane l:
     //   * the end cell of a template is the maximum of a_l over ALL its lanes (prefix maximum along the
     //     template), so the B reduction takes every lane's total with its template's end offset
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     //     KB = max(K, B+del) >= K: slot 0's u is KB itself;
     //   * totals never decrease from row to row in the stored domain (the insertion move is "keep"),
     //     so the new carry replaces the old one without a max.
-    const uint32_t endOff = HRED ? CO::from_i16x2(pk_adds(lc[FLC_ENDALL], pack2(sc.del)))
+    const uint32_t endOff = HRED ? CO::from_i16x2(pk_adds(RANKED ? cendoff[(size_t)c * 64 + lane] : lc[FLC_ENDALL], pack2(sc.del)))
                                  : CO::from_i16x2(RANKED ? cendoff[(size_t)c * 64 + lane] : endOffPlan);
     const uint32_t rank2 = RANKED ? crank[(size_t)c * 64 + lane] : 0u;
     const uint32_t row0adj = CO::from_i16x2(lc[FLC_ROW0]);
@@ -149,6 +149,16 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
             unsigned long long mlo, mhi;
             asm("v_cmp_eq_f16_e64 %0, %1, %2" : "=s"(mlo) : "v"(val), "s"(b16));
             asm("v_cmp_eq_f16_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:WORD_0" : "=s"(mhi) : "v"(val), "s"(b16));
+            if constexpr (RANKED) {
+                if (__popcll(mlo) + __popcll(mhi) > 1) {   // wave-uniform: several lanes tie (often lanes of one template)
+                    // ties go to the first template of the chunk's filtered order (main.cpp:141-147)
+                    const int klo = ((mlo >> lane) & 1ull) ? (int)(rank2 & 0xffffu) : 0x7fff;
+                    const int khi = ((mhi >> lane) & 1ull) ? (int)(rank2 >> 16) : 0x7fff;
+                    const int kmin = -wave_max(-min(klo, khi));
+                    mlo = __ballot(klo == kmin);
+                    mhi = __ballot(khi == kmin);
+                }
+            }
             const int vlo = __ffsll((long long)mlo) - 1, vhi = 63 + __ffsll((long long)mhi);  // both scalar
             const int v = vlo >= 0 ? vlo : vhi;
             bdel16 = b16;

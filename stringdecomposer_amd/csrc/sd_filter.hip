@@ -198,7 +198,8 @@ __global__ void sd_rank_keep(int n_chunks, int T, int ed_thr, const int32_t* __r
                              const int32_t* __restrict__ end_vlane, const int32_t* __restrict__ end_off,
                              uint16_t* __restrict__ cendoff, uint16_t* __restrict__ crank,
                              uint16_t* __restrict__ grank, int W, uint16_t* __restrict__ kpos,
-                             uint16_t* __restrict__ klist, int32_t* __restrict__ nkept) {
+                             uint16_t* __restrict__ klist, int32_t* __restrict__ nkept,
+                             const int32_t* __restrict__ vlane0) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long long)n_chunks * T) return;
     const int c = (int)(g / T), j = (int)(g % T);
@@ -225,10 +226,14 @@ __global__ void sd_rank_keep(int n_chunks, int T, int ed_thr, const int32_t* __r
         grank[(size_t)c * T + j] = (uint16_t)(kept ? rank : 0xffff);
         return;
     }
-    const int v = end_vlane[j];  // virtual lane holding the template's end: (wave << 7) | (plane << 6) | lane
-    const size_t at = (((size_t)c * W + (size_t)(v >> 7)) * 64 + (v & 63)) * 2 + ((v >> 6) & 1);
-    cendoff[at] = (uint16_t)(kept ? end_off[j] : -32768);
-    crank[at] = (uint16_t)(kept ? rank : 0x7fff);
+    // every virtual lane of the template ((wave << 7) | (plane << 6) | lane; the lanes of a template are consecutive
+    // in one plane): the fp16 fills reduce the totals of all lanes (the maximum over a template's lanes is its end)
+    const int v1 = end_vlane[j], v0 = vlane0 ? vlane0[j] : v1;
+    for (int v = v0; v <= v1; ++v) {
+        const size_t at = (((size_t)c * W + (size_t)(v >> 7)) * 64 + (v & 63)) * 2 + ((v >> 6) & 1);
+        cendoff[at] = (uint16_t)(kept ? end_off[j] : -32768);
+        crank[at] = (uint16_t)(kept ? rank : 0x7fff);
+    }
 }
 
 __global__ void sd_fill_u32(uint32_t* p, size_t n, uint32_t v) {
@@ -282,7 +287,7 @@ void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, 
                          const uint32_t* bases2, const uint32_t* nmask, const unsigned long long* peq,
                          const int32_t* tlen, const int32_t* end_vlane, const int32_t* end_off,
                          int32_t* dist, uint32_t* cendoff, uint32_t* crank, uint16_t* grank, int waves,
-                         uint16_t* kpos, uint16_t* klist, int32_t* nkept, int uniform_half) {
+                         uint16_t* kpos, uint16_t* klist, int32_t* nkept, int uniform_half, const int32_t* vlane0) {
     const long long total = (long long)n_chunks * T;
     const int grid = (int)((total + 255) / 256);
     if (!grank) {
@@ -322,7 +327,7 @@ void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, 
 #undef SD_HW
     hipLaunchKernelGGL(sd_rank_keep, dim3(grid), dim3(256), 0, st, n_chunks, T, ed_thr, dist, end_vlane, end_off,
                        reinterpret_cast<uint16_t*>(cendoff), reinterpret_cast<uint16_t*>(crank), grank, waves, kpos, klist,
-                       nkept);
+                       nkept, vlane0);
 }
 
 }  // namespace sd
