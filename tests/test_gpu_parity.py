@@ -652,6 +652,38 @@ def test_fill_without_dominated_start_maxima(oracle, name):
         assert uni == exp
 
 
+def test_plan_choices_do_not_change_rows():
+    """Lane boundaries moved by the plan, the slot count it picks among three, and the kernels that leave out
+    dominated start-term maxima are pure optimisations: on random template sets (2-23 monomers of 100-200 bp, with
+    N, homopolymer runs and late bases) the rows equal those of the plain layout with the full kernels."""
+    st = synth.Stream(21, 8)
+    for trial in range(14):
+        n = 2 + int(st.below(1, 22)[0])
+        ms = []
+        for j in range(n):
+            L = 100 + int(st.below(1, 101)[0])
+            alpha = [b"ACGT", b"ACGT", b"AT", b"ACT"][int(st.below(1, 4)[0])]
+            m = bytearray(bytes(alpha[int(x)] for x in st.below(L, len(alpha))))
+            if int(st.below(1, 4)[0]) == 0:
+                k = int(st.below(1, L - 30)[0])
+                m[k:k + 20] = bytes([m[k]]) * 20
+            if int(st.below(1, 6)[0]) == 0:
+                m[int(st.below(1, L)[0])] = ord("N")
+            ms.append(bytes(m))
+        mn = ["m%d" % j for j in range(n)]
+        rn, rs = synth.make_reads(ms, 2, read_len=4000, seed=100 + trial)
+        ed = -1 if trial % 3 else 35
+        got = lib.decompose(rn, rs, mn, ms, ed_thr=ed)
+        os.environ["SD_FILL_FULLFLOOR"] = "1"
+        os.environ["SD_PLAN_UNIFORM_LANES"] = "1"
+        try:
+            plain = lib.decompose(rn, rs, mn, ms, ed_thr=ed)
+        finally:
+            del os.environ["SD_FILL_FULLFLOOR"]
+            del os.environ["SD_PLAN_UNIFORM_LANES"]
+        assert got == plain, (trial, n, ed)
+
+
 @pytest.mark.parametrize("thr", [0, 25, 48, 60, 200])
 def test_ed_thr_compacts_large_template_sets(oracle, thr):
     """--ed_thr with more than 128 templates (csrc/sd_fast_wn_ck.hip): a chunk whose kept templates number at
