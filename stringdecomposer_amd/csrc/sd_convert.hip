@@ -73,18 +73,21 @@ int PostProcessor::tmpl_of_name(const std::string& nm) const {
 // identities (percent, main.py:38-60) of n_seg segments against `tmpl` (all-vs-all, out[s * T + t]) or against
 // tmpl[pair[s]] only (out[s])
 int PostProcessor::identities(const std::vector<std::pair<const char*, int64_t>>& spans, const std::vector<int64_t>& seg_start,
-                              const std::vector<int32_t>& seg_len, const int32_t* pair, bool homo, std::vector<double>& out,
+                              const std::vector<int32_t>& seg_len, const int32_t* pair, bool homo, RawVec<double>& out,
                               std::string& err) {
     const int64_t n_seg = (int64_t)seg_start.size();
     const int T = (int)il_seq.size();
     const int64_t n_pairs = pair ? n_seg : n_seg * T;
-    std::vector<int32_t> d((size_t)n_pairs), m((size_t)n_pairs);
+    // (14 M pairs per 50 Mbp with --second-best: vectors that zero-fill cost 40 ms of one thread per call)
+    RawVec<int32_t> d, m;
+    d.resize((size_t)n_pairs);
+    m.resize((size_t)n_pairs);
     int rc = SD_ERR_UNSUPPORTED;
     if (device >= 0) {
         rc = nw_identity_device(spans, seg_start.data(), seg_len.data(), n_seg, il_seq, pair, homo, device, threads, d.data(), m.data());
         if (rc != SD_OK && rc != SD_ERR_UNSUPPORTED) { err = "identity kernel failed (rc " + std::to_string(rc) + ")"; return rc; }
     }
-    std::vector<int32_t> c;
+    RawVec<int32_t> c;
     if (rc == SD_ERR_UNSUPPORTED) {  // host implementation on the concatenated text
         std::string text;
         for (const auto& sp : spans) text.append(sp.first, (size_t)sp.second);
@@ -151,7 +154,7 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
         }
     }
     const double t_a = now_seconds();
-    std::vector<double> vals, hvals;
+    RawVec<double> vals, hvals;
     int rc;
     if (!second_best) {
         std::vector<int32_t> pair((size_t)nB);

@@ -124,6 +124,7 @@ struct NoInitAlloc : std::allocator<T> {
     }
 };
 using TextBuf = std::vector<char, NoInitAlloc<char>>;
+template <class T> using RawVec = std::vector<T, NoInitAlloc<T>>;   // resize() leaves the new elements unwritten
 
 // decimal text of an int, appended (std::to_string(int), main.cpp:277-281)
 inline void put_int(std::string& o, int64_t v) {
