@@ -313,7 +313,7 @@ int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans
         for (uint8_t b : bad)
             if (b) return SD_ERR_UNSUPPORTED;
     }
-    // resident lanes: up to 32 waves per CU, within a history budget of 8 GB (and a third of the free HBM)
+    // resident lanes: up to 16 waves per CU, within a history budget of 8 GB (and a third of the free HBM)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SD_ERR_HIP;
     const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -321,7 +321,10 @@ int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return SD_ERR_HIP;
     size_t budget = std::min<size_t>((size_t)8 << 30, (free_b + g_nw.hist.cap) / 3);
-    int64_t lanes = std::min<int64_t>((int64_t)n_cu * 8 * 256, (int64_t)((n_pairs + 255) / 256 * 256));
+    // 16 waves per CU: the kernel is HBM-bound and measured the same from 8 to 32 waves per CU (137-146 M pairs/s),
+    // and the history of the resident lanes is what this call allocates (SD_NW_BLOCKS_PER_CU: developer knob)
+    const char* lpc = getenv("SD_NW_BLOCKS_PER_CU");
+    int64_t lanes = std::min<int64_t>((int64_t)n_cu * (lpc ? std::max(1, atoi(lpc)) : 4) * 256, (int64_t)((n_pairs + 255) / 256 * 256));
     lanes = std::min<int64_t>(lanes, (int64_t)(budget / per_lane) / 256 * 256);
     if (lanes < 256) lanes = 256;
     const int grid = (int)(lanes / 256);
