@@ -213,6 +213,7 @@ struct sd_engine {
     DevBuf<int> d_queue;             // work-queue heads of the persistent kernels: a fresh zeroed (fill, trace) pair per run
     int q_run = 0;                   // pairs handed out since the array was last zeroed
     static constexpr int QN = 2048;
+    static constexpr int QS = 16;    // queue heads per run: fill, traceback, then one per further fill class (--ed_thr)
     int n_cu = 256;
 
     // batch
@@ -477,8 +478,8 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
             hipDeviceProp_t prop;
             SD_HIP(hipGetDeviceProperties(&prop, p->device));
             e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            e->d_queue.alloc(4 * (size_t)sd_engine::QN);
-            SD_HIP(hipMemset(e->d_queue.p, 0, sizeof(int) * 4 * (size_t)sd_engine::QN));
+            e->d_queue.alloc(sd_engine::QS * (size_t)sd_engine::QN);
+            SD_HIP(hipMemset(e->d_queue.p, 0, sizeof(int) * sd_engine::QS * (size_t)sd_engine::QN));
         }
         // kernel family
         int family = p->kernel;
@@ -673,11 +674,11 @@ static int load_chunks_impl(sd_engine* e, const std::vector<const char*>& cptr,
                 const char* ck = getenv("SD_EDTHR_COMPACT");   // "0": every chunk on the W-wave ranked kernel (A/B, tests)
                 e->compact_edthr = e->fplan.wide && e->fplan.waves > 1 && !(ck && ck[0] == '0');
                 if (e->compact_edthr) {
-                    e->d_klist.alloc(C * 128);
+                    e->d_klist.alloc(C * (size_t)e->T + 2);
                     e->d_kpos.alloc(C * (size_t)e->T);
                     e->d_nkept.alloc(C);
-                    e->d_order12.alloc(2 * C);
-                    e->d_cls.alloc(2);
+                    e->d_order12.alloc((size_t)e->fplan.waves * C);
+                    e->d_cls.alloc(8);
                 }
             }
             e->d_fckpt.alloc((size_t)nck * (size_t)e->fplan.P * 64 * (size_t)e->fplan.waves);
@@ -767,12 +768,11 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
             } else {
                 const bool ranked = e->p.ed_thr > -1;
                 if (e->q_run == sd_engine::QN) {  // every queue head used once: zero them again (no kernel of this
-                    SD_HIP(hipMemsetAsync(e->d_queue.p, 0, sizeof(int) * 4 * (size_t)sd_engine::QN, st));  // engine is running)
+                    SD_HIP(hipMemsetAsync(e->d_queue.p, 0, sizeof(int) * sd_engine::QS * (size_t)sd_engine::QN, st));  // engine is running)
                     e->q_run = 0;
                 }
-                int* qfill = e->d_queue.p + 4 * e->q_run;   // heads of this run: fill, traceback, second fill class
+                int* qfill = e->d_queue.p + sd_engine::QS * e->q_run;   // heads of this run: fill, traceback, fill classes 2..8
                 int* qtrace = qfill + 1;
-                int* qfill2 = qfill + 2;
                 ++e->q_run;
                 const bool compact = ranked && e->compact_edthr;
                 if (ranked)  // main.cpp:91-93: per-chunk template prefilter
@@ -787,16 +787,19 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                     // more than 128 templates: the chunks whose kept templates fit one wave are filled by one wave
                     // holding exactly those (the point of the reference's prefilter, main.cpp:128-149: less DP
                     // work); the others by the W-wave ranked kernel.  The class sizes stay on the device.
-                    int* o1 = e->d_order12.p;
-                    int* o2 = o1 + C;
-                    sd::launch_split_order(st, e->dp_order, C, e->d_nkept.p, o1, o2, e->d_cls.p);
-                    sd::launch_fast_fill_wn_compact(e->fplan, st, e->dp_chunks, e->dp_bases2, e->dp_nmask, e->d_flane.p,
-                                                    e->sc, e->d_B.p, e->d_fckpt.p, e->d_fckbase.p, qfill, o1,
-                                                    e->d_cls.p, e->n_cu, e->d_klist.p, e->d_ftcodes.p, e->d_toff.p,
-                                                    e->d_tlen.p);
+                    const int W = e->fplan.waves;
+                    int* ord = e->d_order12.p;   // [W][C]: class w-1 = the chunks whose kept templates need w waves
+                    sd::launch_split_order(st, e->dp_order, C, e->d_nkept.p, ord, e->d_cls.p, W);
+                    for (int w = 1; w < W; ++w)
+                        sd::launch_fast_fill_wn_compact(e->fplan, st, e->dp_chunks, e->dp_bases2, e->dp_nmask, e->d_flane.p,
+                                                        e->sc, e->d_B.p, e->d_fckpt.p, e->d_fckbase.p,
+                                                        w == 1 ? qfill : qfill + 1 + w, ord + (size_t)(w - 1) * C,
+                                                        e->d_cls.p + (w - 1), e->n_cu, e->d_klist.p, e->d_ftcodes.p,
+                                                        e->d_toff.p, e->d_tlen.p, w);
                     sd::launch_fast_fill_wn(e->fplan, st, e->dp_chunks, C, e->dp_bases2, e->dp_nmask, e->d_ftable.p,
-                                            e->d_flane.p, e->sc, e->d_B.p, e->d_fckpt.p, e->d_fckbase.p, qfill2, o2,
-                                            e->n_cu, e->d_cendoff.p, e->d_crank.p, e->d_cls.p + 1);
+                                            e->d_flane.p, e->sc, e->d_B.p, e->d_fckpt.p, e->d_fckbase.p, qfill + 2,
+                                            ord + (size_t)(W - 1) * C, e->n_cu, e->d_cendoff.p, e->d_crank.p,
+                                            e->d_cls.p + (W - 1));
                 } else
                 sd::launch_fast_fill(e->fplan, st, e->dp_chunks, C, e->dp_bases2, e->dp_nmask,
                                      e->d_ftable.p, e->d_flane.p, e->sc, e->d_B.p, e->d_argB.p,

@@ -75,12 +75,12 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
     const int mD = sc.match - sc.del, xD = sc.mismatch - sc.del;
 
     // --ed_thr with more than 128 templates: a chunk filled in the compacted form (sd_fast_wn_ck.hip) has its kept
-    // templates, in their filtered order, in the virtual lanes of wave 0
-    const bool cmp = klist != nullptr && nkept[c] <= 128;
-    const uint16_t* klc = cmp ? klist + (size_t)c * 128 : nullptr;
+    // templates, in their filtered order, in the virtual lanes of its first ceil(kept / 128) waves
+    const bool cmp = klist != nullptr && nkept[c] <= 128 * (W - 1);
+    const uint16_t* klc = cmp ? klist + (size_t)c * (size_t)T : nullptr;
     const uint16_t* kpc = cmp ? kpos + (size_t)c * (size_t)T : nullptr;
     auto tmpl_of = [&](int v) {
-        if (cmp) return (int)klc[v & 127];
+        if (cmp) return (int)klc[v];   // v = (wave << 7) | virtual lane = the place in the filtered order
         const uint32_t t = lane_consts[(((v >> 7) << 6) | (v & 63)) * FAST_LANE_WORDS + FLC_TMPL];
         return (int)(((v >> 6) & 1) ? (t >> 16) : (t & 0xffffu));
     };
@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
             for (int q = 0; q < QQ; ++q) {
                 const int kk = lane * QQ + q;
                 cl.code[q] = kk < Lj ? (int)tcodes[x0 + kk] : 7;
-                cl.slot[q] = kk < Lj ? (cmp ? ((kk << 7) | (int)kpc[j]) : (int)slot_of[x0 + kk]) : 0;
+                cl.slot[q] = kk < Lj ? (cmp ? ((((int)kpc[j] >> 7) << 16) | (kk << 7) | ((int)kpc[j] & 127))
+                                                 : (int)slot_of[x0 + kk]) : 0;
 #pragma unroll
                 for (int b = 0; b < 5; ++b) mt[b][lane][q] = (int16_t)(4 * ((cl.code[q] == b ? mD : xD) - ins) - 1);
             }

@@ -81,9 +81,9 @@ void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, 
                          int uniform_half = -1,    // 0 / 1: every template ends in the low / high half of word ceil(L/64)-1
                                                    // and all have that many words (sd_hw_dist_u); -1: general kernel
                          const int32_t* vlane0 = nullptr);   // first virtual lane of each template (narrow layout)
-// --ed_thr with more than 128 templates: chunks whose kept templates fit one wave (order1) / the rest (order2)
-void launch_split_order(hipStream_t st, const int* order, int n, const int32_t* nkept, int* order1, int* order2,
-                        int* counts);
+// --ed_thr with more than 128 templates: the chunk order split into W classes by ceil(kept templates / 128)
+void launch_split_order(hipStream_t st, const int* order, int n, const int32_t* nkept, int* orders, int* counts,
+                        int W);   // orders: [W][n] -- class w-1 = the chunks that need w waves, in the given order
 
 // number of checkpoint rows of the batch; fills ChunkDesc::pad with each chunk's first checkpoint
 int64_t fast_ckpt_rows_total(const FastPlan& plan, std::vector<ChunkDesc>& chunks);
@@ -133,9 +133,9 @@ void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* 
 // --ed_thr, more than 128 templates: the chunks whose kept templates fit one wave (sd_fast_wn_ck.hip)
 void launch_fast_fill_wn_compact(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, const uint32_t* bases2,
                                  const uint32_t* nmask, const uint32_t* lane_consts, ScoreArgs sc, int32_t* B,
-                                 uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order1, const int* n_ptr,
+                                 uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order_w, const int* n_ptr,
                                  int n_cu, const uint16_t* klist, const uint8_t* tcodes, const int32_t* toff,
-                                 const int32_t* tlen);
+                                 const int32_t* tlen, int wb);   // wb: waves per chunk of this class
 
 bool launch_fast_fill_wn_fl(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks,
                             int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,

@@ -41,7 +41,7 @@ void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
         hipLaunchKernelGGL((sd_fast_fill_wn<PP, RK>), dim3(grid), dim3(W * 64), lds, st, chunks, n_chunks, bases2, \
                            nmask, table, lane_consts, sc, W, plan.bf8_match, plan.bf8_mismatch, B, ckpt, ckbase,  \
-                           queue, order, cendoff, crank, n_ptr, nullptr, nullptr, nullptr, nullptr);             \
+                           queue, order, cendoff, crank, n_ptr, nullptr, nullptr, nullptr, nullptr, 0);             \
     }
 #define SD_FILLWN(PP)                                                   \
     case PP:                                                            \

@@ -21,12 +21,14 @@ __device__ __forceinline__ uint32_t cvt_bf8_pair(uint32_t tb, int pair, uint32_t
 }
 }  // namespace
 
-// COMPACT (--ed_thr with more than 128 templates, sd_fast_wn_ck.hip): ONE wave per chunk, whose 128 virtual lanes
-// hold the chunk's kept templates in their filtered order (klist, written by sd_rank_keep) -- the reference's
+// COMPACT (--ed_thr with more than 128 templates, sd_fast_wn_ck.hip): a chunk is filled by as many waves as its
+// KEPT templates need (blockDim.x / 64 = ceil(kept / 128), chosen per chunk class by the launcher), whose virtual
+// lanes hold the kept templates in their filtered order (klist, written by sd_rank_keep) -- the reference's
 // prefilter exists to cut the DP work of large monomer sets (main.cpp:128-149), and here it turns a chunk of W
-// waves into a chunk of one.  The wave gathers the codes of its templates into LDS when it takes the chunk;
-// lane order = filtered order, so "smallest virtual lane among equal ends" is already the reference's tie-break
-// and the unranked reduction applies.  Same B words and checkpoints (wave 0 of the W-wave layout).
+// waves into a chunk of one, two, ...  The waves gather the codes of their templates into LDS when they take the
+// chunk; (wave, lane) order = filtered order, so "smallest wave, then smallest virtual lane among equal ends" is
+// already the reference's tie-break and the unranked reduction applies.  Same B words and checkpoint layout (the
+// first waves of the W-wave layout).
 template <int P, bool RANKED, int FL = P, bool COMPACT = false>
 __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
@@ -35,13 +37,15 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     int32_t* __restrict__ Bout, uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase,
     int* __restrict__ queue, const int* __restrict__ order, const uint32_t* __restrict__ cendoff,
     const uint32_t* __restrict__ crank, const int* __restrict__ n_ptr, const uint16_t* __restrict__ klist,
-    const uint8_t* __restrict__ tcodes, const int32_t* __restrict__ toff, const int32_t* __restrict__ tlen) {
+    const uint8_t* __restrict__ tcodes, const int32_t* __restrict__ toff, const int32_t* __restrict__ tlen,
+    int klist_stride) {
     static_assert(P % 16 == 0, "the code table is streamed 16 slots at a time");
     static_assert(!(COMPACT && RANKED), "the compacted form needs no ranks");
     constexpr int G = P / 16;
     extern __shared__ uint32_t lds[];  // [W][G][2 halves][64 lanes][4 dwords] codes, then the exchange area
     if (n_ptr) n_chunks = *n_ptr;      // the size of a chunk class is known on the device only
-    const int TBL = (COMPACT ? 1 : W) * G * 512;
+    const int Wb = COMPACT ? (int)(blockDim.x >> 6) : W;   // waves of this workgroup; W stays the checkpoint stride
+    const int TBL = Wb * G * 512;
     if constexpr (!COMPACT)
     for (int idx = threadIdx.x * 4; idx < TBL; idx += blockDim.x * 4)
         *reinterpret_cast<uint4*>(&lds[idx]) = *reinterpret_cast<const uint4*>(&codes[idx]);
@@ -61,21 +65,13 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     const uint32_t ins2 = CO::splat(sc.ins);
 
     for (;;) {
-        int c;
-        if constexpr (COMPACT) {
-            int q = 0;
-            if (lane == 0) q = atomicAdd(queue, 1);
-            q = __builtin_amdgcn_readfirstlane(q);
-            c = q < n_chunks ? __builtin_amdgcn_readfirstlane(order[q]) : -1;
-        } else {
-            if (threadIdx.x == 0) {
-                const int q = atomicAdd(queue, 1);
-                xc[0] = q < n_chunks ? order[q] : -1;
-            }
-            __syncthreads();
-            c = __builtin_amdgcn_readfirstlane(xc[0]);
-            __syncthreads();
+        if (threadIdx.x == 0) {
+            const int q = atomicAdd(queue, 1);
+            xc[0] = q < n_chunks ? order[q] : -1;
         }
+        __syncthreads();
+        const int c = __builtin_amdgcn_readfirstlane(xc[0]);
+        __syncthreads();
         if (c < 0) break;
         const ChunkDesc cd = chunks[c];
         const int n = cd.n;
@@ -85,9 +81,12 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
         const size_t cl = ((size_t)c * (size_t)W + (size_t)wave) * 64 + (size_t)lane;
         uint32_t endOffC = 0;
         if constexpr (COMPACT) {
-            // this lane's two templates (lo plane: place `lane` of the filtered order, hi plane: place 64 + lane)
-            const uint16_t* kl = klist + (size_t)c * 128;
-            const int tlo = kl[lane], thi = kl[64 + lane];
+            // this lane's two templates (lo plane: place 128 wave + lane of the filtered order, hi plane: + 64);
+            // klist: [chunk][T], 0xffff behind the kept ones
+            const int T = klist_stride;
+            const uint16_t* kl = klist + (size_t)c * (size_t)T;
+            const int plo = 128 * wave + lane, phi_ = plo + 64;
+            const int tlo = plo < T ? kl[plo] : 0xffff, thi = phi_ < T ? kl[phi_] : 0xffff;
             const int Llo = tlo != 0xffff ? tlen[tlo] : 0, Lhi = thi != 0xffff ? tlen[thi] : 0;
             const uint8_t* clo = tcodes + (tlo != 0xffff ? toff[tlo] : 0);
             const uint8_t* chi = tcodes + (thi != 0xffff ? toff[thi] : 0);
@@ -148,14 +147,14 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
             }
             const int vw = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
             int b = bw, arg = vw;
-            if constexpr (!COMPACT) {
+            if (!COMPACT || Wb > 1) {
                 const int par = (row & 1) * 8;
                 if (lane == 0) { xv[par + wave] = bw; xa[par + wave] = vw; xr[par + wave] = kw; }
                 __syncthreads();
                 int rk = xr[par];
                 b = xv[par];
                 arg = xa[par];
-                for (int w2 = 1; w2 < W; ++w2) {
+                for (int w2 = 1; w2 < Wb; ++w2) {
                     const int b2 = xv[par + w2], r2 = xr[par + w2];
                     if (b2 > b || (RANKED && b2 == b && r2 < rk)) { b = b2; rk = r2; arg = (w2 << 7) | xa[par + w2]; }
                 }
@@ -256,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
             ++tp;
             reduce_ends(L[P - 1], i + 1);
         }
-        if constexpr (!COMPACT) __syncthreads();   // the exchange area and xc are rewritten for the next chunk
+        __syncthreads();   // the exchange area and xc are rewritten for the next chunk
     }
 }
 

@@ -19,7 +19,7 @@ bool launch_fast_fill_wn_fl(const FastPlan& plan, hipStream_t st, int grid, size
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
         hipLaunchKernelGGL((sd_fast_fill_wn<PP, RK, 48>), dim3(grid), dim3(W * 64), lds, st, chunks, n_chunks,      \
                            bases2, nmask, table, lane_consts, sc, W, plan.bf8_match, plan.bf8_mismatch, B, ckpt,   \
-                           ckbase, queue, order, cendoff, crank, n_ptr, nullptr, nullptr, nullptr, nullptr);       \
+                           ckbase, queue, order, cendoff, crank, n_ptr, nullptr, nullptr, nullptr, nullptr, 0);       \
         return true;                                                                                               \
     }
 #define SD_WNFL(PP)                                                 \

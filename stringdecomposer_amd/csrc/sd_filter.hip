@@ -217,9 +217,9 @@ __global__ void sd_rank_keep(int n_chunks, int T, int ed_thr, const int32_t* __r
     }
     if (kpos) {
         // compacted form for large template sets (sd_fast_wn_ck.hip): the kept templates of the chunk in their
-        // filtered order (klist: [chunk][128], filled with 0xffff before), every template's place in it, the count
+        // filtered order (klist: [chunk][T], filled with 0xffff before), every template's place in it, the count
         kpos[(size_t)c * T + j] = (uint16_t)(kept ? rank : 0xffff);
-        if (kept && rank < 128) klist[(size_t)c * 128 + rank] = (uint16_t)j;
+        if (kept) klist[(size_t)c * T + rank] = (uint16_t)j;
         if (j == 0) nkept[c] = total;
     }
     if (grank) {
@@ -257,30 +257,28 @@ void build_peq(const std::vector<std::string>& tseq, std::vector<unsigned long l
         }
 }
 
-// Splits the chunk order (longest first) of a batch into the chunks whose kept templates fit one wave (<= 128)
-// and the rest, both in the original order; counts[0], counts[1] = sizes.  One wave.
+// Splits the chunk order (longest first) of a batch into W classes by the number of waves a chunk's kept templates
+// need, ceil(kept / 128), each in the original order; counts[w-1] = size of class w.  One wave.
 __global__ __launch_bounds__(64) void sd_split_order(const int* __restrict__ order, int n, const int32_t* __restrict__ nkept,
-                                                     int* __restrict__ order1, int* __restrict__ order2,
-                                                     int* __restrict__ counts) {
+                                                     int* __restrict__ orders, int* __restrict__ counts, int W) {
     const int lane = threadIdx.x;
-    int n1 = 0, n2 = 0;
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int base = 0; base < n; base += 64) {
         const int x = base + lane;
         const int c = x < n ? order[x] : -1;
-        const bool small = c >= 0 && nkept[c] <= 128;
-        const unsigned long long m1 = __ballot(small), m2 = __ballot(c >= 0 && !small);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (small) order1[n1 + __popcll(m1 & below)] = c;
-        else if (c >= 0) order2[n2 + __popcll(m2 & below)] = c;
-        n1 += __popcll(m1);
-        n2 += __popcll(m2);
+        const int cls = c >= 0 ? min(W, max(1, (nkept[c] + 127) / 128)) - 1 : -1;
+        for (int w = 0; w < W; ++w) {
+            const unsigned long long m = __ballot(cls == w);
+            if (cls == w) orders[(size_t)w * n + cnt[w] + __popcll(m & ((1ull << lane) - 1ull))] = c;
+            cnt[w] += __popcll(m);
+        }
     }
-    if (lane == 0) { counts[0] = n1; counts[1] = n2; }
+    for (int w = 0; w < W; ++w)
+        if (lane == w) counts[w] = cnt[w];
 }
 
-void launch_split_order(hipStream_t st, const int* order, int n, const int32_t* nkept, int* order1, int* order2,
-                        int* counts) {
-    hipLaunchKernelGGL(sd_split_order, dim3(1), dim3(64), 0, st, order, n, nkept, order1, order2, counts);
+void launch_split_order(hipStream_t st, const int* order, int n, const int32_t* nkept, int* orders, int* counts, int W) {
+    hipLaunchKernelGGL(sd_split_order, dim3(1), dim3(64), 0, st, order, n, nkept, orders, counts, W);
 }
 
 void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, int T, int Lmax, int ed_thr,
@@ -296,7 +294,7 @@ void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, 
         hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, crank, words, 0x7fff7fffu);
     }
     if (klist) {
-        const size_t words = (size_t)n_chunks * 64;   // [chunk][128] uint16
+        const size_t words = ((size_t)n_chunks * T + 1) / 2;   // [chunk][T] uint16
         hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st,
                            reinterpret_cast<uint32_t*>(klist), words, 0xffffffffu);
     }

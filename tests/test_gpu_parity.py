@@ -684,13 +684,14 @@ def test_plan_choices_do_not_change_rows():
         assert got == plain, (trial, n, ed)
 
 
-@pytest.mark.parametrize("thr", [0, 25, 48, 60, 200])
-def test_ed_thr_compacts_large_template_sets(oracle, thr):
-    """--ed_thr with more than 128 templates (csrc/sd_fast_wn_ck.hip): a chunk whose kept templates number at
-    most 128 is filled by one wave holding exactly those, in their filtered order; chunks that keep more stay on
-    the W-wave ranked kernel.  Thresholds from "only the nearest template" to "everything kept" (both classes,
-    and mixes of them), against the oracle and against the same job with the compaction switched off."""
-    mn, ms = synth.make_monomers(150, seed=12)          # 300 templates: three waves per chunk
+@pytest.mark.parametrize("thr,nm", [(0, 150), (25, 150), (48, 150), (60, 150), (200, 150), (30, 330), (52, 330), (75, 330)])
+def test_ed_thr_compacts_large_template_sets(oracle, thr, nm):
+    """--ed_thr with more than 128 templates (csrc/sd_fast_wn_ck.hip): a chunk is filled by ceil(kept / 128) waves
+    holding exactly its kept templates, in their filtered order; chunks that need all W waves stay on the W-wave
+    ranked kernel.  Thresholds from "only the nearest template" to "everything kept" (every class, and mixes of
+    them; 330 monomers = 660 templates = six waves), against the oracle and against the same job with the
+    compaction switched off."""
+    mn, ms = synth.make_monomers(nm, seed=12)          # 150 monomers: 300 templates, three waves per chunk
     rn, rs = synth.make_reads(ms, 4, read_len=3200, seed=5)
     st = synth.Stream(8, 2)
     rs = list(rs) + [synth._ACGT[st.below(1500, 4)].tobytes(), (ms[3] * 9)[:1400] + b"N" * 2 + ms[77] * 3]
