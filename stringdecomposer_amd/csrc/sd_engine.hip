@@ -204,10 +204,10 @@ struct sd_engine {
     DevBuf<uint32_t> d_cendoff, d_crank;
     DevBuf<int32_t> d_vlane0;        // --ed_thr, fast family: first virtual lane of each template
     // --ed_thr with more than 128 templates (compacted fill, sd_fast_wn_ck.hip): per chunk the kept templates in
-    // filtered order [128], every template's place [T], the kept count; the two chunk classes and their sizes
+    // filtered order [T], every template's place [T], the kept count; the W chunk classes (by waves needed) and their sizes
     DevBuf<uint16_t> d_klist, d_kpos;
     DevBuf<int32_t> d_nkept;
-    DevBuf<int> d_order12, d_cls;
+    DevBuf<int> d_orders, d_cls;
     bool compact_edthr = false;
     int filter_uniform = -1;         // prefilter: -1 general kernel; 0 / 1 every template ends in the low / high half of the same word
     DevBuf<int> d_queue;             // work-queue heads of the persistent kernels: a fresh zeroed (fill, trace) pair per run
@@ -677,7 +677,7 @@ static int load_chunks_impl(sd_engine* e, const std::vector<const char*>& cptr,
                     e->d_klist.alloc(C * (size_t)e->T + 2);
                     e->d_kpos.alloc(C * (size_t)e->T);
                     e->d_nkept.alloc(C);
-                    e->d_order12.alloc((size_t)e->fplan.waves * C);
+                    e->d_orders.alloc((size_t)e->fplan.waves * C);
                     e->d_cls.alloc(8);
                 }
             }
@@ -784,11 +784,11 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                                             e->filter_uniform, e->d_vlane0.p);
                 SD_HIP(hipEventRecord(e->ev_fill[0], st));
                 if (compact) {
-                    // more than 128 templates: the chunks whose kept templates fit one wave are filled by one wave
-                    // holding exactly those (the point of the reference's prefilter, main.cpp:128-149: less DP
-                    // work); the others by the W-wave ranked kernel.  The class sizes stay on the device.
+                    // more than 128 templates: a chunk is filled by as many waves as its kept templates need, holding
+                    // exactly those (the point of the reference's prefilter, main.cpp:128-149: less DP work); chunks
+                    // that need all W waves by the W-wave ranked kernel.  The class sizes stay on the device.
                     const int W = e->fplan.waves;
-                    int* ord = e->d_order12.p;   // [W][C]: class w-1 = the chunks whose kept templates need w waves
+                    int* ord = e->d_orders.p;   // [W][C]: class w-1 = the chunks whose kept templates need w waves
                     sd::launch_split_order(st, e->dp_order, C, e->d_nkept.p, ord, e->d_cls.p, W);
                     for (int w = 1; w < W; ++w)
                         sd::launch_fast_fill_wn_compact(e->fplan, st, e->dp_chunks, e->dp_bases2, e->dp_nmask, e->d_flane.p,

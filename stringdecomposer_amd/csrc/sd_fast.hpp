@@ -130,7 +130,7 @@ void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* 
                          const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
                          int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank,
                          const int* n_ptr = nullptr);   // n_ptr: the number of chunks lives on the device (order = a class list)
-// --ed_thr, more than 128 templates: the chunks whose kept templates fit one wave (sd_fast_wn_ck.hip)
+// --ed_thr, more than 128 templates: one class of chunks, filled by wb waves holding their kept templates (sd_fast_wn_ck.hip)
 void launch_fast_fill_wn_compact(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, const uint32_t* bases2,
                                  const uint32_t* nmask, const uint32_t* lane_consts, ScoreArgs sc, int32_t* B,
                                  uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order_w, const int* n_ptr,
