@@ -14,8 +14,9 @@ data-path collective -- SURVEY.md section 8(e)); torch.distributed is used for t
 max-over-ranks time only.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline      algorithmic bytes of the fill (sum_chunks n*(sumL/4 + 6.25) + 24*rows)
-                over the fill kernel's average HIP-event duration, against the 8 TB/s HBM peak
+  roofline      the fill kernel against what binds it: VALU wave-instructions per second against the measured
+                issue ceiling (bound "valu"); roofline.hbm_notional = algorithmic bytes of the fill (SURVEY 8(d):
+                sum_chunks n*(sumL/4 + 6.25) + 24*rows) over the fill's average HIP-event duration against 8 TB/s
   cpu_baseline  the real reference binary (oracle/_ref/dp, kind "reference") or the C oracle
                 (kind "port") timed on this box's host cores on a bounded sample of the same reads.
 """
@@ -34,6 +35,15 @@ if ROOT not in sys.path:
 from stringdecomposer_amd import lib, shard, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# VALU issue ceiling of the fill, MEASURED (tools/ubench_issue.hip -> profiles/r03_ubench_issue.txt): every
+# instruction class the fill is made of (v_pk_max/add/maximum3_f16, DPP, SDWA, v_and_or, v_readlane, v_cmp)
+# sustains one wave64 instruction per SIMD per 4.07-4.20 cycles at 4 and 8 waves per SIMD -- they do not
+# dual-issue (only plain v_add_f32/u32, v_mov, v_max_f16, and/or/xor reach 2.2-2.3, and those do not overlap
+# with packed ops either: add_u32 + pk_maximum3 alternating = 3.9 per instruction).  1024 SIMDs, 2.4 GHz.
+VALU_CYC_PER_WAVE_INST = 4.1
+SHADER_CLOCK_HZ = 2.4e9
+N_SIMDS = 1024
+VALU_PEAK_GINST = N_SIMDS * SHADER_CLOCK_HZ / VALU_CYC_PER_WAVE_INST / 1e9
 
 
 def cpu_baseline(mn, ms, rn, rs, gpu_rows_text):
@@ -282,17 +292,53 @@ def main():
             if tj.get("workload_rows") == rows and tj.get("kernel_family") == info["family"]:
                 traffic = tj.get("hbm_bytes_per_launch")
                 if tj.get("SQ_INSTS_VALU_per_launch") and tj.get("cells", info["cells"]) == info["cells"]:
-                    # what actually binds the fill (SURVEY 8(d) caveat): VALU issue slots, one wave64
-                    # instruction per 4 cycles per SIMD, 4 SIMDs x 256 CUs; clock from GRBM_GUI_ACTIVE
+                    # what actually binds the fill (SURVEY 8(d) caveat): VALU issue slots.  The instruction count of
+                    # a launch is a property of (binary, workload) -- counted once by rocprofv3 --pmc SQ_INSTS_VALU
+                    # (committed profile) -- the durations are measured in this run.
                     cyc = tj["GRBM_GUI_ACTIVE_per_launch"] / 8.0
                     valu = {"wave_insts_per_launch": tj["SQ_INSTS_VALU_per_launch"],
                             "insts_per_row": tj["SQ_INSTS_VALU_per_launch"] / rows,
-                            "issue_frac_profiled": tj["SQ_INSTS_VALU_per_launch"] * 4.0 / (1024.0 * cyc),
-                            "source": "committed profile: profiles/fill_traffic.json (rocprofv3 --pmc SQ_INSTS_VALU "
-                                      "GRBM_GUI_ACTIVE, device-resident single launch), not measured in this run"}
+                            "cycles_per_wave_inst_per_simd": VALU_CYC_PER_WAVE_INST,
+                            "ceiling_source": "profiles/r03_ubench_issue.txt (tools/ubench_issue.hip, this GPU model)",
+                            "issue_frac_profiled": tj["SQ_INSTS_VALU_per_launch"] * VALU_CYC_PER_WAVE_INST / (N_SIMDS * cyc),
+                            "source": "instruction count: committed profile profiles/fill_traffic.json (rocprofv3 --pmc "
+                                      "SQ_INSTS_VALU GRBM_GUI_ACTIVE, device-resident single launch); durations: this run"}
         except Exception:
             traffic = None
     kname = ("sd_fast_fill_wide" if info["cells_per_lane"] > 64 else "sd_fast_fill") if info["family"] == "fast" else "sd_generic_fill"
+
+    # contract figure (hbm_notional): SURVEY 8(d) algorithmic bytes of a fill launch / its HIP-event duration, launches
+    # of the timed region (in the default stream mode a fill's span contains the neighbouring batch's traceback and
+    # the drain hand-over; isolated_* = the same kernel launched alone, from the device_resident steps).  The fill is
+    # NOT HBM bound: it moves 0.28x the algorithmic bytes (pointers are recomputed by the traceback, not stored) and
+    # is limited by VALU issue slots, so the primary figure is wave-instructions per second against the measured
+    # issue ceiling of the chip; the notional HBM fraction north_star asks for is carried next to it.
+    hbm_notional = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": alg_per_launch,
+                    "isolated_frac": res_achieved / HBM_PEAK_GBS if res_steps else None,
+                    "path_frac": alg_bytes * K / dt / 1e9 / HBM_PEAK_GBS if ws == 1 else None,
+                    "note": "algorithmic bytes (2 bit per cell + per-row words + records) / fill duration against 8 TB/s"}
+    if valu is not None and fill_s > 0:
+        v_ach = valu["wave_insts_per_launch"] / fill_s / 1e9
+        v_iso = valu["wave_insts_per_launch"] / res_fill_s / 1e9 if res_steps and res_fill_s > 0 else None
+        roofline = {"bound": "valu", "achieved": v_ach, "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s",
+                    "frac": v_ach / VALU_PEAK_GINST,
+                    "isolated_frac": None if v_iso is None else v_iso / VALU_PEAK_GINST}
+    else:   # no instruction count for this workload / binary: only the notional figure
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS,
+                    "isolated_frac": res_achieved / HBM_PEAK_GBS if res_steps else None}
+    roofline.update({
+        "traffic": traffic,
+        "traffic_source": None if traffic is None else
+        "committed profile: profiles/fill_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+        "device-resident single launch), not measured in this run",
+        "kernel": kname, "avg_launch_ms": fill_s * 1e3, "launches_timed": launches,
+        "isolated_avg_launch_ms": res_fill_s * 1e3 if res_steps else None,
+        "valu_issue": valu, "hbm_notional": hbm_notional,
+        "binding_resource": "VALU issue slots: packed-f16 / DPP / SDWA wave64 instructions issue once per 4.1 cycles per "
+                            "SIMD on gfx950 (measured), the fill is 116 of them per row",
+        "cells_per_s": rows * sumL * K / launches / fill_s if fill_s > 0 else 0.0})
 
     out = {
         "metric": "decomposed read-bp/sec (whole node) at 12 monomers x 50kb reads",
@@ -318,21 +364,7 @@ def main():
         # contract figure: SURVEY 8(d) algorithmic bytes of a fill launch / its HIP-event duration, launches of
         # the timed region (in the default stream mode a fill's span contains the neighbouring batch's traceback
         # and the drain hand-over; isolated_* = the same kernel launched alone, from the device_resident steps)
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": None if traffic is None else
-                     "committed profile: profiles/fill_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-                     "device-resident single launch), not measured in this run",
-                     "kernel": kname,
-                     "algorithmic_bytes_per_launch": alg_per_launch,
-                     "avg_launch_ms": fill_s * 1e3, "launches_timed": launches, "valu_issue": valu,
-                     "isolated_avg_launch_ms": res_fill_s * 1e3 if res_steps else None,
-                     "isolated_frac": res_achieved / HBM_PEAK_GBS if res_steps else None,
-                     "binding_resource": "VALU issue slots (the fill writes 0.28x the algorithmic bytes: pointers are "
-                                         "recomputed by the traceback, not stored); the HBM fraction is the contract's "
-                                         "notional figure",
-                     "path_frac": alg_bytes * K / dt / 1e9 / HBM_PEAK_GBS if ws == 1 else None,
-                     "cells_per_s": rows * sumL * K / launches / fill_s if fill_s > 0 else 0.0},
+        "roofline": roofline,
         "kernel_ms_per_step": {"fill": d["fill_ms"] / K, "traceback": d["trace_ms"] / K, "compact": d["compact_ms"] / K,
                                "note": "HIP-event spans per batch, summed; batches on the two streams overlap"},
         "host_ms_per_step": {"pack_upload_enqueue": d["host_pack_ms"] / K, "wait_for_device": d["host_wait_ms"] / K,

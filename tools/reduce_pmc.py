@@ -5,8 +5,10 @@ usage: reduce_pmc.py <gpurun_out/<tag>> <out.json> [fill_traffic.json to rewrite
 
 Per pass directory (pmc_valu_<workload>, pmc_FETCH_SIZE, pmc_WRITE_SIZE, pmc_nw_<counter>) and kernel:
 the median counter value over the launches seen.  VALU issue-slot fraction of a launch =
-SQ_INSTS_VALU / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs): a CU issues at most one VALU wave-instruction per
-cycle over its four SIMDs (MI355X_MICROARCH.md).  FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE counts half
+SQ_INSTS_VALU x 4.1 / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): measured on this GPU (tools/ubench_issue.hip,
+profiles/r03_ubench_issue.txt) a SIMD issues one packed-f16 / DPP / SDWA / 3-operand wave64 instruction per
+4.07-4.20 cycles at any occupancy; only plain v_add_f32/u32, v_mov, v_max_f16, and/or/xor reach 2.2-2.3, and
+not while packed ops are in the stream.  FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE counts half
 of the bytes of wide streaming reads on gfx950 and is reported raw here (fill_traffic.json doubles it)."""
 import csv
 import glob
@@ -47,7 +49,7 @@ def main():
             cyc = act / 8.0
             res["valu"]["%s:%s" % (wl, k)] = {"SQ_INSTS_VALU_per_launch": insts, "GRBM_GUI_ACTIVE_per_launch": act,
                                               "cycles": cyc, "launches_seen": n,
-                                              "valu_issue_frac": round(insts / (cyc * 256.0), 4)}
+                                              "valu_issue_frac": round(insts * 4.1 / (cyc * 1024.0), 4)}
     for tag, pat in (("c2", "pmc_%s"), ("nw", "pmc_nw_%s")):
         per = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
