@@ -2,24 +2,10 @@
 // drop-in CLI: what stringdecomposer/main.py:29-60 `edist` + `aai` obtain from python-edlib for every
 // (block, monomer) pair; with --second-best that is 2*T alignments per output row, main.py:118-146).
 //
-// One lane per (read segment, template) pair.  Myers' bit-vector algorithm (J. ACM 46(3), 1999; block
-// form of Hyyro 2003) with the bit rows along the TEMPLATE (its match masks are shared by every pair of
-// that template) and one column per segment symbol, K 64-bit words per column.  edlib's traceback
-// (obtainAlignmentTraceback, edlib.cpp:945-1150) walks from the bottom-right corner with priority
-//     up   (consume a query symbol,  'I'):  D[i-1][j] + 1 == D[i][j]
-//     left (consume a target symbol, 'D'):  D[i][j-1] + 1 == D[i][j]
-//     diagonal ('=' / 'X')
-// Here the query (segment) runs along the columns, so "up" is the positive HORIZONTAL delta of the
-// cell and "left" the positive VERTICAL delta: the forward pass stores, per column, the two delta
-// vectors {Ph (before its shift), Pv (after the column)} -- 16 B per word -- in a per-lane history in
-// HBM, and the walk reads one such pair per step.  The walk only counts: with nL = number of "left"
-// moves, an optimal path has  matches = qlen - dist + nL  ('=' columns) and dist + matches columns.
-//
-// History: [workgroup][column][K][thread] x 16 B: the 64 lanes of a wave write one contiguous KB per (column,
-// word), and lanes that walk near the same column read neighbouring pieces of the same sectors.  ~8 KB per
-// 171 x 171 pair, written once and read about once: the kernel is HBM-bound, not ALU-bound.  (A lane-major
-// history -- every lane its own 8-KB region -- wrote 16-B pieces of 64 different sectors per instruction:
-// 2.4x the bytes at the memory, 73 M instead of 141 M pairs/s end to end.)
+// The kernel is in sd_nw_kernel.hpp: one lane per (read segment, template) pair, Myers' bit vectors along the
+// template, forward pass with a checkpoint of the column state every S columns, then a block-wise recomputation
+// whose history stays in registers while edlib's traceback priorities (up > left > diagonal,
+// edlib.cpp:945-1150) are walked.  This file holds the launch for segments of an ASCII text and the host driver.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -34,112 +20,66 @@
 #include "../../include/sd_hip.h"
 #include "sd_host.hpp"
 #include "sd_nw.hpp"
+#include "sd_nw_kernel.hpp"
 
 namespace sd {
 
-namespace {
-__device__ __forceinline__ int base_code_dev(uint32_t ch) {
-    // A,C,G,T,N -> 0..4 (the caller guarantees the alphabet)
-    return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
-}
-}  // namespace
-
+// pairs: all-vs-all (pair_tmpl == nullptr: pair p = segment p / T, template p % T) or one template per segment
+// (pair_tmpl[s]); seg_idx (optional) = the segments this launch works on (results are indexed by the true
+// segment).  eq_lds: the match masks of all templates fit the dynamic LDS of the launch.
 template <int K>
-__global__ __launch_bounds__(256) void sd_nw_pairs(const uint8_t* __restrict__ seq,
-                                                   const int64_t* __restrict__ seg_start,
-                                                   const int32_t* __restrict__ seg_len, int64_t n_seg, int T,
-                                                   const int32_t* __restrict__ pair_tmpl,
-                                                   const unsigned long long* __restrict__ peq,
-                                                   const int32_t* __restrict__ tlen, int homo, int qmax,
-                                                   uint4* __restrict__ hist, int32_t* __restrict__ dist,
-                                                   int32_t* __restrict__ matches) {
-    typedef unsigned long long u64;
+__global__ __launch_bounds__(256, 3) void sd_nw_pairs(const uint8_t* __restrict__ seq,
+                                                      const int64_t* __restrict__ seg_start,
+                                                      const int32_t* __restrict__ seg_len,
+                                                      const int32_t* __restrict__ seg_idx, int64_t n_seg, int T,
+                                                      const int32_t* __restrict__ pair_tmpl,
+                                                      const unsigned long long* __restrict__ peq,
+                                                      const int32_t* __restrict__ tlen, int homo, int cap,
+                                                      uint4* __restrict__ ck, int* __restrict__ ckpos, int eq_lds,
+                                                      int32_t* __restrict__ dist, int32_t* __restrict__ matches) {
+    extern __shared__ unsigned long long speq[];   // [T][5][K] when eq_lds
+    if (eq_lds) {
+        for (int idx = threadIdx.x; idx < T * 5 * K; idx += blockDim.x) speq[idx] = peq[idx];
+        __syncthreads();
+    }
     const int64_t n_pairs = pair_tmpl ? n_seg : n_seg * (int64_t)T;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // history of this lane: [column][word][thread of the workgroup] -- the 64 lanes of a wave write one
-    // contiguous KB per (column, word), whole sectors (a lane-major layout wrote 16-B pieces of 64 different
-    // sectors per instruction: 2.4x the bytes at the memory)
-    uint4* H = hist + (size_t)blockIdx.x * 256 * (size_t)qmax * K + threadIdx.x;
+    // checkpoints of this lane: [workgroup][slot][word][thread] x 16 B -- a wave writes one contiguous KB per
+    // (slot, word)
+    uint4* ckl = ck + (size_t)blockIdx.x * (size_t)cap * K * 256 + threadIdx.x;
+    int* ckp = ckpos + (size_t)blockIdx.x * (size_t)cap * 256 + threadIdx.x;
     for (int64_t p = gid; p < n_pairs; p += stride) {
-        const int64_t s = pair_tmpl ? p : p / T;
-        const int t = pair_tmpl ? pair_tmpl[p] : (int)(p - s * T);
+        const int64_t sl = pair_tmpl ? p : p / T;
+        const int64_t s = seg_idx ? seg_idx[sl] : sl;
+        const int t = pair_tmpl ? pair_tmpl[s] : (int)(p - sl * T);
+        const int64_t o = pair_tmpl ? s : s * T + t;
         const int ql = seg_len[s];
         const int tl = tlen[t];
         if (ql <= 0 || tl <= 0) {  // main.py:30-33: an empty side has no alignment
-            dist[p] = -1;
-            matches[p] = 0;
+            dist[o] = -1;
+            matches[o] = 0;
             continue;
         }
-        const int64_t q0 = seg_start[s];
-        const u64* pq = peq + (size_t)t * 5 * K;
-        const int lastW = (tl - 1) >> 6;
-        const u64 lastBit = 1ull << ((tl - 1) & 63);
-        u64 Pv[K], Mv[K];
-#pragma unroll
-        for (int w = 0; w < K; ++w) { Pv[w] = ~0ull; Mv[w] = 0ull; }
-        int score = tl;  // D[0][tl]
-        int c = 0;       // columns done (= query symbols kept)
-        uint32_t prev = 0x100, word = 0;
-        for (int i = 0; i < ql; ++i) {
-            const int64_t pos = q0 + i;
-            if (i == 0 || (pos & 3) == 0) word = *reinterpret_cast<const uint32_t*>(seq + (pos & ~(int64_t)3));
-            const uint32_t ch = (word >> (8 * (int)(pos & 3))) & 0xffu;
-            if (homo && ch == prev) continue;  // homopolymer compression of the query, main.py:87-92
-            prev = ch;
-            const u64* eqp = pq + base_code_dev(ch) * K;
-            int hin = 1;  // global alignment: D[c][0] - D[c-1][0] = 1
-            uint4* hc = H + (size_t)c * K * 256;
-#pragma unroll
-            for (int w = 0; w < K; ++w) {
-                if (w <= lastW) {
-                    u64 Eq = eqp[w];
-                    const u64 pv = Pv[w], mv = Mv[w];
-                    const u64 Xv = Eq | mv;
-                    if (hin < 0) Eq |= 1ull;
-                    const u64 Xh = (((Eq & pv) + pv) ^ pv) | Eq;
-                    u64 Ph = mv | ~(Xh | pv);
-                    u64 Mh = pv & Xh;
-                    const u64 top = w == lastW ? lastBit : (1ull << 63);
-                    const int hout = (Ph & top) ? 1 : ((Mh & top) ? -1 : 0);
-                    const u64 PhU = Ph;  // delta of row r lives in bit r-1 before the shift
-                    Ph <<= 1;
-                    Mh <<= 1;
-                    if (hin < 0) Mh |= 1ull;
-                    if (hin > 0) Ph |= 1ull;
-                    const u64 npv = Mh | ~(Xv | Ph);
-                    Pv[w] = npv;
-                    Mv[w] = Ph & Xv;
-                    hin = hout;
-                    hc[w * 256] = make_uint4((uint32_t)PhU, (uint32_t)(PhU >> 32), (uint32_t)npv, (uint32_t)(npv >> 32));
-                }
-            }
-            score += hin;  // vertical... the last word's carry is the horizontal delta of row tl
-            ++c;
-        }
-        // walk (edlib priority: up > left > diagonal), counting the "left" moves
-        int ci = c, r = tl, nL = 0;
-        while (ci > 0 && r > 0) {
-            const uint4 h = H[((size_t)(ci - 1) * K + ((r - 1) >> 6)) * 256];
-            const int b = (r - 1) & 63;
-            const u64 ph = ((u64)h.y << 32) | h.x, pv = ((u64)h.w << 32) | h.z;
-            if ((ph >> b) & 1ull) { --ci; }
-            else if ((pv >> b) & 1ull) { --r; ++nL; }
-            else { --ci; --r; }
-        }
-        nL += r;  // column 0 reached with target symbols left: they are all "left" moves
-        dist[p] = score;
-        matches[p] = c - score + nL;
+        const uint2* eqt = reinterpret_cast<const uint2*>(eq_lds ? speq + (size_t)t * 5 * K : peq + (size_t)t * 5 * K);
+        NwQueryAscii q{seq, seg_start[s]};
+        int d = -2, m = 0;
+        (void)nw_pair<K>(q, ql, eqt, tl, homo != 0, ckl, ckp, (size_t)256, cap, d, m);
+        dist[o] = d;       // -2: more columns than the launch has checkpoint slots for (the host driver sizes them)
+        matches[o] = m;
     }
 }
 
 void launch_nw_pairs(int K, hipStream_t st, int grid, const uint8_t* seq, const int64_t* seg_start,
-                     const int32_t* seg_len, int64_t n_seg, int T, const int32_t* pair_tmpl,
-                     const unsigned long long* peq, const int32_t* tlen, int homo, int qmax, void* hist,
+                     const int32_t* seg_len, const int32_t* seg_idx, int64_t n_seg, int T, const int32_t* pair_tmpl,
+                     const unsigned long long* peq, const int32_t* tlen, int homo, int cap, void* ck, int* ckpos,
                      int32_t* dist, int32_t* matches) {
-#define SD_NW(KK)                                                                                        \
-    hipLaunchKernelGGL(sd_nw_pairs<KK>, dim3(grid), dim3(256), 0, st, seq, seg_start, seg_len, n_seg, T, \
-                       pair_tmpl, peq, tlen, homo, qmax, reinterpret_cast<uint4*>(hist), dist, matches)
+    const size_t eq_bytes = (size_t)T * 5 * (size_t)K * 8;
+    const int eq_lds = eq_bytes <= 60 * 1024 ? 1 : 0;
+    const size_t lds = eq_lds ? eq_bytes : 0;
+#define SD_NW(KK)                                                                                              \
+    hipLaunchKernelGGL(sd_nw_pairs<KK>, dim3(grid), dim3(256), lds, st, seq, seg_start, seg_len, seg_idx, n_seg, T, \
+                       pair_tmpl, peq, tlen, homo, cap, reinterpret_cast<uint4*>(ck), ckpos, eq_lds, dist, matches)
     switch (K) {
         case 1: SD_NW(1); break;
         case 2: SD_NW(2); break;
@@ -149,6 +89,26 @@ void launch_nw_pairs(int K, hipStream_t st, int grid, const uint8_t* seq, const 
         default: SD_NW(8); break;
     }
 #undef SD_NW
+}
+
+// match masks of a template set, top-aligned in K words per (template, symbol): symbol k of a template of length
+// L sits at bit 64 K - L + k (sd_nw_kernel.hpp)
+void nw_build_masks(const std::vector<std::string>& ts, int K, std::vector<unsigned long long>& peq,
+                    std::vector<int32_t>& tl) {
+    const size_t T = ts.size();
+    peq.assign(T * 5 * (size_t)K, 0ull);
+    tl.assign(T, 0);
+    for (size_t t = 0; t < T; ++t) {
+        const int L = (int)ts[t].size();
+        tl[t] = L;
+        const int pad = 64 * K - L;
+        for (int k = 0; k < L; ++k) {
+            const char ch = ts[t][(size_t)k];
+            const int code = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
+            const int bit = pad + k;
+            peq[(t * 5 + (size_t)code) * K + (size_t)(bit >> 6)] |= 1ull << (bit & 63);
+        }
+    }
 }
 
 }  // namespace sd
@@ -175,14 +135,14 @@ struct NwBuf {
 struct NwCtx {
     std::mutex m;
     int dev = -1;
-    NwBuf seq, starts, lens, pair, peq, tlen, hist, dist, matches;
+    NwBuf seq, starts, lens, pair, peq, tlen, ck, ckpos, idx, dist, matches;
     char* stage = nullptr;      // pinned staging of the text
     size_t stage_cap = 0;
     void release() {
         if (stage) (void)hipHostFree(stage);
         stage = nullptr;
         stage_cap = 0;
-        for (NwBuf* b : {&seq, &starts, &lens, &pair, &peq, &tlen, &hist, &dist, &matches}) {
+        for (NwBuf* b : {&seq, &starts, &lens, &pair, &peq, &tlen, &ck, &ckpos, &idx, &dist, &matches}) {
             if (b->p) (void)hipFree(b->p);
             b->p = nullptr;
             b->cap = 0;
@@ -257,13 +217,9 @@ int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans
     int K = (tmax + 63) / 64;
     if (K == 5) K = 6;
     if (K == 7) K = 8;
-    std::vector<unsigned long long> peq((size_t)T * 5 * K, 0ull);
-    std::vector<int32_t> tl((size_t)T);
-    for (int t = 0; t < T; ++t) {
-        tl[(size_t)t] = (int32_t)ts[(size_t)t].size();
-        for (size_t k = 0; k < ts[(size_t)t].size(); ++k)
-            peq[((size_t)t * 5 + (size_t)nw_code(ts[(size_t)t][k])) * K + (k >> 6)] |= 1ull << (k & 63);
-    }
+    std::vector<unsigned long long> peq;
+    std::vector<int32_t> tl;
+    sd::nw_build_masks(ts, K, peq, tl);
     int64_t text = 0;
     std::vector<int64_t> span_off(spans.size() + 1, 0);
     for (size_t i = 0; i < spans.size(); ++i) { span_off[i] = text; text += spans[i].second; }
@@ -313,43 +269,66 @@ int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans
         for (uint8_t b : bad)
             if (b) return SD_ERR_UNSUPPORTED;
     }
-    // resident lanes: up to 16 waves per CU, within a history budget of 8 GB (and a third of the free HBM)
+    // Two launches: the segments of up to NW_SHORT symbols -- practically all of them, a block is about a monomer long --
+    // with NW_SHORT / S checkpoint slots per lane and 12 waves per CU, and the few long ones (a non-satellite flank can
+    // be a whole chunk) with slots for the longest, on as many lanes as 1 GB of checkpoints allows.  (Round 2 sized the
+    // history of EVERY lane by the longest segment of the call: one 5.5-kb block cost 264 KB per lane.)
+    constexpr int NW_SHORT = 1024;
+    const int S = sd::nw_block_cols(K);
+    std::vector<int32_t> idx_short, idx_long;
+    for (int64_t s = 0; s < n_seg; ++s) (seg_len[s] > NW_SHORT ? idx_long : idx_short).push_back((int32_t)s);
+    if (n_seg > 0x7fffffff) return SD_ERR_UNSUPPORTED;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SD_ERR_HIP;
     const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    const size_t per_lane = (size_t)qmax * K * 16;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return SD_ERR_HIP;
-    size_t budget = std::min<size_t>((size_t)8 << 30, (free_b + g_nw.hist.cap) / 3);
-    // 16 waves per CU: the kernel is HBM-bound and measured the same from 8 to 32 waves per CU (137-146 M pairs/s),
-    // and the history of the resident lanes is what this call allocates (SD_NW_BLOCKS_PER_CU: developer knob)
-    const char* lpc = getenv("SD_NW_BLOCKS_PER_CU");
-    int64_t lanes = std::min<int64_t>((int64_t)n_cu * (lpc ? std::max(1, atoi(lpc)) : 4) * 256, (int64_t)((n_pairs + 255) / 256 * 256));
-    lanes = std::min<int64_t>(lanes, (int64_t)(budget / per_lane) / 256 * 256);
-    if (lanes < 256) lanes = 256;
-    const int grid = (int)(lanes / 256);
+    const size_t slot_bytes = (size_t)K * 16 + 4;
+    struct Launch { const std::vector<int32_t>* idx; int cap; int grid; size_t idx_off; };
+    std::vector<Launch> launches;
+    size_t ck_lanes_bytes = 0, ckpos_bytes = 0;
+    {
+        const char* lpc = getenv("SD_NW_BLOCKS_PER_CU");   // developer knob
+        const int bpc = lpc ? std::max(1, atoi(lpc)) : 3;
+        auto add = [&](const std::vector<int32_t>& ix, int maxlen, size_t budget, size_t off) {
+            if (ix.empty()) return;
+            const int cap = std::max(1, (maxlen + S - 1) / S);
+            const int64_t pairs = pair_tmpl ? (int64_t)ix.size() : (int64_t)ix.size() * T;
+            int64_t lanes = std::min<int64_t>((int64_t)n_cu * bpc * 256, (pairs + 255) / 256 * 256);
+            lanes = std::min<int64_t>(lanes, (int64_t)(budget / ((size_t)cap * slot_bytes)) / 256 * 256);
+            if (lanes < 256) lanes = 256;
+            launches.push_back(Launch{&ix, cap, (int)(lanes / 256), off});
+            ck_lanes_bytes = std::max(ck_lanes_bytes, (size_t)lanes * cap * (size_t)K * 16);
+            ckpos_bytes = std::max(ckpos_bytes, (size_t)lanes * cap * 4);
+        };
+        add(idx_short, std::min(qmax, NW_SHORT), (size_t)2 << 30, 0);
+        add(idx_long, qmax, (size_t)1 << 30, idx_short.size());
+    }
     bool ok = g_nw.seq.need((size_t)text + 8) && g_nw.starts.need(sizeof(int64_t) * (size_t)n_seg) &&
               g_nw.lens.need(sizeof(int32_t) * (size_t)n_seg) && g_nw.peq.need(sizeof(unsigned long long) * peq.size()) &&
-              g_nw.tlen.need(sizeof(int32_t) * (size_t)std::max(T, 1)) && g_nw.hist.need((size_t)lanes * per_lane) &&
+              g_nw.tlen.need(sizeof(int32_t) * (size_t)std::max(T, 1)) && g_nw.ck.need(ck_lanes_bytes) &&
+              g_nw.ckpos.need(ckpos_bytes) && g_nw.idx.need(sizeof(int32_t) * (size_t)n_seg) &&
               g_nw.dist.need(sizeof(int32_t) * (size_t)n_pairs) && g_nw.matches.need(sizeof(int32_t) * (size_t)n_pairs) &&
               (!pair_tmpl || g_nw.pair.need(sizeof(int32_t) * (size_t)n_seg));
-    if (!ok) return SD_ERR_HIP;
+    if (!ok) return SD_ERR_UNSUPPORTED;   // no memory for the device form: the caller's host implementation runs
     lap.to(0);
     auto up = [](void* d, const void* h, size_t n) { return n == 0 || hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; };
     ok = up(g_nw.seq.p, g_nw.stage, (size_t)text) && up(g_nw.starts.p, seg_start, sizeof(int64_t) * (size_t)n_seg) &&
          up(g_nw.lens.p, seg_len, sizeof(int32_t) * (size_t)n_seg) &&
          up(g_nw.peq.p, peq.data(), sizeof(unsigned long long) * peq.size()) &&
          up(g_nw.tlen.p, tl.data(), sizeof(int32_t) * (size_t)T) &&
+         up(g_nw.idx.p, idx_short.data(), sizeof(int32_t) * idx_short.size()) &&
+         up(static_cast<int32_t*>(g_nw.idx.p) + idx_short.size(), idx_long.data(), sizeof(int32_t) * idx_long.size()) &&
          (!pair_tmpl || up(g_nw.pair.p, pair_tmpl, sizeof(int32_t) * (size_t)n_seg));
     if (!ok) return SD_ERR_HIP;
     lap.to(1);
-    sd::launch_nw_pairs(K, nullptr, grid, static_cast<const uint8_t*>(g_nw.seq.p), static_cast<const int64_t*>(g_nw.starts.p),
-                        static_cast<const int32_t*>(g_nw.lens.p), n_seg, T,
-                        pair_tmpl ? static_cast<const int32_t*>(g_nw.pair.p) : nullptr,
-                        static_cast<const unsigned long long*>(g_nw.peq.p), static_cast<const int32_t*>(g_nw.tlen.p),
-                        homo ? 1 : 0, qmax, g_nw.hist.p, static_cast<int32_t*>(g_nw.dist.p),
-                        static_cast<int32_t*>(g_nw.matches.p));
-    if (hipGetLastError() != hipSuccess) return SD_ERR_HIP;
+    for (const Launch& L : launches) {
+        sd::launch_nw_pairs(K, nullptr, L.grid, static_cast<const uint8_t*>(g_nw.seq.p), static_cast<const int64_t*>(g_nw.starts.p),
+                            static_cast<const int32_t*>(g_nw.lens.p), static_cast<const int32_t*>(g_nw.idx.p) + L.idx_off,
+                            (int64_t)L.idx->size(), T, pair_tmpl ? static_cast<const int32_t*>(g_nw.pair.p) : nullptr,
+                            static_cast<const unsigned long long*>(g_nw.peq.p), static_cast<const int32_t*>(g_nw.tlen.p),
+                            homo ? 1 : 0, L.cap, g_nw.ck.p, static_cast<int*>(g_nw.ckpos.p),
+                            static_cast<int32_t*>(g_nw.dist.p), static_cast<int32_t*>(g_nw.matches.p));
+        if (hipGetLastError() != hipSuccess) return SD_ERR_HIP;
+    }
     lap.to(2);
     if (hipMemcpy(dist, g_nw.dist.p, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(matches, g_nw.matches.p, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost) != hipSuccess)

@@ -10,12 +10,15 @@
 
 namespace sd {
 
-// One lane per (segment, template) pair; K = 64-bit words per template (ceil(max tlen / 64), 1..8).
-// hist: grid * 256 lanes x qmax columns x K x 16 B.
+// One lane per (segment, template) pair; K = 64-bit words per template (ceil(max tlen / 64): 1, 2, 3, 4, 6, 8).
+// ck / ckpos: grid * 256 lanes x cap checkpoint slots x (K x 16 B + 4 B); peq: [T][5][K], top-aligned
+// (nw_build_masks); seg_idx (optional): the segments of this launch.
 void launch_nw_pairs(int K, hipStream_t st, int grid, const uint8_t* seq, const int64_t* seg_start,
-                     const int32_t* seg_len, int64_t n_seg, int T, const int32_t* pair_tmpl,
-                     const unsigned long long* peq, const int32_t* tlen, int homo, int qmax, void* hist,
+                     const int32_t* seg_len, const int32_t* seg_idx, int64_t n_seg, int T, const int32_t* pair_tmpl,
+                     const unsigned long long* peq, const int32_t* tlen, int homo, int cap, void* ck, int* ckpos,
                      int32_t* dist, int32_t* matches);
+void nw_build_masks(const std::vector<std::string>& ts, int K, std::vector<unsigned long long>& peq,
+                    std::vector<int32_t>& tl);
 
 // Host driver (sd_nw.hip): identity of segments of a text (the concatenation of `spans`) against templates on
 // the device; see the definition.

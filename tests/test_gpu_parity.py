@@ -508,6 +508,8 @@ def test_nw_identity_kernel_equals_host_and_edlib(shape):
     starts = np.sort(st.below(n, len(seq) - 2 * hi - 2))
     lens = st.below(n, 2 * hi) + 1
     lens[:5] = [1, 2, 64, 65, 2 * hi]
+    lens[5:7] = [1100, 2600]          # longer than the short launch's checkpoint slots: the second launch
+    starts[5:7] = np.minimum(starts[5:7], len(seq) - 2700)
     ends = starts + lens - 1
     pair = st.below(n, len(tm)).astype(np.int32)
     for homo in (False, True):
