@@ -61,6 +61,7 @@ int PostProcessor::init(const std::vector<Seq>& monos, int min_identity_, bool s
         key_of_t[t] = kidx[tname[t]];
         own_il_of_t[t] = kcol[(size_t)key_of_t[t]];   // light mode keeps the last monomer of that name (main.py:112-116)
     }
+    own_il32.assign(own_il_of_t.begin(), own_il_of_t.end());
     return SD_OK;
 }
 
@@ -122,8 +123,19 @@ inline double now_seconds() {
 inline void put_f2(std::string& o, double v) { put_fixed2(o, v); }   // == Python "{:.2f}".format(v)
 }  // namespace
 
+namespace {
+// identity in percent of a device word (dist << 16) | matches: the arithmetic of main.py:47-60 on the same integers
+inline double ident_percent(uint32_t w) {
+    const uint32_t d = w >> 16, m = w & 0xffffu;
+    double a = 0.0;
+    a += (double)m;
+    a /= (double)(d + m);
+    return a * 100;
+}
+}  // namespace
+
 int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off, TextBuf& fin,
-                           TextBuf& alt, std::string& err) {
+                           TextBuf& alt, std::string& err, const uint32_t* id, const uint32_t* idh) {
     fin.clear();
     alt.clear();
     const int64_t nB = row_off[n_reads];
@@ -131,6 +143,24 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
     const double t_0 = now_seconds();
     const int T = (int)il_seq.size();
     const int nK = (int)keys.size();
+    if (id && (!second_best || idh)) {
+        // every word computed?  (0xffffffff: a pair the kernel left out; dist + matches == 0 cannot be an alignment)
+        const int64_t nw = second_best ? nB * T : nB;
+        std::vector<uint8_t> bad((size_t)((nw + 65535) / 65536), 0);
+        parallel_for((int64_t)bad.size(), threads, 1, [&](int64_t blk) {
+            const int64_t e = std::min<int64_t>(nw, (blk + 1) * 65536);
+            uint8_t b = 0;
+            for (int64_t x = blk * 65536; x < e; ++x) {
+                b |= (uint8_t)(id[x] == 0xffffffffu || id[x] == 0u);
+                if (idh) b |= (uint8_t)(idh[x] == 0xffffffffu || idh[x] == 0u);
+            }
+            bad[(size_t)blk] = b;
+        });
+        for (uint8_t b : bad) if (b) { id = nullptr; break; }
+    } else {
+        id = nullptr;
+    }
+    if (!id) idh = nullptr;
     // text = the reads that have blocks, concatenated; blocks never cross a read
     std::vector<std::pair<const char*, int64_t>> spans;
     std::vector<int64_t> seg_start((size_t)nB);
@@ -156,7 +186,9 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
     const double t_a = now_seconds();
     RawVec<double> vals, hvals;
     int rc;
-    if (!second_best) {
+    if (id) {
+        // identities came with the rows
+    } else if (!second_best) {
         std::vector<int32_t> pair((size_t)nB);
         for (int64_t b = 0; b < nB; ++b) pair[(size_t)b] = own_il_of_t[(size_t)rows[b].tmpl];
         rc = identities(spans, seg_start, seg_len, pair.data(), false, vals, err);
@@ -186,12 +218,21 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
             const std::string* h1n = nullptr;
             const double* kv = nullptr;
             std::vector<double> kbuf;
+            std::vector<double> hbuf;
             if (!second_best) {
-                score = vals[(size_t)b];
+                score = id ? ident_percent(id[b]) : vals[(size_t)b];
             } else {
-                const double* v = &vals[(size_t)b * T];
                 kbuf.resize((size_t)nK);
-                for (int k = 0; k < nK; ++k) kbuf[(size_t)k] = v[kcol[(size_t)k]];
+                if (id) {
+                    const uint32_t* v = id + (size_t)b * T;
+                    for (int k = 0; k < nK; ++k) kbuf[(size_t)k] = ident_percent(v[kcol[(size_t)k]]);
+                    hbuf.resize((size_t)T);
+                    const uint32_t* hw = idh + (size_t)b * T;
+                    for (int j = 0; j < T; ++j) hbuf[(size_t)j] = ident_percent(hw[j]);
+                } else {
+                    const double* v = &vals[(size_t)b * T];
+                    for (int k = 0; k < nK; ++k) kbuf[(size_t)k] = v[kcol[(size_t)k]];
+                }
                 kv = kbuf.data();
                 score = kv[ko];
                 int sb = -1;   // main.py:124-128: first maximum among the other names
@@ -202,7 +243,7 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
                 if (sb >= 0) sbn = &keys[(size_t)sb];
                 else sbs = -1;
                 // main.py:130-135: all monomers (the own one included), stable sort by -score: ranks 0 and 1
-                const double* h = &hvals[(size_t)b * T];
+                const double* h = id ? hbuf.data() : &hvals[(size_t)b * T];
                 int i0 = 0;
                 for (int j = 1; j < T; ++j) if (h[j] > h[i0]) i0 = j;
                 int i1 = -1;

@@ -25,8 +25,14 @@ class PostProcessor {
     // rows[row_off[r] .. row_off[r+1]) = blocks of reads[r] (sd_rec.tmpl in the DP's template order: monomers,
     // then their reverse complements; read-global inclusive coordinates).  Appends the text of the final TSV
     // rows (main.py:157-160) and, with second_best, of the _alt rows (:161-165).
+    // id / idh (optional): identities that came with the rows from the device (sd_ident.hip), one word
+    // (dist << 16) | matches per row (light mode: the row's own monomer) or per (row, interleaved monomer) pair,
+    // plain / homopolymer-compressed; rows without a computed word send the batch through the text-based path.
     int process(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off, TextBuf& fin,
-                TextBuf& alt, std::string& err);   // fin / alt are REPLACED by the text of this batch
+                TextBuf& alt, std::string& err, const uint32_t* id = nullptr,
+                const uint32_t* idh = nullptr);   // fin / alt are REPLACED by the text of this batch
+    const std::vector<std::string>& interleaved_seqs() const { return il_seq; }   // m0, m0', m1, m1', ... (main.py:79-84)
+    const std::vector<int32_t>& own_interleaved() const { return own_il32; }      // DP template -> interleaved index
     int tmpl_of_name(const std::string& nm) const;   // first template of that name in the DP's order, -1 if none
     std::vector<std::string> tname;                  // the DP's template names: m, ..., m', ...
     double t_prepare = 0, t_identity = 0, t_format = 0, t_concat = 0;   // seconds spent in process(), by stage
@@ -39,6 +45,7 @@ class PostProcessor {
     std::vector<std::string> keys;                   // distinct names in first-occurrence order
     std::vector<int> kcol;                           // key -> last interleaved index of that name
     std::vector<int> key_of_t, own_il_of_t;
+    std::vector<int32_t> own_il32;
     int min_identity = 0;
     bool second_best = false;
     double coef[3] = {0, 0, 0};

@@ -21,6 +21,7 @@
 
 #include "../../include/sd_hip.h"
 #include "sd_convert.hpp"
+#include "sd_ident.hpp"
 #include "sd_nw.hpp"
 #include "sd_device.hpp"
 #include "sd_fast.hpp"
@@ -239,6 +240,21 @@ struct sd_engine {
     DevBuf<sd::DevRec> d_recs, d_dense;
     DevBuf<int64_t> d_roff;
     int64_t dense_cap = 0;
+    // in-stream identities of the final TSV (sd_ident.hip), set up by engine_set_identity: 0 off, 1 the record's
+    // own template (main.py:112-116), 2 every template, plain and homopolymer-compressed (--second-best)
+    int ident_mode = 0;
+    int iT = 0, iK = 0, iKh = 0;                 // interleaved templates (m0, m0', m1, ...), words per template
+    DevBuf<unsigned long long> d_ipeq, d_ihpeq;  // match masks, plain / compressed templates
+    DevBuf<int32_t> d_itlen, d_ihtlen, d_iown;   // lengths; DP template index -> interleaved index (mode 1)
+    DevBuf<int32_t> d_recchunk, d_ilong;
+    DevBuf<int> d_ilongcnt, d_ickpos;
+    DevBuf<uint4> d_ick;
+    DevBuf<uint32_t> d_ident, d_identh;
+    PinBuf<uint32_t> h_ident, h_identh;
+    int64_t ident_cap = 0;                       // records the identity outputs have room for
+    bool ident_valid = false;                    // the last fetch brought identities for every record
+    sd::IdentArgs ia_plain{}, ia_homo{};
+    hipEvent_t ev_id0 = nullptr, ev_id1 = nullptr;
 
     // run state
     hipStream_t last_stream = nullptr;
@@ -252,7 +268,7 @@ struct sd_engine {
     ~sd_engine() {
         for (hipEvent_t e : ev_fill) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_trace) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {ev_run0, ev_run1, ev_cmp0, ev_cmp1, ev_in})
+        for (hipEvent_t e : {ev_run0, ev_run1, ev_cmp0, ev_cmp1, ev_in, ev_id0, ev_id1})
             if (e) (void)hipEventDestroy(e);
     }
 
@@ -261,7 +277,8 @@ struct sd_engine {
                d_ftable.bytes() + d_flane.bytes() + d_fslot.bytes() + d_ftcodes.bytes() + d_fckpt.bytes() +
                d_fckbase.bytes() + d_in.bytes() +
                d_B.bytes() + d_argB.bytes() + d_cnt.bytes() + d_recs.bytes() + d_dense.bytes() +
-               d_roff.bytes();
+               d_roff.bytes() + d_recchunk.bytes() + d_ilong.bytes() + d_ick.bytes() + d_ickpos.bytes() +
+               d_ident.bytes() + d_identh.bytes();
     }
 };
 
@@ -541,6 +558,58 @@ void sd_engine_destroy(sd_engine* e) {
     delete e;
 }
 
+// In-stream identities (sd_ident.hip).  il_seq = the monomers and their reverse complements interleaved (m0, m0', m1,
+// ..., main.py:79-84), own[t] = interleaved index of the DP's template t; second_best = every template, plain and
+// homopolymer-compressed, instead of the record's own.  Returns false (mode stays 0: the post-processing computes the
+// identities from the read text as before) for template sets the kernel does not take.
+static bool engine_set_identity(sd_engine* e, const std::vector<std::string>& il_seq, const std::vector<int32_t>& own,
+                                bool second_best) {
+    e->ident_mode = 0;
+    if (il_seq.empty() || (int)own.size() != e->T) return false;
+    auto hpc = [](const std::string& x) {
+        std::string o;
+        for (size_t i = 0; i < x.size(); ++i)
+            if (i == 0 || x[i] != x[i - 1]) o.push_back(x[i]);
+        return o;
+    };
+    std::vector<std::string> hs;
+    size_t tmax = 1, hmax = 1;
+    for (const std::string& t : il_seq) {
+        for (char c : t)
+            if (!(c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N')) return false;
+        if (t.empty()) return false;
+        hs.push_back(hpc(t));
+        tmax = std::max(tmax, t.size());
+        hmax = std::max(hmax, hs.back().size());
+    }
+    if (tmax > 512) return false;
+    auto words = [](size_t L) { int k = (int)((L + 63) / 64); return k == 5 ? 6 : k == 7 ? 8 : k; };
+    if ((int64_t)e->p.part_size + e->p.overlap > 60000) return false;   // dist / matches travel as 16-bit fields
+    try {
+        SD_HIP(hipSetDevice(e->device));
+        std::vector<unsigned long long> peq;
+        std::vector<int32_t> tl;
+        e->iT = (int)il_seq.size();
+        e->iK = words(tmax);
+        sd::nw_build_masks(il_seq, e->iK, peq, tl);
+        e->d_ipeq.upload(peq);
+        e->d_itlen.upload(tl);
+        e->d_iown.upload(own);
+        if (second_best) {
+            e->iKh = words(hmax);
+            sd::nw_build_masks(hs, e->iKh, peq, tl);
+            e->d_ihpeq.upload(peq);
+            e->d_ihtlen.upload(tl);
+        }
+        if (!e->ev_id0) SD_HIP(hipEventCreate(&e->ev_id0));
+        if (!e->ev_id1) SD_HIP(hipEventCreate(&e->ev_id1));
+    } catch (const HipFail&) {
+        return false;
+    }
+    e->ident_mode = second_best ? 2 : 1;
+    return true;
+}
+
 // Packs the given chunks (pointer + length each) into the pinned staging buffer, starts their copy to
 // the device on `st` (asynchronous) and sizes the per-batch device buffers.  Chunk c refers to
 // cptr[c][0 .. clen[c]).  The kernels of sd_engine_run must be enqueued on the same stream (or after
@@ -635,6 +704,51 @@ static int load_chunks_impl(sd_engine* e, const std::vector<const char*>& cptr,
         e->dense_cap = std::max<int64_t>(4096, e->rows / 16);
         e->d_dense.alloc((size_t)e->dense_cap);
         e->dense_cap = (int64_t)e->d_dense.cap;
+        if (e->ident_mode) {
+            // identity outputs for up to one record per 48 rows (a block is about a monomer long: ~170 rows); a batch
+            // with more records falls back to the text-based identities of the post-processing
+            int32_t maxlen = 1;
+            for (const sd::ChunkDesc& cd : e->chunks) maxlen = std::max(maxlen, cd.n);
+            const int per = e->ident_mode == 2 ? e->iT : 1;
+            e->ident_cap = std::min<int64_t>(e->dense_cap, std::max<int64_t>(4096, e->rows / 48));
+            e->d_recchunk.alloc((size_t)e->dense_cap);
+            e->d_ilong.alloc((size_t)e->ident_cap);
+            e->d_ilongcnt.alloc(1);
+            e->d_ident.alloc((size_t)e->ident_cap * per);
+            if (e->ident_mode == 2) e->d_identh.alloc((size_t)e->ident_cap * per);
+            auto fill_args = [&](sd::IdentArgs& a, bool homo) {
+                a = sd::IdentArgs{};
+                a.chunks = e->dp_chunks; a.bases2 = e->dp_bases2; a.nmask = e->dp_nmask;
+                a.dense = e->d_dense.p; a.rec_chunk = e->d_recchunk.p; a.total = e->d_roff.p + C;
+                a.rec_cap = e->ident_cap;
+                a.T = per; a.own = e->ident_mode == 1 ? e->d_iown.p : nullptr;
+                a.peq = homo ? e->d_ihpeq.p : e->d_ipeq.p;
+                a.tlen = homo ? e->d_ihtlen.p : e->d_itlen.p;
+                a.Tmask = e->iT; a.K = homo ? e->iKh : e->iK; a.homo = homo ? 1 : 0;
+                const int S = sd::nw_block_cols(a.K);
+                a.short_max = std::min<int>(512, maxlen);
+                a.cap_short = (a.short_max + S - 1) / S;
+                a.grid_short = e->n_cu * 3;
+                a.cap_long = (maxlen + S - 1) / S;
+                // the long launch: as many lanes as 192 MB of checkpoints allow, at most one workgroup per CU
+                const size_t per_block = (size_t)a.cap_long * 256 * ((size_t)a.K * 16 + 4);
+                a.grid_long = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->n_cu, ((size_t)192 << 20) / per_block));
+                a.long_cnt = e->d_ilongcnt.p; a.long_list = e->d_ilong.p;
+                a.out = homo ? e->d_identh.p : e->d_ident.p;
+            };
+            fill_args(e->ia_plain, false);
+            size_t lanes = sd::ident_ck_lanes(e->ia_plain) * (size_t)e->ia_plain.K;
+            size_t pos = sd::ident_ck_lanes(e->ia_plain);
+            if (e->ident_mode == 2) {
+                fill_args(e->ia_homo, true);
+                lanes = std::max(lanes, sd::ident_ck_lanes(e->ia_homo) * (size_t)e->ia_homo.K);
+                pos = std::max(pos, sd::ident_ck_lanes(e->ia_homo));
+            }
+            e->d_ick.alloc(lanes);
+            e->d_ickpos.alloc(pos);
+            e->ia_plain.ck = e->d_ick.p; e->ia_plain.ckpos = e->d_ickpos.p;
+            e->ia_homo.ck = e->d_ick.p; e->ia_homo.ckpos = e->d_ickpos.p;
+        }
         e->subs.clear();
         if (e->family == 1) {
             // pointer workspace: sub-batches of consecutive chunks within the budget
@@ -820,8 +934,16 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
             }
             SD_HIP(hipEventRecord(e->ev_cmp0, ts));
             sd::launch_compact(ts, e->dp_chunks, C, e->d_cnt.p, e->d_roff.p, e->d_recs.p,
-                               e->d_dense.p, e->dense_cap, true);
+                               e->d_dense.p, e->dense_cap, true, e->ident_mode ? e->d_recchunk.p : nullptr);
             SD_HIP(hipEventRecord(e->ev_cmp1, ts));
+            if (e->ident_mode) {   // identities of the final TSV on the batch's compact records (sd_ident.hip)
+                SD_HIP(hipEventRecord(e->ev_id0, ts));
+                e->ia_plain.dense = e->ia_homo.dense = e->d_dense.p;            // (a fetch may have grown them)
+                e->ia_plain.rec_chunk = e->ia_homo.rec_chunk = e->d_recchunk.p;
+                sd::launch_ident(ts, e->ia_plain);
+                if (e->ident_mode == 2) sd::launch_ident(ts, e->ia_homo);
+                SD_HIP(hipEventRecord(e->ev_id1, ts));
+            }
             // the record offsets travel right behind the compaction: the fetch then knows the record
             // count as soon as the stream is idle, without a second round trip
             SD_HIP(hipMemcpyAsync(e->h_roff.p, e->d_roff.p, sizeof(int64_t) * ((size_t)C + 1), hipMemcpyDeviceToHost, ts));
@@ -856,9 +978,11 @@ static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errle
         hipStream_t cs = e->copy_stream ? e->copy_stream : e->last_stream;
         if (C == 0) { e->h_roff.alloc(1); e->h_roff.p[0] = 0; return SD_OK; }
         total = e->h_roff.p[C];
+        e->ident_valid = e->ident_mode != 0 && total <= e->ident_cap && total <= e->dense_cap;
         if (total > e->dense_cap) {
             e->d_dense.alloc((size_t)total);
             e->dense_cap = (int64_t)e->d_dense.cap;
+            if (e->ident_mode) e->d_recchunk.alloc((size_t)e->dense_cap);   // a later run of the same load compacts into it
             sd::launch_compact(e->last_stream, e->dp_chunks, (int)C, e->d_cnt.p, e->d_roff.p,
                                e->d_recs.p, e->d_dense.p, e->dense_cap, false);
             SD_HIP(hipStreamSynchronize(e->last_stream));
@@ -867,6 +991,15 @@ static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errle
         static_assert(sizeof(sd_rec) == sizeof(sd::DevRec), "record layout");
         if (total > 0) {
             SD_HIP(hipMemcpyAsync(e->h_recs.p, e->d_dense.p, sizeof(sd_rec) * (size_t)total, hipMemcpyDeviceToHost, cs));
+            if (e->ident_valid) {
+                const size_t per = e->ident_mode == 2 ? (size_t)e->iT : 1;
+                e->h_ident.alloc((size_t)total * per);
+                SD_HIP(hipMemcpyAsync(e->h_ident.p, e->d_ident.p, sizeof(uint32_t) * (size_t)total * per, hipMemcpyDeviceToHost, cs));
+                if (e->ident_mode == 2) {
+                    e->h_identh.alloc((size_t)total * per);
+                    SD_HIP(hipMemcpyAsync(e->h_identh.p, e->d_identh.p, sizeof(uint32_t) * (size_t)total * per, hipMemcpyDeviceToHost, cs));
+                }
+            }
             SD_HIP(hipStreamSynchronize(cs));
         }
         if (e->score_scale != 1)
@@ -1022,6 +1155,9 @@ struct Pipeline {
     hipStream_t trace_st = nullptr;                // traceback + compaction of all batches (lower priority)
     bool streams_tried = false;
     RecSink sinks[NSMAX];
+    std::function<void(sd_engine*)> on_engine;     // called once for every engine the pipeline creates
+    // identities that came with the batch a sink is being called for (in-stream, sd_ident.hip); id == nullptr: none
+    struct IdentOut { const uint32_t* id = nullptr; const uint32_t* idh = nullptr; int per = 0; } cur_ident;
     uint64_t pushed = 0, popped = 0;
     char eb[1024] = {0};
     // accumulated over all batches: HIP-event kernel times (ms) and host stage times (s)
@@ -1034,7 +1170,9 @@ struct Pipeline {
         if (const char* ev = getenv("SD_PIPE_SLOTS")) NS = std::min(NSMAX, std::max(1, atoi(ev)));
         mseq.assign(mono_seqs, mono_seqs + n_mono);
         mlen.assign(mono_lens, mono_lens + n_mono);
-        return sd_engine_create(&eng[0], &p, mseq.data(), mlen.data(), n_mono, eb, sizeof eb);
+        const int rc = sd_engine_create(&eng[0], &p, mseq.data(), mlen.data(), n_mono, eb, sizeof eb);
+        if (rc == SD_OK && on_engine) on_engine(eng[0]);
+        return rc;
     }
     // rows one batch may hold: <= 64 M (~1200 reads of 50 kb, 18 GB of checkpoints) and <= 27 % of the free HBM.
     // The kernels are persistent -- 4096 resident waves pull chunks from a queue -- so a launch is efficient
@@ -1098,6 +1236,7 @@ struct Pipeline {
         if (!eng[k]) {
             rc = sd_engine_create(&eng[k], &p, mseq.data(), mlen.data(), (int32_t)mseq.size(), eb, sizeof eb);
             if (rc) return rc;
+            if (on_engine) on_engine(eng[k]);
         }
         make_streams();
         const double t0 = now_s();
@@ -1127,6 +1266,10 @@ struct Pipeline {
         ++batches;
         rows += eng[k]->rows;
         t0 = now_s();
+        cur_ident = IdentOut{};
+        if (eng[k]->ident_valid)
+            cur_ident = IdentOut{eng[k]->h_ident.p, eng[k]->ident_mode == 2 ? eng[k]->h_identh.p : nullptr,
+                                 eng[k]->ident_mode == 2 ? eng[k]->iT : 1};
         if (sinks[k]) sinks[k](eng[k]->h_recs.p, eng[k]->h_roff.p, eng[k]->chunks.size());
         sinks[k] = nullptr;
         sink_s += now_s() - t0;
@@ -1607,24 +1750,51 @@ struct RowJob {
     int32_t chunks_seen = 0;      // chunks of next_read already in carry
     int batches_left = 0;
     bool oom = false;
-    ~RowJob() { std::free(rows); std::free(row_off); }
+    // In-stream identities (sd_ident.hip) follow their records through the merge: `per` words per record in up to two
+    // arrays (plain / homopolymer-compressed).  per == 0: not tracked.  bid / bidh = the arrays of the batch being
+    // added (set by the caller before add); rid / ridh = the words of the assembled rows, [n_rows][per], malloc'ed.
+    int per = 0;
+    const uint32_t* bid = nullptr;
+    const uint32_t* bidh = nullptr;
+    uint32_t* rid = nullptr;
+    uint32_t* ridh = nullptr;
+    bool ident_ok = true;         // every batch of the rows assembled so far came with identities
+    std::vector<uint32_t> carry_id, carry_idh;
+    std::vector<int64_t> src_tmp, carry_src;
+    ~RowJob() { std::free(rows); std::free(row_off); std::free(rid); std::free(ridh); }
     void reserve(size_t need) {
         if (need <= cap_rows) return;
         size_t nc = std::max<size_t>(need, cap_rows * 2 + 4096);
         sd_rec* q = static_cast<sd_rec*>(std::realloc(rows, nc * sizeof(sd_rec)));
         if (!q) { oom = true; return; }
         rows = q;
+        if (per) {
+            uint32_t* a = static_cast<uint32_t*>(std::realloc(rid, nc * (size_t)per * sizeof(uint32_t)));
+            if (!a) { oom = true; return; }
+            rid = a;
+            uint32_t* h = static_cast<uint32_t*>(std::realloc(ridh, nc * (size_t)per * sizeof(uint32_t)));
+            if (!h) { oom = true; return; }
+            ridh = h;
+        }
         cap_rows = nc;
     }
-    void emit(size_t read, const sd_rec* r, size_t n) {
-        reserve(n_rows + n);
-        if (oom) return;
-        if (n) std::memcpy(rows + n_rows, r, n * sizeof(sd_rec));
-        n_rows += n;
-        row_off[read + 1] = (int64_t)n_rows;
+    // words of record `x` of the current batch / of the carry -> the words of row `row`
+    void put_ident(size_t row, const uint32_t* from, const uint32_t* fromh, int64_t x) {
+        if (!per) return;
+        if (from) std::memcpy(rid + row * (size_t)per, from + (size_t)x * (size_t)per, (size_t)per * sizeof(uint32_t));
+        if (fromh) std::memcpy(ridh + row * (size_t)per, fromh + (size_t)x * (size_t)per, (size_t)per * sizeof(uint32_t));
+    }
+    void carry_push(const sd_rec& t, int64_t x) {
+        carry.push_back(t);
+        if (!per) return;
+        if (!bid) { ident_ok = false; carry_id.resize(carry.size() * (size_t)per, 0u); carry_idh.resize(carry.size() * (size_t)per, 0u); return; }
+        carry_id.insert(carry_id.end(), bid + (size_t)x * (size_t)per, bid + (size_t)(x + 1) * (size_t)per);
+        if (bidh) carry_idh.insert(carry_idh.end(), bidh + (size_t)x * (size_t)per, bidh + (size_t)(x + 1) * (size_t)per);
+        else carry_idh.resize(carry.size() * (size_t)per, 0u);
     }
     void add(size_t c0, size_t c1, const sd_rec* recs, const int64_t* roff) {
         size_t c = c0;
+        if (per && !bid) ident_ok = false;
         // (1) the read that began in an earlier batch
         if (chunks_seen > 0) {
             while (c < c1 && chunks_seen < nch[next_read]) {
@@ -1632,13 +1802,23 @@ struct RowJob {
                 for (int64_t x = roff[c - c0]; x < roff[c - c0 + 1]; ++x) {
                     sd_rec t = recs[x];
                     t.start += add; t.end += add;
-                    carry.push_back(t);
+                    carry_push(t, x);
                 }
                 ++c; ++chunks_seen;
             }
             if (chunks_seen < nch[next_read]) return;  // still open
-            emit(next_read, carry.data(), sd::seam_merge_inplace(carry.data(), carry.size()));
+            carry_src.resize(carry.size());
+            for (size_t k = 0; k < carry.size(); ++k) carry_src[k] = (int64_t)k;
+            const size_t n = sd::seam_merge_inplace(carry.data(), carry_src.data(), carry.size());
+            reserve(n_rows + n);
+            if (oom) return;
+            if (n) std::memcpy(rows + n_rows, carry.data(), n * sizeof(sd_rec));
+            for (size_t k = 0; k < n; ++k) put_ident(n_rows + k, carry_id.data(), carry_idh.data(), carry_src[k]);
+            n_rows += n;
+            row_off[next_read + 1] = (int64_t)n_rows;
             carry.clear();
+            carry_id.clear();
+            carry_idh.clear();
             chunks_seen = 0;
             ++next_read;
         }
@@ -1654,29 +1834,41 @@ struct RowJob {
         if (!items.empty()) {
             const int64_t lo = roff[c - c0], hi = roff[cc - c0];
             tmp.resize((size_t)(hi - lo));
+            if (per) src_tmp.resize((size_t)(hi - lo));
             sd::parallel_for((int64_t)items.size(), threads, 8, [&](int64_t q) {
                 Item& it = items[(size_t)q];
                 sd_rec* dst = tmp.data() + (roff[it.ca - c0] - lo);
+                int64_t* sdst = per ? src_tmp.data() + (roff[it.ca - c0] - lo) : nullptr;
                 size_t k = 0;
                 for (size_t ch = it.ca; ch < it.cb; ++ch) {
                     const int32_t add = (int32_t)table[ch].off;
                     for (int64_t x = roff[ch - c0]; x < roff[ch - c0 + 1]; ++x) {
                         sd_rec t = recs[x];
                         t.start += add; t.end += add;
+                        if (sdst) sdst[k] = x;
                         dst[k++] = t;
                     }
                 }
-                it.n = sd::seam_merge_inplace(dst, k);
+                it.n = sdst ? sd::seam_merge_inplace(dst, sdst, k) : sd::seam_merge_inplace(dst, k);
             });
             size_t total = 0;
             for (const Item& it : items) total += it.n;
             reserve(n_rows + total);
             if (oom) return;
-            for (const Item& it : items) {
+            std::vector<size_t> at(items.size());
+            for (size_t q = 0; q < items.size(); ++q) {
+                const Item& it = items[q];
+                at[q] = n_rows;
                 std::memcpy(rows + n_rows, tmp.data() + (roff[it.ca - c0] - lo), it.n * sizeof(sd_rec));
                 n_rows += it.n;
                 row_off[it.read + 1] = (int64_t)n_rows;
             }
+            if (per && bid)   // the identity words of the kept records, gathered by all threads (2 T words per row with --second-best)
+                sd::parallel_for((int64_t)items.size(), threads, 8, [&](int64_t q) {
+                    const Item& it = items[(size_t)q];
+                    const int64_t* sp = src_tmp.data() + (roff[it.ca - c0] - lo);
+                    for (size_t k = 0; k < it.n; ++k) put_ident(at[(size_t)q] + k, bid, bidh, sp[k]);
+                });
             next_read = r;
             c = cc;
         }
@@ -1686,7 +1878,7 @@ struct RowJob {
             for (int64_t x = roff[c - c0]; x < roff[c - c0 + 1]; ++x) {
                 sd_rec t = recs[x];
                 t.start += add; t.end += add;
-                carry.push_back(t);
+                carry_push(t, x);
             }
             ++c; ++chunks_seen;
         }
@@ -1992,15 +2184,22 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         return SD_ERR_INTERNAL;
     }
     Pipeline pipe;
+    // identities of the final TSV in-stream, behind every batch's compaction (sd_ident.hip); template sets the kernel
+    // does not take (and SD_IDENT_STREAM=0, developer A/B) leave them to the post-processing as in round 2
+    bool stream_ident = !(getenv("SD_IDENT_STREAM") && getenv("SD_IDENT_STREAM")[0] == '0');
+    pipe.on_engine = [&](sd_engine* e) {
+        if (stream_ident && !engine_set_identity(e, pp.interleaved_seqs(), pp.own_interleaved(), second_best != 0)) stream_ident = false;
+    };
     rc = pipe.create(p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size());
     if (rc) err = pipe.eb;
+    if (stream_ident) job.per = second_best ? (int)pp.interleaved_seqs().size() : 1;
     std::vector<std::pair<size_t, size_t>> batches;
     if (rc == SD_OK) plan_batches(job.table, 0, job.table.size(), pipe.row_budget(), 1, batches);
     lap("chunk table, engine");
     // The rows of a batch are assembled on the driver thread (they come out of the engine's pinned buffer, which
     // the next load reuses) and handed to a second host thread that turns them into the three texts and writes
     // them, while the driver packs and enqueues the next batch.  At most two batches wait in the hand-over.
-    struct Work { size_t r0, r1; sd_rec* rows; std::vector<int64_t> off; };
+    struct Work { size_t r0, r1; sd_rec* rows; std::vector<int64_t> off; uint32_t* id; uint32_t* idh; };
     std::mutex wq_m;
     std::condition_variable wq_cv;
     std::deque<Work> wq;
@@ -2045,7 +2244,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
                 for (size_t r = w.r0; r < w.r1; ++r)
                     preads.push_back(sd::PostRead{reads[r].name, reads[r].name_len, reads[r].seq, reads[r].len});
                 std::string e2;
-                const int r2 = pp.process(preads.data(), preads.size(), w.rows, off, fin, alt, e2);
+                const int r2 = pp.process(preads.data(), preads.size(), w.rows, off, fin, alt, e2, w.id, second_best ? w.idh : nullptr);
                 t_post += now_s() - t0;
                 t0 = now_s();
                 if (r2) {
@@ -2060,6 +2259,8 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
                 t_io += now_s() - t0;
             }
             std::free(w.rows);
+            std::free(w.id);
+            std::free(w.idh);
         }
     };
     std::thread sink_thread(sink_loop);
@@ -2068,6 +2269,8 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         const size_t r0 = job.next_read;
         job.n_rows = 0;
         job.row_off[r0] = 0;
+        job.bid = pipe.cur_ident.id;
+        job.bidh = pipe.cur_ident.idh;
         job.add(c0, c1, recs, roff);
         if (job.oom) { sink_err = "out of host memory"; sink_rc.store(SD_ERR_INTERNAL); return; }
         const size_t r1 = job.next_read;
@@ -2077,6 +2280,13 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         w.r1 = r1;
         w.rows = job.rows;
         w.off.assign(job.row_off + r0, job.row_off + r1 + 1);
+        // identities that came with the batches of these rows; a batch without them (more records than the outputs
+        // had room for) sends the whole hand-over through the text-based identities
+        w.id = job.per && job.ident_ok ? job.rid : nullptr;
+        w.idh = job.per && job.ident_ok ? job.ridh : nullptr;
+        if (!w.id) { std::free(job.rid); std::free(job.ridh); }
+        job.rid = job.ridh = nullptr;
+        job.ident_ok = job.carry.empty() || job.bid != nullptr;
         job.rows = nullptr;       // the next batch assembles into a fresh (or recycled) buffer
         job.cap_rows = 0;
         job.n_rows = 0;

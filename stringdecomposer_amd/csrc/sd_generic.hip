@@ -445,20 +445,22 @@ __global__ __launch_bounds__(1024) void sd_scan_counts(const int32_t* __restrict
 
 __global__ void sd_compact(const ChunkDesc* __restrict__ chunks, const int32_t* __restrict__ cnt,
                            const int64_t* __restrict__ roff, const DevRec* __restrict__ recs,
-                           DevRec* __restrict__ out, int64_t out_cap) {
+                           DevRec* __restrict__ out, int64_t out_cap, int32_t* __restrict__ out_chunk) {
     const int c = blockIdx.x;
     const int k = cnt[c];
     if (roff[c] + k > out_cap) return;  // host re-runs the compaction with a larger buffer
     const DevRec* src = recs + chunks[c].row0;
     DevRec* dst = out + roff[c];
     for (int a = threadIdx.x; a < k; a += blockDim.x) dst[a] = src[k - 1 - a];  // reverse, main.cpp:268
+    if (out_chunk)   // in-stream identities (sd_ident.hip): which chunk's bases a record's segment lies in
+        for (int a = threadIdx.x; a < k; a += blockDim.x) out_chunk[roff[c] + a] = c;
 }
 
 void launch_compact(hipStream_t st, const ChunkDesc* chunks, int n_chunks, const int32_t* cnt,
-                    int64_t* roff, const DevRec* recs, DevRec* out, int64_t out_cap, bool scan) {
+                    int64_t* roff, const DevRec* recs, DevRec* out, int64_t out_cap, bool scan, int32_t* out_chunk) {
     if (scan) hipLaunchKernelGGL(sd_scan_counts, dim3(1), dim3(1024), 0, st, cnt, n_chunks, roff);
     hipLaunchKernelGGL(sd_compact, dim3(n_chunks), dim3(64), 0, st, chunks, cnt, roff, recs, out,
-                       out_cap);
+                       out_cap, out_chunk);
 }
 
 }  // namespace sd

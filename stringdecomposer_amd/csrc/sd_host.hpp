@@ -111,6 +111,24 @@ inline size_t seam_merge_inplace(sd_rec* b, size_t N) {
     return w;
 }
 inline void seam_merge(std::vector<sd_rec>& b) { b.resize(seam_merge_inplace(b.data(), b.size())); }
+// the same merge with a parallel array that follows the records (where a kept record came from)
+inline size_t seam_merge_inplace(sd_rec* b, int64_t* src, size_t N) {
+    size_t w = 0, i = 0;
+    while (i < N) {
+        const size_t lim = i + 7 < N ? i + 7 : N;
+        for (size_t j = i + 1; j < lim; ++j) {
+            if ((b[i].end - b[j].start) * 2 > (b[j].end - b[j].start)) {
+                src[w] = src[i];
+                b[w++] = b[i];
+                i = j + 1;
+                break;
+            }
+        }
+        if (i < N) { src[w] = src[i]; b[w++] = b[i]; }
+        ++i;
+    }
+    return w;
+}
 
 // Text of a batch: a byte vector whose resize() does not zero-fill (the parts of a batch are copied into it by
 // all threads; a std::string would first write 200 MB of zeros for the _alt rows of a --second-best batch).

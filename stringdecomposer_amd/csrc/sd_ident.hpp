@@ -1,0 +1,42 @@
+// sd_ident.hpp -- in-stream identities (sd_ident.hip): the identity kernel of sd_nw_kernel.hpp run on the compact
+// records of a device batch, right behind the compaction, reading the 2-bit reads the DP already holds in HBM.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "sd_device.hpp"
+
+namespace sd {
+
+struct IdentArgs {
+    const ChunkDesc* chunks;
+    const uint32_t* bases2;
+    const uint32_t* nmask;
+    const DevRec* dense;            // compact records (chunk-local coordinates)
+    const int32_t* rec_chunk;       // chunk of every compact record
+    const int64_t* total;           // device: number of compact records (roff[C])
+    int64_t rec_cap;                // records the outputs have room for
+    int T;                          // templates per record: 1 (own template, `own` maps the DP's template index) or all
+    const int32_t* own;
+    const unsigned long long* peq;  // [Tmask][5][K], top-aligned (nw_build_masks)
+    const int32_t* tlen;
+    int Tmask;
+    int K;
+    int homo;
+    int short_max, cap_short, grid_short;   // first launch: segments of up to short_max symbols
+    int cap_long, grid_long;                // second launch: the records the first one put on the list
+    void* ck;                       // checkpoint workspace, max(grid * 256 * cap) * K * 16 B
+    int* ckpos;                     // max(grid * 256 * cap) ints
+    int* long_cnt;                  // zeroed by launch_ident
+    int32_t* long_list;             // rec_cap entries
+    uint32_t* out;                  // [record][T]: (dist << 16) | matches; IDENT_NONE where nothing was computed
+};
+constexpr uint32_t IDENT_NONE = 0xffffffffu;
+
+void launch_ident(hipStream_t st, const IdentArgs& a);
+// bytes of checkpoint workspace (ck) and ints of ckpos for the two launches of launch_ident
+size_t ident_ck_lanes(const IdentArgs& a);
+
+}  // namespace sd

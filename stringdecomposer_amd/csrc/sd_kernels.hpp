@@ -19,6 +19,7 @@ void launch_generic_trace(int n_sub, hipStream_t st, const ChunkDesc* chunks, in
                           const int32_t* argB, const int32_t* toff, const int32_t* tlen,
                           DevRec* recs, int32_t* rec_cnt);
 void launch_compact(hipStream_t st, const ChunkDesc* chunks, int n_chunks, const int32_t* cnt,
-                    int64_t* roff, const DevRec* recs, DevRec* out, int64_t out_cap, bool scan);
+                    int64_t* roff, const DevRec* recs, DevRec* out, int64_t out_cap, bool scan,
+                    int32_t* out_chunk = nullptr);
 
 }  // namespace sd

@@ -10,6 +10,10 @@
 
 namespace sd {
 
+// columns per register-resident block of the identity kernel (sd_nw_kernel.hpp): S * K * 4 history registers;
+// a pair of q columns needs ceil(q / S) - 1 checkpoint slots
+__host__ __device__ constexpr int nw_block_cols(int K) { return K <= 1 ? 16 : K == 2 ? 12 : K == 3 ? 9 : K == 4 ? 6 : K <= 6 ? 4 : 3; }
+
 // One lane per (segment, template) pair; K = 64-bit words per template (ceil(max tlen / 64): 1, 2, 3, 4, 6, 8).
 // ck / ckpos: grid * 256 lanes x cap checkpoint slots x (K x 16 B + 4 B); peq: [T][5][K], top-aligned
 // (nw_build_masks); seg_idx (optional): the segments of this launch.

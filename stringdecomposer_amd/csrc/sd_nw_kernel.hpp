@@ -31,10 +31,10 @@
 
 #include <cstdint>
 
+#include "sd_nw.hpp"
+
 namespace sd {
 
-// columns per register-resident block: S * K * 4 history registers
-__host__ __device__ constexpr int nw_block_cols(int K) { return K <= 1 ? 16 : K == 2 ? 12 : K == 3 ? 9 : K == 4 ? 6 : K <= 6 ? 4 : 3; }
 
 template <int K>
 struct NwState {
