@@ -103,6 +103,12 @@ int sd_run_files_range(const char* reads_fa, const char* monomers_fa, const sd_p
                        int32_t world, const char* raw_tsv_out, const char* final_tsv_out,
                        const char* alt_tsv_out, int32_t min_identity, int32_t second_best,
                        const double* lr_coef, int64_t* info, char* errbuf, size_t errlen);
+/* Stage times (ms) of the last sd_run_files / sd_run_files_range call of this process: [0] fill, [1] traceback,
+ * [2] compaction, [3] in-stream identity kernels (HIP events, summed over the batches), [4] identity pairs computed
+ * in-stream, [5] device batches, [6] DP rows, [7] pack + enqueue, [8] waits for the device, [9] raw text,
+ * [10] post-processing, [11] file writes, [12] text-based identities (0 when they all came in-stream), [13] final /
+ * _alt text, [14] whole call, [15] device / pinned allocations.  Measurement only (bench.py, tools/). */
+void sd_last_run_stats(double out[16]);
 
 /* convert_tsv (main.py:168-184) alone: an existing raw TSV + the two FASTA files -> final TSV and _alt TSV,
  * streamed in batches of reads.  device < 0: host identities (sd_identity_segments). */

@@ -1161,7 +1161,8 @@ struct Pipeline {
     uint64_t pushed = 0, popped = 0;
     char eb[1024] = {0};
     // accumulated over all batches: HIP-event kernel times (ms) and host stage times (s)
-    double fill_ms = 0, trace_ms = 0, compact_ms = 0, run_ms = 0;
+    double fill_ms = 0, trace_ms = 0, compact_ms = 0, run_ms = 0, ident_ms = 0;
+    int64_t ident_pairs = 0;
     double pack_s = 0, wait_s = 0, sink_s = 0;
     int64_t launches = 0, batches = 0, rows = 0;
 
@@ -1262,6 +1263,11 @@ struct Pipeline {
         if (rc) return rc;
         float ms[4];
         if (sd_engine_timings(eng[k], ms) == SD_OK) { fill_ms += ms[0]; trace_ms += ms[1]; compact_ms += ms[2]; run_ms += ms[3]; }
+        if (eng[k]->ident_mode && !eng[k]->chunks.empty()) {
+            float im = 0.f;
+            if (hipEventElapsedTime(&im, eng[k]->ev_id0, eng[k]->ev_id1) == hipSuccess) ident_ms += im;
+            if (eng[k]->ident_valid) ident_pairs += total * (eng[k]->ident_mode == 2 ? 2 * (int64_t)eng[k]->iT : 1);
+        }
         launches += eng[k]->fill_launches;
         ++batches;
         rows += eng[k]->rows;
@@ -2090,6 +2096,10 @@ int32_t sd_pack_bases(const char* seq, int64_t n, uint32_t* words, uint32_t* nma
 // past the last read, [2] reads in the file, [3] chunks of this rank.  A read set that cannot be split by
 // reads (one read holds more than half a rank's share, e.g. a single chromosome) gives SD_ERR_UNSUPPORTED
 // before anything is written; the caller then shards by chunk range instead.
+// stage times of the last sd_run_files / sd_run_files_range call of this process (sd_last_run_stats)
+static std::mutex g_last_m;
+static double g_last_run[16] = {0};
+
 static int run_files_impl(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank, int32_t world,
                           const char* raw_tsv_out, const char* final_tsv_out, const char* alt_tsv_out,
                           int32_t min_identity, int32_t second_best, const double* lr_coef, int64_t* info,
@@ -2329,6 +2339,14 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     if (timing)
         std::fprintf(stderr, "[sd timing] post-processing: segments %.1f ms, identities %.1f ms, text %.1f ms, concatenation %.1f ms\n",
                      pp.t_prepare * 1e3, pp.t_identity * 1e3, pp.t_format * 1e3, pp.t_concat * 1e3);
+    {
+        std::lock_guard<std::mutex> lk(g_last_m);
+        const double v[16] = {pipe.fill_ms, pipe.trace_ms, pipe.compact_ms, pipe.ident_ms, (double)pipe.ident_pairs,
+                              (double)pipe.batches, (double)pipe.rows, pipe.pack_s * 1e3, pipe.wait_s * 1e3, t_fmt * 1e3,
+                              t_post * 1e3, t_io * 1e3, pp.t_identity * 1e3, pp.t_format * 1e3, (now_s() - t_begin) * 1e3,
+                              (double)g_alloc_ns.load() / 1e6};
+        std::memcpy(g_last_run, v, sizeof v);
+    }
     if (timing) {
         double nw[4];
         sd::nw_stage_seconds(nw);
@@ -2337,6 +2355,11 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     }
     if (rc) { set_err(errbuf, errlen, err); return rc; }
     return SD_OK;
+}
+
+void sd_last_run_stats(double out[16]) {
+    std::lock_guard<std::mutex> lk(g_last_m);
+    std::memcpy(out, g_last_run, sizeof g_last_run);
 }
 
 int sd_run_files(const char* reads_fa, const char* monomers_fa, const sd_params* p, const char* raw_tsv_out,

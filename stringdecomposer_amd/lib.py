@@ -32,7 +32,7 @@ EXPORTS = [
     "sd_fasta_free", "sd_nw_identity_batch", "sd_identity_segments", "sd_chunk_table_size",
     "sd_decompose_chunk_range", "sd_assemble_tsv", "sd_release_cache", "sd_format_alt_rows",
     "sd_stream_create", "sd_stream_destroy", "sd_stream_submit", "sd_stream_collect", "sd_stream_stats",
-    "sd_stream_info", "sd_pack_bases", "sd_identity_segments_dev", "sd_nw_release_cache",
+    "sd_stream_info", "sd_pack_bases", "sd_identity_segments_dev", "sd_nw_release_cache", "sd_last_run_stats",
     "sd_run_files", "sd_convert_raw_tsv", "sd_decompose_files_range", "sd_assemble_files_tsv",
     "sd_host_stage_rates", "sd_run_files_range", "sd_plan_info",
 ]
@@ -222,6 +222,16 @@ def run_files(reads_fa, monomers_fa, raw_tsv_out, final_tsv_out, alt_tsv_out, mi
                         coef, err, 4096)
     if rc != SD_OK:
         raise SdError(rc, err.value.decode(errors="replace"))
+
+
+def last_run_stats():
+    """Stage times of the last run_files / run_files_range call of this process (sd_last_run_stats)."""
+    L = load()
+    v = (C.c_double * 16)()
+    L.sd_last_run_stats(v)
+    keys = ("fill_ms", "trace_ms", "compact_ms", "ident_ms", "ident_pairs", "batches", "rows", "pack_ms", "wait_ms",
+            "raw_text_ms", "post_ms", "io_ms", "text_identity_ms", "final_text_ms", "total_ms", "alloc_ms")
+    return dict(zip(keys, [float(x) for x in v]))
 
 
 def run_files_range(reads_fa, monomers_fa, rank, world, raw_tsv_out, final_tsv_out, alt_tsv_out, min_identity=0,

@@ -145,7 +145,8 @@ def emit(work, name, reads_fa, mono_fa, extra, inputs_rel, keep_alt):
                                                       meta["alt_sha256"][:16], len(alt)))
 
 
-def main():
+def prepare():
+    """Scratch copy of the reference with its binary in place and the two shim packages -> the scratch directory."""
     ob.build()
     if not (ob.have_ref_dp() and os.path.isfile(ob.REF_EDLIB)):
         raise SystemExit("needs oracle/_ref (make -C oracle ref), i.e. /root/reference")
@@ -160,6 +161,11 @@ def main():
                     ("Bio/SeqRecord.py", BIO_SEQRECORD), ("Bio/SeqIO.py", BIO_SEQIO)):
         with open(os.path.join(sh, fn), "w") as f:
             f.write(txt)
+    return work
+
+
+def main():
+    work = prepare()
     rf, mf = os.path.join(TD, "read.fa"), os.path.join(TD, "DXZ1_star_monomers.fa")
     rel = ["test_data/read.fa", "test_data/DXZ1_star_monomers.fa"]
     emit(work, "td_second_best", rf, mf, ["--second-best"], rel, keep_alt=False)
