@@ -291,13 +291,12 @@ def main():
     def timed_steps(pipe_mode, steps, warmup, bracket):
         """K pipelined steps of the stream in the given kernel-stream mode; returns (seconds, rows of the
         last step, stats delta, info)."""
-        # SD_PIPE_MODE (read by the library when a stream starts its first batch): 0 = all kernels of all
+        # pipe_mode (sd_params.reserved[0]): 0 = all kernels of all
         # batches in order on one HIP stream (per-kernel event spans are clean); 2 = the library default:
         # traceback + compaction on a second, lower-priority stream and consecutive fills on two streams, the
         # next fill moving in as the current one drains (5-7 % faster, but the kernels' event spans overlap)
-        os.environ["SD_PIPE_MODE"] = str(pipe_mode)
         st = lib.Stream(ms, sub_batches=args.sub_batches, device=local_rank, kernel=kernel, threads=threads,
-                        ed_thr=args.ed_thr)
+                        ed_thr=args.ed_thr, pipe_mode=pipe_mode)
         inf = st.info()
         for _ in range(max(warmup, 2)):   # at least one step per pipeline slot: buffers of both engines exist
             st.submit(readset)

@@ -44,8 +44,20 @@ typedef struct sd_params {
     int32_t device;                    /* HIP device ordinal                                      */
     int32_t kernel;                    /* 0 auto, 1 generic family (int32, workgroup per chunk), 2 fast family (packed 16-bit cells, wave(s) per chunk) */
     int32_t max_batch_rows;            /* 0 = size device batches from free HBM; >0 = cap on chunk rows per batch */
+    /* Switches that have no counterpart in the reference's argv (all 0 = the defaults):
+     *   reserved[0]  kernel streams of the batch pipeline: 0 default (SD_PIPE_* below), else mode + 1
+     *                (1: every kernel in order on one stream, 2: traceback on a second stream, 3: fills alternating too)
+     *   reserved[1]  SD_FLAG_* bits
+     *   reserved[2]  fp16 range guard of the fills: magnitude limit (0 = 2040); a smaller value makes the guard trip
+     *                on ordinary input -- the test hook of the guard and of the re-run with integer cells
+     *   reserved[3..4] must be 0 */
     int32_t reserved[5];
 } sd_params;
+#define SD_FLAG_NO_F16 1           /* no fp16 cell format: integer cells (or the generic family)                   */
+#define SD_FLAG_FULL_FLOOR 2       /* fills that take the start-term maximum in every slot (A/B of the FL variants) */
+#define SD_FLAG_NO_EDTHR_COMPACT 4 /* --ed_thr with > 128 templates: every chunk on the W-wave ranked kernel        */
+#define SD_FLAG_FILTER_GENERAL 8   /* --ed_thr: the general prefilter kernel instead of the uniform one             */
+#define SD_FLAG_NO_STREAM_IDENT 16 /* sd_run_files: identities from the read text in the post-processing (round 2)  */
 
 void sd_params_default(sd_params* p); /* -1,-1,-1,1 / 5000 / 500 / -1 / 1 / 0 / auto */
 
@@ -108,6 +120,9 @@ int sd_run_files_range(const char* reads_fa, const char* monomers_fa, const sd_p
  * in-stream, [5] device batches, [6] DP rows, [7] pack + enqueue, [8] waits for the device, [9] raw text,
  * [10] post-processing, [11] file writes, [12] text-based identities (0 when they all came in-stream), [13] final /
  * _alt text, [14] whole call, [15] device / pinned allocations.  Measurement only (bench.py, tools/). */
+/* Batches of this process that were repeated with integer cells because the fp16 range guard of a fill tripped
+ * (0 unless sd_params.reserved[2] lowers the limit, or the layout plan's range bound is wrong). */
+int64_t sd_guard_trips(void);
 void sd_last_run_stats(double out[16]);
 
 /* convert_tsv (main.py:168-184) alone: an existing raw TSV + the two FASTA files -> final TSV and _alt TSV,
@@ -194,7 +209,9 @@ int sd_engine_info(sd_engine* e, int64_t info[8]);
 /* Host only (no device needed): the layout sd_engine_create would choose for this monomer set and scoring.
  * info: [0] kernel family of "auto" (2 fast, 1 generic; generic: the reason is in errbuf, rc is still SD_OK)
  * [1] slots per lane P [2] cell arithmetic code (as sd_engine_info [4] >> 8) [3] last slot of a lane that needs
- * the maximum with the start term [4] waves per chunk [5] cells in the shortest first lane of a template
+ * the maximum with the start term [4] low byte: waves per chunk; bits 8..: the proven bound on the magnitude of a
+ * stored cell (fp16 cell formats are chosen when it is <= 2040; tests/test_host_cpu.py checks it against the
+ * recurrence itself) [5] cells in the shortest first lane of a template
  * [6] cells in the fullest lane [7] common factor divided out of the four scores. */
 int sd_plan_info(const sd_params* p, const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono,
                  int64_t info[8], char* errbuf, size_t errlen);

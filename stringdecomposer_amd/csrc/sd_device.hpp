@@ -17,6 +17,11 @@ struct ChunkDesc {
 // scoring, kept as plain ints in kernel arguments
 struct ScoreArgs {
     int32_t ins, del, mismatch, match;
+    // fp16 cell formats only (sd_fast_dev.hpp: F16Guard): the magnitude every stored cell must stay below for the
+    // arithmetic to be exact, and the device flag a wave raises when one does not (the host then repeats the batch
+    // with integer cells)
+    int32_t guard_lim = 0;
+    int* guard_flag = nullptr;
 };
 
 // Device-side record as emitted by the traceback kernels (emission order = reverse read order).

@@ -211,6 +211,8 @@ struct sd_engine {
     DevBuf<int> d_orders, d_cls;
     bool compact_edthr = false;
     int filter_uniform = -1;         // prefilter: -1 general kernel; 0 / 1 every template ends in the low / high half of the same word
+    DevBuf<int> d_guard;             // fp16 range guard of the fills: raised by a wave whose cells left the exact range
+    PinBuf<int> h_guard;
     DevBuf<int> d_queue;             // work-queue heads of the persistent kernels: a fresh zeroed (fill, trace) pair per run
     int q_run = 0;                   // pairs handed out since the array was last zeroed
     static constexpr int QN = 2048;
@@ -258,6 +260,7 @@ struct sd_engine {
 
     // run state
     hipStream_t last_stream = nullptr;
+    hipStream_t run_st = nullptr, run_ts = nullptr;   // streams of the last run (a guard trip repeats it on them)
     hipStream_t copy_stream = nullptr;   // pipeline: H2D of the batch / D2H of its records (not owned)
     bool lds_gate = false;               // pipeline mode 2: the fill asks for LDS that admits two workgroups per CU only
     bool ran = false;
@@ -296,6 +299,23 @@ void ensure_events(std::vector<hipEvent_t>& v, size_t pairs) {
         SD_HIP(hipEventCreate(&e));
         v.push_back(e);
     }
+}
+
+// Developer overrides of sd_params.reserved[] from the environment, read HERE and nowhere else (the switches are part
+// of the parameters; the variables exist so that a test or an A/B run can flip one without touching the caller):
+// SD_PIPE_MODE=0|1|2, SD_FILL_CELLS=i16, SD_FILL_FULLFLOOR=1, SD_EDTHR_COMPACT=0, SD_FILTER_GENERAL=1, SD_IDENT_STREAM=0,
+// SD_F16_GUARD=<limit>.
+void apply_env_overrides(sd_params& p) {
+    if (p.reserved[0] == 0)
+        if (const char* ev = getenv("SD_PIPE_MODE")) p.reserved[0] = std::max(0, std::min(2, atoi(ev))) + 1;
+    auto on = [](const char* name, char c) { const char* e = getenv(name); return e && e[0] == c; };
+    if (on("SD_FILL_CELLS", 'i')) p.reserved[1] |= SD_FLAG_NO_F16;
+    if (getenv("SD_FILL_FULLFLOOR")) p.reserved[1] |= SD_FLAG_FULL_FLOOR;
+    if (on("SD_EDTHR_COMPACT", '0')) p.reserved[1] |= SD_FLAG_NO_EDTHR_COMPACT;
+    if (getenv("SD_FILTER_GENERAL")) p.reserved[1] |= SD_FLAG_FILTER_GENERAL;
+    if (on("SD_IDENT_STREAM", '0')) p.reserved[1] |= SD_FLAG_NO_STREAM_IDENT;
+    if (p.reserved[2] == 0)
+        if (const char* ev = getenv("SD_F16_GUARD")) p.reserved[2] = std::max(0, atoi(ev));
 }
 
 int validate_params(const sd_params* p, std::string& err) {
@@ -354,6 +374,45 @@ void build_generic_tables(sd_engine* e) {
 
 }  // namespace
 
+// Kernel family and layout plan of an engine (sd_params.kernel: 0 auto, 1 generic, 2 fast) and their tables on the
+// device.  allow_f16 = false: no fp16 cell format (the fills' range guard tripped, or sd_params.reserved[1] bit 0).
+static int engine_pick_family(sd_engine* e, bool allow_f16, std::string& err) {
+    const sd_params* p = &e->p;
+    int family = p->kernel;
+    std::string why;
+    const bool no_f16 = !allow_f16 || (p->reserved[1] & SD_FLAG_NO_F16);
+    const bool fast_ok = sd::fast_plan_build(e->tseq, e->sc, p->part_size + p->overlap, e->fplan, why, !no_f16);
+    e->fplan.full_floor = (p->reserved[1] & SD_FLAG_FULL_FLOOR) != 0;
+    if (family == 0) family = fast_ok ? 2 : 1;
+    if (family == 2 && !fast_ok) { err = "fast kernel family not applicable: " + why; return SD_ERR_UNSUPPORTED; }
+    if (family != 1 && family != 2) { err = "bad kernel family"; return SD_ERR_PARAM; }
+    if (p->ed_thr > -1 && e->Lmax > 512) { err = "--ed_thr supports templates of up to 512 bp"; return SD_ERR_UNSUPPORTED; }
+    if (e->T > 65534) { err = "more than 65534 templates"; return SD_ERR_UNSUPPORTED; }
+    e->family = family;
+    e->d_toff.upload(e->toff);
+    e->d_tlen.upload(e->tlen);
+    if (family == 1) {
+        e->Q = sd::generic_pick_q(e->sumL);
+        build_generic_tables(e);
+    } else {
+        e->d_ftable.upload(e->fplan.table);
+        e->d_flane.upload(e->fplan.lane_consts);
+        e->d_fslot.upload(e->fplan.slot_of);
+        e->d_ftcodes.upload(e->fplan.tcodes);
+        if (p->ed_thr > -1) {
+            e->d_endvl.upload(e->fplan.end_vlane);
+            e->d_endoff.upload(e->fplan.end_off);
+            e->d_vlane0.upload(e->fplan.vlane0);
+        }
+        // run-time guard of the fp16 cell formats (sd_fast_dev.hpp: F16Guard); reserved[2]: a smaller limit (tests)
+        e->sc.guard_lim = p->reserved[2] > 0 ? p->reserved[2] : 2040;
+        e->d_guard.alloc(1);
+        SD_HIP(hipMemset(e->d_guard.p, 0, sizeof(int)));
+        e->sc.guard_flag = e->d_guard.p;
+    }
+    return SD_OK;
+}
+
 extern "C" {
 
 void sd_params_default(sd_params* p) {
@@ -392,14 +451,16 @@ int sd_plan_info(const sd_params* p, const char* const* mono_seqs, const int32_t
     }
     sd::FastPlan plan;
     std::string why;
-    const bool ok = sd::fast_plan_build(tseq, sc, p->part_size + p->overlap, plan, why);
+    sd_params pe = *p;
+    apply_env_overrides(pe);
+    const bool ok = sd::fast_plan_build(tseq, sc, p->part_size + p->overlap, plan, why, !(pe.reserved[1] & SD_FLAG_NO_F16));
     for (int i = 0; i < 8; ++i) info[i] = 0;
     info[0] = ok ? 2 : 1;                       // kernel family "auto" would take: 2 fast, 1 generic
     if (!ok) { set_err(errbuf, errlen, why); return SD_OK; }
     info[1] = plan.P;
     info[2] = plan.waves > 1 ? 5 : plan.wide ? (plan.f16 ? 4 : 3) : plan.f16 ? 2 : 1;   // as sd_engine_info [4] >> 8
     info[3] = plan.floor_slots;
-    info[4] = plan.waves;
+    info[4] = plan.waves | ((int64_t)plan.range_bound << 8);
     // narrow layout: cells in the shortest first lane of a template and in the fullest lane (from slot_of)
     int64_t min_first = 1 << 30, max_lane = 0, x = 0;
     for (size_t j = 0; j < tseq.size(); ++j) {
@@ -435,6 +496,7 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
     if (n_mono <= 0) { set_err(errbuf, errlen, "no monomers"); return SD_ERR_PARAM; }
     std::unique_ptr<sd_engine> e(new sd_engine);
     e->p = *p;
+    apply_env_overrides(e->p);
     // A common factor of the four scores scales every DP value, every difference and every tie alike:
     // the device works with the reduced scores (more scorings fit the packed fp16 / int16 cells) and
     // the record scores are multiplied back when they are fetched.
@@ -471,6 +533,7 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
         bool same = true;
         for (int j = 1; j < e->T; ++j) same = same && ((e->tlen[j] - 1) >> 6) == w0 && (((e->tlen[j] - 1) >> 5) & 1) == h0;
         e->filter_uniform = same && w0 == ((e->Lmax + 63) / 64) - 1 ? h0 : -1;
+        if (e->p.reserved[1] & SD_FLAG_FILTER_GENERAL) e->filter_uniform = -1;
     }
     rc = check_score_range(*p, e->Lmax, err);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
@@ -498,39 +561,8 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
             e->d_queue.alloc(sd_engine::QS * (size_t)sd_engine::QN);
             SD_HIP(hipMemset(e->d_queue.p, 0, sizeof(int) * sd_engine::QS * (size_t)sd_engine::QN));
         }
-        // kernel family
-        int family = p->kernel;
-        std::string why;
-        const bool fast_ok = sd::fast_plan_build(e->tseq, e->sc, p->part_size + p->overlap, e->fplan, why);
-        const bool fast_usable = fast_ok;
-        if (family == 0) family = fast_usable ? 2 : 1;
-        if (family == 2 && !fast_usable) {
-            set_err(errbuf, errlen, "fast kernel family not applicable: " + why);
-            return SD_ERR_UNSUPPORTED;
-        }
-        if (family != 1 && family != 2) { set_err(errbuf, errlen, "bad kernel family"); return SD_ERR_PARAM; }
-        if (p->ed_thr > -1 && e->Lmax > 512) {
-            set_err(errbuf, errlen, "--ed_thr supports templates of up to 512 bp");
-            return SD_ERR_UNSUPPORTED;
-        }
-        if (e->T > 65534) { set_err(errbuf, errlen, "more than 65534 templates"); return SD_ERR_UNSUPPORTED; }
-        e->family = family;
-        e->d_toff.upload(e->toff);
-        e->d_tlen.upload(e->tlen);
-        if (family == 1) {
-            e->Q = sd::generic_pick_q(e->sumL);
-            build_generic_tables(e.get());
-        } else {
-            e->d_ftable.upload(e->fplan.table);
-            e->d_flane.upload(e->fplan.lane_consts);
-            e->d_fslot.upload(e->fplan.slot_of);
-            e->d_ftcodes.upload(e->fplan.tcodes);
-            if (p->ed_thr > -1) {
-                e->d_endvl.upload(e->fplan.end_vlane);
-                e->d_endoff.upload(e->fplan.end_off);
-                e->d_vlane0.upload(e->fplan.vlane0);
-            }
-        }
+        rc = engine_pick_family(e.get(), true, err);
+        if (rc) { set_err(errbuf, errlen, err); return rc; }
         if (p->ed_thr > -1) {
             std::vector<unsigned long long> peq;
             sd::build_peq(e->tseq, peq);
@@ -614,6 +646,118 @@ static bool engine_set_identity(sd_engine* e, const std::vector<std::string>& il
 // the device on `st` (asynchronous) and sizes the per-batch device buffers.  Chunk c refers to
 // cptr[c][0 .. clen[c]).  The kernels of sd_engine_run must be enqueued on the same stream (or after
 // a synchronisation with it).
+// Device buffers of the loaded batch that depend on the kernel family and its layout plan (throws HipFail).
+// Separate from the packing / upload of load_chunks_impl because a batch is re-run under another plan when the
+// fp16 range guard of the fills trips (engine_rerun_without_f16).
+static void engine_alloc_batch(sd_engine* e, int64_t nck) {
+    const size_t C = e->chunks.size();
+    e->d_B.alloc((size_t)e->rows + C);
+    e->d_argB.alloc((size_t)e->rows + C);
+    e->d_cnt.alloc(C);
+    e->d_roff.alloc(C + 1);
+    e->h_roff.alloc(C + 1);
+    e->d_recs.alloc((size_t)e->rows);
+    e->dense_cap = std::max<int64_t>(4096, e->rows / 16);
+    e->d_dense.alloc((size_t)e->dense_cap);
+    e->dense_cap = (int64_t)e->d_dense.cap;
+    if (e->ident_mode) {
+        // identity outputs for up to one record per 48 rows (a block is about a monomer long: ~170 rows); a batch
+        // with more records falls back to the text-based identities of the post-processing
+        int32_t maxlen = 1;
+        for (const sd::ChunkDesc& cd : e->chunks) maxlen = std::max(maxlen, cd.n);
+        const int per = e->ident_mode == 2 ? e->iT : 1;
+        e->ident_cap = std::min<int64_t>(e->dense_cap, std::max<int64_t>(4096, e->rows / 48));
+        e->d_recchunk.alloc((size_t)e->dense_cap);
+        e->d_ilong.alloc((size_t)e->ident_cap);
+        e->d_ilongcnt.alloc(1);
+        e->d_ident.alloc((size_t)e->ident_cap * per);
+        if (e->ident_mode == 2) e->d_identh.alloc((size_t)e->ident_cap * per);
+        auto fill_args = [&](sd::IdentArgs& a, bool homo) {
+            a = sd::IdentArgs{};
+            a.chunks = e->dp_chunks; a.bases2 = e->dp_bases2; a.nmask = e->dp_nmask;
+            a.dense = e->d_dense.p; a.rec_chunk = e->d_recchunk.p; a.total = e->d_roff.p + C;
+            a.rec_cap = e->ident_cap;
+            a.T = per; a.own = e->ident_mode == 1 ? e->d_iown.p : nullptr;
+            a.peq = homo ? e->d_ihpeq.p : e->d_ipeq.p;
+            a.tlen = homo ? e->d_ihtlen.p : e->d_itlen.p;
+            a.Tmask = e->iT; a.K = homo ? e->iKh : e->iK; a.homo = homo ? 1 : 0;
+            const int S = sd::nw_block_cols(a.K);
+            a.short_max = std::min<int>(512, maxlen);
+            a.cap_short = (a.short_max + S - 1) / S;
+            a.grid_short = e->n_cu * 3;
+            a.cap_long = (maxlen + S - 1) / S;
+            // the long launch: as many lanes as 192 MB of checkpoints allow, at most one workgroup per CU
+            const size_t per_block = (size_t)a.cap_long * 256 * ((size_t)a.K * 16 + 4);
+            a.grid_long = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->n_cu, ((size_t)192 << 20) / per_block));
+            a.long_cnt = e->d_ilongcnt.p; a.long_list = e->d_ilong.p;
+            a.out = homo ? e->d_identh.p : e->d_ident.p;
+        };
+        fill_args(e->ia_plain, false);
+        size_t lanes = sd::ident_ck_lanes(e->ia_plain) * (size_t)e->ia_plain.K;
+        size_t pos = sd::ident_ck_lanes(e->ia_plain);
+        if (e->ident_mode == 2) {
+            fill_args(e->ia_homo, true);
+            lanes = std::max(lanes, sd::ident_ck_lanes(e->ia_homo) * (size_t)e->ia_homo.K);
+            pos = std::max(pos, sd::ident_ck_lanes(e->ia_homo));
+        }
+        e->d_ick.alloc(lanes);
+        e->d_ickpos.alloc(pos);
+        e->ia_plain.ck = e->d_ick.p; e->ia_plain.ckpos = e->d_ickpos.p;
+        e->ia_homo.ck = e->d_ick.p; e->ia_homo.ckpos = e->d_ickpos.p;
+    }
+    e->subs.clear();
+    if (e->family == 1) {
+        // pointer workspace: sub-batches of consecutive chunks within the budget
+        size_t free_b = 0, total_b = 0;
+        SD_HIP(hipMemGetInfo(&free_b, &total_b));
+        size_t budget = std::min<size_t>(free_b / 2 + e->d_ptr.bytes(), (size_t)48 << 30);
+        size_t max_sub = 0, cur = 0;
+        int begin = 0;
+        for (size_t c = 0; c < C; ++c) {
+            const size_t need = (size_t)e->chunks[c].n * (size_t)e->rowBytes;
+            if (cur + need > budget && cur > 0) {
+                e->subs.emplace_back(begin, (int)c);
+                max_sub = std::max(max_sub, cur);
+                begin = (int)c;
+                cur = 0;
+            }
+            cur += need;
+        }
+        if (C > 0) { e->subs.emplace_back(begin, (int)C); max_sub = std::max(max_sub, cur); }
+        e->d_ptr.alloc(max_sub);
+        if (e->n_tiles > 1) {
+            size_t most = 0;
+            for (const auto& sb : e->subs) most = std::max(most, (size_t)(sb.second - sb.first));
+            e->d_estate.alloc(most * (size_t)e->n_tiles * 1024 * 32);
+        }
+        if (e->p.ed_thr > -1) {
+            e->d_dist.alloc(C * (size_t)e->T);
+            e->d_grank.alloc(C * (size_t)e->T);
+        }
+        ensure_events(e->ev_fill, e->subs.size());
+        ensure_events(e->ev_trace, e->subs.size());
+    } else {
+        if (e->p.ed_thr > -1) {
+            e->d_dist.alloc(C * (size_t)e->T);
+            e->d_cendoff.alloc(C * 64 * (size_t)e->fplan.waves);
+            e->d_crank.alloc(C * 64 * (size_t)e->fplan.waves);
+            const char* ck = getenv("SD_EDTHR_COMPACT");   // "0": every chunk on the W-wave ranked kernel (A/B, tests)
+            e->compact_edthr = e->fplan.wide && e->fplan.waves > 1 && !(ck && ck[0] == '0');
+            if (e->compact_edthr) {
+                e->d_klist.alloc(C * (size_t)e->T + 2);
+                e->d_kpos.alloc(C * (size_t)e->T);
+                e->d_nkept.alloc(C);
+                e->d_orders.alloc((size_t)e->fplan.waves * C);
+                e->d_cls.alloc(8);
+            }
+        }
+        e->d_fckpt.alloc((size_t)nck * (size_t)e->fplan.P * 64 * (size_t)e->fplan.waves);
+        e->d_fckbase.alloc((size_t)nck + 1);
+        ensure_events(e->ev_fill, 1);
+        ensure_events(e->ev_trace, 1);
+    }
+}
+
 static int load_chunks_impl(sd_engine* e, const std::vector<const char*>& cptr,
                             const std::vector<int32_t>& clen, hipStream_t st, char* errbuf, size_t errlen) {
     e->ran = false;
@@ -695,111 +839,7 @@ static int load_chunks_impl(sd_engine* e, const std::vector<const char*>& cptr,
         SD_HIP(hipMemcpyAsync(e->d_in.p, e->h_in.p, in_bytes, hipMemcpyHostToDevice, st));
         SD_HIP(hipEventRecord(e->ev_in, st));
         e->in_pending = true;
-        e->d_B.alloc((size_t)e->rows + C);
-        e->d_argB.alloc((size_t)e->rows + C);
-        e->d_cnt.alloc(C);
-        e->d_roff.alloc(C + 1);
-        e->h_roff.alloc(C + 1);
-        e->d_recs.alloc((size_t)e->rows);
-        e->dense_cap = std::max<int64_t>(4096, e->rows / 16);
-        e->d_dense.alloc((size_t)e->dense_cap);
-        e->dense_cap = (int64_t)e->d_dense.cap;
-        if (e->ident_mode) {
-            // identity outputs for up to one record per 48 rows (a block is about a monomer long: ~170 rows); a batch
-            // with more records falls back to the text-based identities of the post-processing
-            int32_t maxlen = 1;
-            for (const sd::ChunkDesc& cd : e->chunks) maxlen = std::max(maxlen, cd.n);
-            const int per = e->ident_mode == 2 ? e->iT : 1;
-            e->ident_cap = std::min<int64_t>(e->dense_cap, std::max<int64_t>(4096, e->rows / 48));
-            e->d_recchunk.alloc((size_t)e->dense_cap);
-            e->d_ilong.alloc((size_t)e->ident_cap);
-            e->d_ilongcnt.alloc(1);
-            e->d_ident.alloc((size_t)e->ident_cap * per);
-            if (e->ident_mode == 2) e->d_identh.alloc((size_t)e->ident_cap * per);
-            auto fill_args = [&](sd::IdentArgs& a, bool homo) {
-                a = sd::IdentArgs{};
-                a.chunks = e->dp_chunks; a.bases2 = e->dp_bases2; a.nmask = e->dp_nmask;
-                a.dense = e->d_dense.p; a.rec_chunk = e->d_recchunk.p; a.total = e->d_roff.p + C;
-                a.rec_cap = e->ident_cap;
-                a.T = per; a.own = e->ident_mode == 1 ? e->d_iown.p : nullptr;
-                a.peq = homo ? e->d_ihpeq.p : e->d_ipeq.p;
-                a.tlen = homo ? e->d_ihtlen.p : e->d_itlen.p;
-                a.Tmask = e->iT; a.K = homo ? e->iKh : e->iK; a.homo = homo ? 1 : 0;
-                const int S = sd::nw_block_cols(a.K);
-                a.short_max = std::min<int>(512, maxlen);
-                a.cap_short = (a.short_max + S - 1) / S;
-                a.grid_short = e->n_cu * 3;
-                a.cap_long = (maxlen + S - 1) / S;
-                // the long launch: as many lanes as 192 MB of checkpoints allow, at most one workgroup per CU
-                const size_t per_block = (size_t)a.cap_long * 256 * ((size_t)a.K * 16 + 4);
-                a.grid_long = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->n_cu, ((size_t)192 << 20) / per_block));
-                a.long_cnt = e->d_ilongcnt.p; a.long_list = e->d_ilong.p;
-                a.out = homo ? e->d_identh.p : e->d_ident.p;
-            };
-            fill_args(e->ia_plain, false);
-            size_t lanes = sd::ident_ck_lanes(e->ia_plain) * (size_t)e->ia_plain.K;
-            size_t pos = sd::ident_ck_lanes(e->ia_plain);
-            if (e->ident_mode == 2) {
-                fill_args(e->ia_homo, true);
-                lanes = std::max(lanes, sd::ident_ck_lanes(e->ia_homo) * (size_t)e->ia_homo.K);
-                pos = std::max(pos, sd::ident_ck_lanes(e->ia_homo));
-            }
-            e->d_ick.alloc(lanes);
-            e->d_ickpos.alloc(pos);
-            e->ia_plain.ck = e->d_ick.p; e->ia_plain.ckpos = e->d_ickpos.p;
-            e->ia_homo.ck = e->d_ick.p; e->ia_homo.ckpos = e->d_ickpos.p;
-        }
-        e->subs.clear();
-        if (e->family == 1) {
-            // pointer workspace: sub-batches of consecutive chunks within the budget
-            size_t free_b = 0, total_b = 0;
-            SD_HIP(hipMemGetInfo(&free_b, &total_b));
-            size_t budget = std::min<size_t>(free_b / 2 + e->d_ptr.bytes(), (size_t)48 << 30);
-            size_t max_sub = 0, cur = 0;
-            int begin = 0;
-            for (size_t c = 0; c < C; ++c) {
-                const size_t need = (size_t)e->chunks[c].n * (size_t)e->rowBytes;
-                if (cur + need > budget && cur > 0) {
-                    e->subs.emplace_back(begin, (int)c);
-                    max_sub = std::max(max_sub, cur);
-                    begin = (int)c;
-                    cur = 0;
-                }
-                cur += need;
-            }
-            if (C > 0) { e->subs.emplace_back(begin, (int)C); max_sub = std::max(max_sub, cur); }
-            e->d_ptr.alloc(max_sub);
-            if (e->n_tiles > 1) {
-                size_t most = 0;
-                for (const auto& sb : e->subs) most = std::max(most, (size_t)(sb.second - sb.first));
-                e->d_estate.alloc(most * (size_t)e->n_tiles * 1024 * 32);
-            }
-            if (e->p.ed_thr > -1) {
-                e->d_dist.alloc(C * (size_t)e->T);
-                e->d_grank.alloc(C * (size_t)e->T);
-            }
-            ensure_events(e->ev_fill, e->subs.size());
-            ensure_events(e->ev_trace, e->subs.size());
-        } else {
-            if (e->p.ed_thr > -1) {
-                e->d_dist.alloc(C * (size_t)e->T);
-                e->d_cendoff.alloc(C * 64 * (size_t)e->fplan.waves);
-                e->d_crank.alloc(C * 64 * (size_t)e->fplan.waves);
-                const char* ck = getenv("SD_EDTHR_COMPACT");   // "0": every chunk on the W-wave ranked kernel (A/B, tests)
-                e->compact_edthr = e->fplan.wide && e->fplan.waves > 1 && !(ck && ck[0] == '0');
-                if (e->compact_edthr) {
-                    e->d_klist.alloc(C * (size_t)e->T + 2);
-                    e->d_kpos.alloc(C * (size_t)e->T);
-                    e->d_nkept.alloc(C);
-                    e->d_orders.alloc((size_t)e->fplan.waves * C);
-                    e->d_cls.alloc(8);
-                }
-            }
-            e->d_fckpt.alloc((size_t)nck * (size_t)e->fplan.P * 64 * (size_t)e->fplan.waves);
-            e->d_fckbase.alloc((size_t)nck + 1);
-            ensure_events(e->ev_fill, 1);
-            ensure_events(e->ev_trace, 1);
-        }
+        engine_alloc_batch(e, nck);
     } catch (const HipFail& f) {
         set_err(errbuf, errlen, f.msg);
         return SD_ERR_HIP;
@@ -947,6 +987,11 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
             // the record offsets travel right behind the compaction: the fetch then knows the record
             // count as soon as the stream is idle, without a second round trip
             SD_HIP(hipMemcpyAsync(e->h_roff.p, e->d_roff.p, sizeof(int64_t) * ((size_t)C + 1), hipMemcpyDeviceToHost, ts));
+            if (e->family == 2) {   // and the fp16 range guard of the fills (reset for the next run behind the copy)
+                e->h_guard.alloc(1);
+                SD_HIP(hipMemcpyAsync(e->h_guard.p, e->d_guard.p, sizeof(int), hipMemcpyDeviceToHost, ts));
+                SD_HIP(hipMemsetAsync(e->d_guard.p, 0, sizeof(int), ts));
+            }
         }
         SD_HIP(hipEventRecord(e->ev_run1, ts));
         SD_HIP(hipGetLastError());
@@ -955,6 +1000,8 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
         return SD_ERR_HIP;
     }
     e->last_stream = ts;
+    e->run_st = st;
+    e->run_ts = ts;
     e->ran = true;
     return SD_OK;
 }
@@ -967,6 +1014,9 @@ int sd_engine_run(sd_engine* e, void* hip_stream, char* errbuf, size_t errlen) {
 
 // Waits for the last run and brings its compact records into the pinned buffers h_roff / h_recs
 // (valid until the next load / run of this engine).
+static std::atomic<long long> g_guard_trips{0};
+extern "C" int64_t sd_guard_trips(void) { return (int64_t)g_guard_trips.load(); }
+
 static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errlen) {
     total = 0;
     if (!e->ran) { set_err(errbuf, errlen, "sd_engine_fetch before sd_engine_run"); return SD_ERR_PARAM; }
@@ -977,6 +1027,25 @@ static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errle
         e->in_pending = false;
         hipStream_t cs = e->copy_stream ? e->copy_stream : e->last_stream;
         if (C == 0) { e->h_roff.alloc(1); e->h_roff.p[0] = 0; return SD_OK; }
+        if (e->family == 2 && e->h_guard.p && e->h_guard.p[0] != 0) {
+            // A wave's fp16 cells left the range in which they are exact integers (F16Guard, sd_fast_dev.hpp): the
+            // layout plan's bound did not hold for this input.  Nothing of the run is used; the batch (still packed on
+            // the device) is repeated with integer cells, which this engine keeps from now on.
+            ++g_guard_trips;
+            std::string err2;
+            int rc2 = engine_pick_family(e, false, err2);
+            if (rc2) { set_err(errbuf, errlen, "fp16 cell range exceeded, and no integer-cell layout: " + err2); return rc2; }
+            const int64_t nck = e->family == 2 ? sd::fast_ckpt_rows_total(e->fplan, e->chunks) : 0;
+            SD_HIP(hipMemcpy(e->dp_chunks, e->chunks.data(), C * sizeof(sd::ChunkDesc), hipMemcpyHostToDevice));
+            engine_alloc_batch(e, nck);
+            rc2 = engine_run2(e, e->run_st, e->run_ts, errbuf, errlen);
+            if (rc2) return rc2;
+            SD_HIP(hipEventSynchronize(e->ev_run1));
+            if (e->family == 2 && e->h_guard.p[0] != 0) {
+                set_err(errbuf, errlen, "cell range exceeded in the integer-cell fill");
+                return SD_ERR_INTERNAL;
+            }
+        }
         total = e->h_roff.p[C];
         e->ident_valid = e->ident_mode != 0 && total <= e->ident_cap && total <= e->dense_cap;
         if (total > e->dense_cap) {
@@ -1168,6 +1237,7 @@ struct Pipeline {
 
     int create(const sd_params* pp, const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono) {
         p = *pp;
+        apply_env_overrides(p);
         if (const char* ev = getenv("SD_PIPE_SLOTS")) NS = std::min(NSMAX, std::max(1, atoi(ev)));
         mseq.assign(mono_seqs, mono_seqs + n_mono);
         mlen.assign(mono_lens, mono_lens + n_mono);
@@ -1209,8 +1279,7 @@ struct Pipeline {
     void make_streams() {
         if (streams_tried) return;
         streams_tried = true;
-        mode = 2;
-        if (const char* ev = getenv("SD_PIPE_MODE")) mode = atoi(ev);
+        mode = p.reserved[0] > 0 ? p.reserved[0] - 1 : 2;
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least urgent (numerically largest)
         const char* pe = getenv("SD_PIPE_PRIO");
@@ -2196,7 +2265,12 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     Pipeline pipe;
     // identities of the final TSV in-stream, behind every batch's compaction (sd_ident.hip); template sets the kernel
     // does not take (and SD_IDENT_STREAM=0, developer A/B) leave them to the post-processing as in round 2
-    bool stream_ident = !(getenv("SD_IDENT_STREAM") && getenv("SD_IDENT_STREAM")[0] == '0');
+    bool stream_ident;
+    {
+        sd_params pe = *p;
+        apply_env_overrides(pe);
+        stream_ident = !(pe.reserved[1] & SD_FLAG_NO_STREAM_IDENT);
+    }
     pipe.on_engine = [&](sd_engine* e) {
         if (stream_ident && !engine_set_identity(e, pp.interleaved_seqs(), pp.own_interleaved(), second_best != 0)) stream_ident = false;
     };

@@ -282,7 +282,7 @@ static int code_of(char ch) {
 }
 
 bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max_rows,
-                     FastPlan& plan, std::string& why) {
+                     FastPlan& plan, std::string& why, bool allow_f16) {
     (void)max_rows;
     plan = FastPlan();
     const int T = (int)tseq.size();
@@ -312,6 +312,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     const int64_t ub = (int64_t)(Lmax - 1) * ab(sc.del) + (int64_t)(FAST_REBASE + 1) * G +
                        (int64_t)FAST_REBASE * ab(sc.ins) + 8 * (int64_t)maxabs + 8;
     if (ub > 12000) { why = "scores too large for int16 cells"; return false; }
+    plan.range_bound = (int)ub;
     if (Lmax > 64 * 8) { why = "template longer than 512 bp"; return false; }
 
     // narrow layout: the smallest slot counts P whose lanes fit the two planes; the first three are candidates,
@@ -349,9 +350,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     plan.wide = wide;
     {
         // fp16 cells are exact while every value stays an integer below 2048 in magnitude
-        const char* force = getenv("SD_FILL_CELLS");  // "i16" / "f16": developer A/B switch
-        plan.f16 = !wide && ub <= 2040;
-        if (force && force[0] == 'i') plan.f16 = false;
+        plan.f16 = !wide && ub <= 2040 && allow_f16;   // (SD_FLAG_NO_F16 / SD_FILL_CELLS=i16 arrive as allow_f16 = false)
     }
     plan.P = P;
     plan.P4 = (P + 3) & ~3;
@@ -533,10 +532,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         };
         bool bf_ok = true;
         const int xb = bf8_of(xd, bf_ok), mb = bf8_of(md, bf_ok);
-        {
-            const char* force = getenv("SD_FILL_CELLS");
-            plan.f16 = bf_ok && ub <= 2040 && !(force && force[0] == 'i');
-        }
+        plan.f16 = bf_ok && ub <= 2040 && allow_f16;
         if (W > 1) {
             // multi-wave wide layout (sd_fast_wn.hip): LDS holds the template base codes, [wave][G][2 halves][64
             // lanes][4 dwords], bytes as above; code 7 = padding; the two bf8 table bytes travel as kernel arguments
@@ -675,8 +671,8 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
         }                                                                                            \
         break;
     // fp16 cells, 150-200 bp monomers: the variants that skip the dominated start-term maxima (sd_fast_fl.hip);
-    // SD_FILL_FULLFLOOR=1 keeps the full kernel (developer A/B and the parity test of the two)
-    if (!getenv("SD_FILL_FULLFLOOR") &&
+    // FastPlan::full_floor (SD_FLAG_FULL_FLOOR) keeps the full kernel (developer A/B and the parity test of the two)
+    if (!plan.full_floor &&
         (plan.f16 ? launch_fast_fill_fl(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
                                         argV, ckpt, ckbase, queue, order, cendoff, crank)
                   : launch_fast_fill_fl_i16(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc,

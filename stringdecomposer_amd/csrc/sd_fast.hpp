@@ -47,6 +47,8 @@ struct FastPlan {
     int Qk = 0;           // traceback: template cells per lane = ceil(Lmax/64)
     int waves = 1;        // waves per chunk: 1, or ceil(T/128) for the multi-wave wide layout (sd_fast_wn.hip)
     int bshift = 7;       // B words: (B_i << bshift) | arg-max (wave << 7 | virtual lane)
+    int range_bound = 0;       // proven bound on |stored cell| between two rebases (fp16 formats need <= 2040)
+    bool full_floor = false;   // launch the fills that take the start-term maximum in every slot (SD_FLAG_FULL_FLOOR: A/B, parity test)
     int floor_slots = 0;  // last slot of a lane whose diagonal input needs the max with the start term (see sd_fast_fill)
     uint32_t bf8_match = 0, bf8_mismatch = 0;   // multi-wave wide layout: bf8 bytes of the two table values
     std::vector<int32_t> vlane0;         // first virtual lane of template j
@@ -67,7 +69,7 @@ static const int FAST_WIDE_P_LIST[] = {80, 96, 112, 128, 144, 160, 176, 192, 208
 // Builds the plan; returns false (with the reason) when the fast family cannot represent the
 // input exactly (then the generic family is used).
 bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max_rows,
-                     FastPlan& plan, std::string& why);
+                     FastPlan& plan, std::string& why, bool allow_f16 = true);
 
 // --ed_thr prefilter on the device (sd_filter.hip): infix edit distances, kept set and ranks per
 // chunk -> per-chunk lane constants of the fast family (cendoff, crank: [chunk][64] packed {lo,hi}

@@ -144,6 +144,51 @@ struct CellOps {
     }
 };
 
+// Run-time guard of the fp16 cell formats.  The fills keep integers in packed fp16, exact while |value| < 2048;
+// fast_plan_build proves a bound per (template set, scoring) -- and that proof was wrong once (round 1: fuzz seed
+// 906).  So the kernels check the assumption itself.  Between two rebases every stored cell with an insertion move
+// (all but the k = 0 cells, which follow the start term) only grows from row to row -- the insertion candidate of
+// S'[x] is S[x] -- so a period's largest values are those of its last row and its smallest those of its first:
+//   * after row 0 and after every rebase shift: no finite cell below -lim,
+//   * before every rebase shift and after the last row: no cell above +lim.
+// About P + 6 packed ops per 128 rows.  Idle planes (no template) hold -inf in every slot and are exempt.
+template <int P>
+struct F16Guard {
+    uint32_t limneg = 0, limpos = 0;   // per lane and plane: {-lim or -inf}, {+lim}
+    bool bad = false;                  // wave-uniform, sticky over the chunk
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ uint32_t mn(uint32_t a, uint32_t b) {
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_minimum(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b)));
+    }
+    // after row 0: `last` = a slot that is finite on every plane holding a template
+    __device__ __forceinline__ void start(uint32_t last, int lim) {
+        bad = false;
+        limpos = CellOps<true>::splat(lim);
+        const uint32_t nl = CellOps<true>::splat(-lim);
+        const uint32_t lo = (last & 0xffffu) == 0xFC00u ? 0xFC00u : (nl & 0xffffu);
+        const uint32_t hi = (last >> 16) == 0xFC00u ? 0xFC000000u : (nl & 0xffff0000u);
+        limneg = lo | hi;
+    }
+    __device__ __forceinline__ void check_low(const uint32_t (&L)[P]) {
+        uint32_t m = L[0];
+#pragma unroll
+        for (int s = 1; s < P; ++s) m = mn(m, L[s]);
+        const uint32_t t = CellOps<true>::mx(m, limneg);
+        bad = bad || __ballot(t != m) != 0ull;
+    }
+    __device__ __forceinline__ void check_high(const uint32_t (&L)[P]) {
+        uint32_t m = L[0];
+#pragma unroll
+        for (int s = 1; s + 1 < P; s += 2) m = CellOps<true>::mx3(m, L[s], L[s + 1]);
+        if ((P & 1) == 0) m = CellOps<true>::mx(m, L[P - 1]);
+        const uint32_t t = mn(m, limpos);
+        bad = bad || __ballot(t != m) != 0ull;
+    }
+    __device__ __forceinline__ void finish(int* flag) {
+        if (bad && flag && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+    }
+};
+
 // acc[lane == slot] = value (wave-uniform value and slot): one v_mov + one v_cndmask with a
 // scalar one-hot mask instead of v_mov + v_cmp + v_cndmask
 __device__ __forceinline__ void acc_put(int& acc, int value, int slot) {

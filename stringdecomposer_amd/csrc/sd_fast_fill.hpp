@@ -212,6 +212,11 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     for (int q = 1; q < P; ++q) L[q] = CO::mx(L[q - 1], CO::add(tb[q], ins2));
     load_table(rs.code(1), L[P - 1]);
     rs.advance(1);
+    F16Guard<P> guard;
+    if constexpr (F16) {
+        guard.start(L[P - 1], sc.guard_lim);
+        guard.check_low(L);
+    }
     if constexpr (HRED) reduce_ends(L[P - 1], 1);
     K = excl_scan(L[P - 1]);
     uint32_t Eend = CO::mx(L[P - 1], K);
@@ -230,10 +235,12 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
                 tp = 0;
                 if constexpr (HRED) bdel16 = __builtin_amdgcn_readfirstlane((int)(CO::splat(sc.del) & 0xffffu));
                 if constexpr (F16) {
+                    guard.check_high(L);
                     K = bfi(startMask, NEGC, CO::add(K, d2));
                     Eend = CO::add(Eend, d2);
 #pragma unroll
                     for (int s = 0; s < P; ++s) L[s] = CO::add(L[s], d2);
+                    guard.check_low(L);
                 } else {
                 K = bfi(startMask, NEG2, pk_subs(K, d2));
                 Eend = pk_subs(Eend, d2);
@@ -322,6 +329,10 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
             Eend = CO::mx(a, K);
             reduce_ends(Eend, i + 1);
         }
+    }
+    if constexpr (F16) {
+        guard.check_high(L);
+        guard.finish(sc.guard_flag);
     }
     }  // chunk queue
 }

@@ -24,7 +24,7 @@ void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc
     const int grid = std::min((n_chunks + NW - 1) / NW, n_cu);  // persistent: one workgroup per CU (LDS)
     const size_t lds = (size_t)5 * (plan.P / 16) * 512 * sizeof(uint32_t);
     const bool ranked = cendoff != nullptr;
-    if (!getenv("SD_FILL_FULLFLOOR") &&
+    if (!plan.full_floor &&
         launch_fast_fill_wide_fl(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt,
                                  ckbase, queue, order, cendoff, crank))
         return;

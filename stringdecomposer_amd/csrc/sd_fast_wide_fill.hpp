@@ -146,6 +146,11 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
         }
         reduce_ends(L[P - 1], 1);
     }
+    F16Guard<P> guard;   // run-time check of the fp16 exact-integer range (sd_fast_dev.hpp)
+    if constexpr (F16) {
+        guard.start(L[P - 1], sc.guard_lim);
+        guard.check_low(L);
+    }
     int rnext = rs.code(1);  // read symbol of the next row; its group 0 is prefetched into tbg[0]
     rs.advance(1);
     load_group(rnext, 0, 0, L[P - 1]);
@@ -157,8 +162,10 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
                 base += Brel;
                 Brel = 0;
                 tp = 0;
+                if constexpr (F16) guard.check_high(L);
 #pragma unroll
                 for (int s = 0; s < P; ++s) L[s] = CO::sub(L[s], d2);
+                if constexpr (F16) guard.check_low(L);
             }
             const int q = (i / FAST_R) - 1;
 #pragma unroll
@@ -237,6 +244,10 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
         load_group(rnext, 0, 0, L[P - 1]);
         ++tp;
         reduce_ends(L[P - 1], i + 1);
+    }
+    if constexpr (F16) {
+        guard.check_high(L);
+        guard.finish(sc.guard_flag);
     }
     }  // chunk queue
 }

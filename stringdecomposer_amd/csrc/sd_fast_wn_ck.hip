@@ -14,7 +14,7 @@ void launch_fast_fill_wn_compact(const FastPlan& plan, hipStream_t st, const Chu
     const size_t lds = ((size_t)wb * (plan.P / 16) * 512 + 64) * sizeof(uint32_t);
     const int per_cu = std::max(1, std::min(8 / wb, (int)((150 * 1024) / lds)));   // two waves per SIMD, LDS
     const int grid = per_cu * n_cu;
-    const bool fl = plan.floor_slots >= 1 && plan.floor_slots <= 48 && !getenv("SD_FILL_FULLFLOOR");
+    const bool fl = plan.floor_slots >= 1 && plan.floor_slots <= 48 && !plan.full_floor;
 #define SD_CK_K(PP, FF)                                                                                             \
     {                                                                                                              \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill_wn<PP, false, FF, true>),             \

@@ -194,6 +194,9 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
             }
             reduce_ends(L[P - 1], 1);
         }
+        F16Guard<P> guard;   // run-time check of the fp16 exact-integer range (sd_fast_dev.hpp)
+        guard.start(L[P - 1], sc.guard_lim);
+        guard.check_low(L);
         int rnext = rs.code(1);
         rs.advance(1);
         load_group(0, 0, L[P - 1]);
@@ -205,8 +208,10 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
                     base += Brel;
                     Brel = 0;
                     tp = 0;
+                    guard.check_high(L);
 #pragma unroll
                     for (int s = 0; s < P; ++s) L[s] = CO::sub(L[s], d2);
+                    guard.check_low(L);
                 }
                 const int q = (i / FAST_R) - 1;
                 uint32_t* ckq = ck + (uint64_t)q * (uint64_t)W * (uint64_t)(P * 64);
@@ -255,6 +260,8 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
             ++tp;
             reduce_ends(L[P - 1], i + 1);
         }
+        guard.check_high(L);
+        guard.finish(sc.guard_flag);
         __syncthreads();   // the exchange area and xc are rewritten for the next chunk
     }
 }

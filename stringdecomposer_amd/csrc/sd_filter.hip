@@ -308,7 +308,7 @@ void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, 
     }
     // uniform variant (sd_hw_dist_u): same word count and same half of the last word for every template, masks in LDS
     bool done = false;
-    if (uniform_half >= 0 && W >= 1 && W <= 4 && !getenv("SD_FILTER_GENERAL")) {
+    if (uniform_half >= 0 && W >= 1 && W <= 4) {   // (SD_FLAG_FILTER_GENERAL: the engine passes uniform_half = -1)
         const size_t lds = (size_t)std::min(T, 256) * 5 * W * sizeof(unsigned long long);   // <= 40 KB
 #define SD_HWU(WW)                                                                                             \
         {                                                                                                      \

@@ -32,7 +32,7 @@ EXPORTS = [
     "sd_fasta_free", "sd_nw_identity_batch", "sd_identity_segments", "sd_chunk_table_size",
     "sd_decompose_chunk_range", "sd_assemble_tsv", "sd_release_cache", "sd_format_alt_rows",
     "sd_stream_create", "sd_stream_destroy", "sd_stream_submit", "sd_stream_collect", "sd_stream_stats",
-    "sd_stream_info", "sd_pack_bases", "sd_identity_segments_dev", "sd_nw_release_cache", "sd_last_run_stats",
+    "sd_stream_info", "sd_pack_bases", "sd_identity_segments_dev", "sd_nw_release_cache", "sd_last_run_stats", "sd_guard_trips",
     "sd_run_files", "sd_convert_raw_tsv", "sd_decompose_files_range", "sd_assemble_files_tsv",
     "sd_host_stage_rates", "sd_run_files_range", "sd_plan_info",
 ]
@@ -159,8 +159,13 @@ def _strs(seq):
     return arr
 
 
+FLAG_NO_F16, FLAG_FULL_FLOOR, FLAG_NO_EDTHR_COMPACT, FLAG_FILTER_GENERAL, FLAG_NO_STREAM_IDENT = 1, 2, 4, 8, 16
+
+
 def make_params(scoring=(-1, -1, -1, 1), part_size=5000, overlap=500, ed_thr=-1, threads=1,
-                device=0, kernel=KERNEL_AUTO, max_batch_rows=0):
+                device=0, kernel=KERNEL_AUTO, max_batch_rows=0, pipe_mode=None, flags=0, f16_guard=0):
+    """sd_params; pipe_mode (None = the library default, 0 / 1 / 2), flags (FLAG_* bits) and f16_guard (magnitude
+    limit of the fills' fp16 range guard, 0 = 2040) are the reserved[] switches of include/sd_hip.h."""
     L = load()
     p = Params()
     L.sd_params_default(C.byref(p))
@@ -168,12 +173,22 @@ def make_params(scoring=(-1, -1, -1, 1), part_size=5000, overlap=500, ed_thr=-1,
     p.part_size, p.overlap, p.ed_thr = int(part_size), int(overlap), int(ed_thr)
     p.threads, p.device, p.kernel = int(threads), int(device), int(kernel)
     p.max_batch_rows = int(max_batch_rows)
+    p.reserved[0] = 0 if pipe_mode is None else int(pipe_mode) + 1
+    p.reserved[1] = int(flags)
+    p.reserved[2] = int(f16_guard)
     return p
+
+
+def guard_trips():
+    """Batches of this process repeated with integer cells because the fp16 range guard tripped (sd_guard_trips)."""
+    L = load()
+    L.sd_guard_trips.restype = C.c_int64
+    return int(L.sd_guard_trips())
 
 
 def plan_info(mono_seqs, **kw):
     """The layout the fast kernel family would use for this monomer set and scoring (host only, no GPU needed):
-    {"family", "cells_per_lane", "cells", "floor_slots", "waves", "min_first_lane_cells", "max_lane_cells",
+    {"family", "cells_per_lane", "cells", "floor_slots", "waves", "range_bound", "min_first_lane_cells", "max_lane_cells",
     "score_factor", "why"} -- family "generic" carries the reason in "why"."""
     L = load()
     p = make_params(**kw)
@@ -186,7 +201,7 @@ def plan_info(mono_seqs, **kw):
         raise SdError(rc, err.value.decode(errors="replace"))
     cells = {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table", 4: "f16/bf8-table", 5: "f16/bf8-codes x waves"}
     return {"family": {1: "generic", 2: "fast"}[v[0]], "cells_per_lane": v[1], "cells": cells.get(v[2], "?") if v[0] == 2 else "int32",
-            "floor_slots": v[3], "waves": v[4], "min_first_lane_cells": v[5], "max_lane_cells": v[6],
+            "floor_slots": v[3], "waves": v[4] & 0xff, "range_bound": v[4] >> 8, "min_first_lane_cells": v[5], "max_lane_cells": v[6],
             "score_factor": v[7], "why": err.value.decode(errors="replace") if v[0] == 1 else ""}
 
 
