@@ -211,12 +211,104 @@ def bench_c4_second_best(args):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def bench_strong(args):
+    """Strong scaling: ONE job of BASELINE config 3 (a set of reads, 12 monomers, default scoring) or config 5 (one
+    long sequence, scoring -2,-3,-4,2) split over the ranks as the multi-process command line splits it
+    (shard.strong_share: contiguous blocks of reads / of the global chunk table; no data-path collective).  A step =
+    the whole job once; every rank runs its share, the time is the MAX over ranks, value = job bp / that."""
+    import torch
+    rank, local_rank, ws = shard.world()
+    if args.gpus != ws and ws > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, ws))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libsd_hip has no CPU fallback)")
+    share_gpu = bool(os.environ.get("SD_BENCH_SHARE_GPU"))
+    if share_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dist = shard.init_process_group("gloo" if share_gpu else "nccl") if ws > 1 else None
+    dev = torch.device("cpu") if share_gpu else torch.device("cuda", local_rank)
+    bar_dev = None if (share_gpu or not dist) else local_rank
+    threads = max(1, min(32, usable_cores() // max(ws, 1)))
+    K = max(args.steps, 1)
+    mn, ms = synth.make_monomers(12, seed=args.seed)
+    if args.config == "c3":
+        kind, lo, hi = shard.strong_share("c3", rank, ws, n_reads=args.reads_total)
+        rn, rs = synth.make_reads(ms, hi - lo, read_len=args.read_len, seed=args.seed, first_index=lo)
+        my_bp = sum(len(x) for x in rs)
+        job_bp = shard.sum_over_ranks(dist, my_bp, dev)
+        readset = lib.ReadSet(rs)
+        st = lib.Stream(ms, device=local_rank, threads=threads, pipe_mode=args.pipe_mode)
+
+        def step():
+            st.submit(readset)
+            return st.collect()
+        workload = "C3: ONE job of %d synthetic reads x %d bp, 12 monomers, default scoring, part 5000 / overlap 500; " \
+                   "this rank: reads [%d, %d)" % (args.reads_total, args.read_len, lo, hi)
+        scoring = (-1, -1, -1, 1)
+    else:
+        scoring = (-2, -3, -4, 2)
+        kind, lo, hi, n_chunks = shard.strong_share("c5", rank, ws, seq_len=args.seq_len)
+        _, rs = synth.make_reads(ms, 1, read_len=args.seq_len, seed=args.seed)
+        job_bp = args.seq_len
+        st = None
+
+        def step():
+            recs, off = lib.decompose_chunk_range(rs, ms, lo, hi, scoring=scoring, device=local_rank, threads=threads)
+            return len(recs)
+        workload = "C5: ONE sequence of %d bp, 12 monomers, scoring -2,-3,-4,2, part 5000 / overlap 500 (%d chunks); this " \
+                   "rank: chunks [%d, %d)" % (args.seq_len, n_chunks, lo, hi)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    a = st.stats() if st else None
+    shard.barrier(dist, bar_dev)
+    torch.cuda.synchronize()
+    c0 = os.times()
+    t0 = time.perf_counter()
+    out_rows = 0
+    for _ in range(K):
+        out_rows = step()
+    torch.cuda.synchronize()
+    my_dt = time.perf_counter() - t0
+    c1 = os.times()
+    shard.barrier(dist, bar_dev)
+    dt = shard.max_over_ranks(dist, my_dt, dev)
+    rate = shard.job_rate(dist, job_bp * K, my_dt, dev)
+    kern = None
+    if st:
+        b = st.stats()
+        kern = {"fill": (b["fill_ms"] - a["fill_ms"]) / K, "traceback": (b["trace_ms"] - a["trace_ms"]) / K,
+                "batches_per_step": (b["batches"] - a["batches"]) / K}
+        st.close()
+    out = {"metric": "decomposed read-bp/sec (whole node), one job split over the GPUs", "value": rate, "unit": "bp/s",
+           "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "config": {"workload": workload, "job_bp": job_bp, "share": [kind, lo, hi], "scoring": list(scoring),
+                      "host_threads": threads, "seed": args.seed,
+                      "sharding": "contiguous blocks of %s, no collective (shard.strong_share)" % kind},
+           "roofline": None, "cpu_baseline": None,
+           "rank0": {"seconds": my_dt, "rows_out_last_step": out_rows, "kernel_ms_per_step": kern,
+                     "process_cpu_ms_per_step": ((c1.user - c0.user) + (c1.system - c0.system)) * 1e3 / K},
+           "note": "strong-scaling companion of the headline line (which is weak scaling on C2, roofline and cpu_baseline "
+                   "there); time = MAX over ranks of the K steps"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=["c2", "c4-second-best"], default="c2",
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the driver's SCALE runs): every rank owns its own C2 read set; strong: ONE job -- "
+                         "--config c3 (a set of reads) or c5 (one 200-Mb sequence) -- split over the ranks exactly as the "
+                         "multi-process command line splits it (shard.strong_share)")
+    ap.add_argument("--reads-total", type=int, default=100000, help="--scaling strong --config c3: reads of the whole job")
+    ap.add_argument("--seq-len", type=int, default=200000000, help="--scaling strong --config c5: length of the sequence")
+    ap.add_argument("--config", choices=["c2", "c3", "c5", "c4-second-best"], default="c2",
                     help="c2 (default, the headline): BASELINE configs[1]; c4-second-best: BASELINE config 4 (64 monomers x "
                          "256 reads x 50 kb) through the whole command-line path with --second-best, FASTA files -> the three "
                          "TSV files (1 GPU), roofline of the identity kernel")
@@ -254,6 +346,10 @@ def main():
 
     if args.config == "c4-second-best":
         return bench_c4_second_best(args)
+    if args.scaling == "strong" or args.config in ("c3", "c5"):
+        if args.config not in ("c3", "c5"):
+            raise SystemExit("--scaling strong needs --config c3 or c5")
+        return bench_strong(args)
 
     import torch
     rank, local_rank, ws = shard.world()
@@ -388,20 +484,25 @@ def main():
         try:
             with open(tf) as f:
                 tj = json.load(f)
-            if tj.get("workload_rows") == rows and tj.get("kernel_family") == info["family"]:
+            same_kernel = (tj.get("kernel_family") == info["family"] and tj.get("cells", info["cells"]) == info["cells"] and
+                           tj.get("cells_per_lane", 35) == info["cells_per_lane"] and tj.get("sum_template_len", 4096) == sumL)
+            if same_kernel and tj.get("workload_rows") == rows:
                 traffic = tj.get("hbm_bytes_per_launch")
-                if tj.get("SQ_INSTS_VALU_per_launch") and tj.get("cells", info["cells"]) == info["cells"]:
-                    # what actually binds the fill (SURVEY 8(d) caveat): VALU issue slots.  The instruction count of
-                    # a launch is a property of (binary, workload) -- counted once by rocprofv3 --pmc SQ_INSTS_VALU
-                    # (committed profile) -- the durations are measured in this run.
-                    cyc = tj["GRBM_GUI_ACTIVE_per_launch"] / 8.0
-                    valu = {"wave_insts_per_launch": tj["SQ_INSTS_VALU_per_launch"],
-                            "insts_per_row": tj["SQ_INSTS_VALU_per_launch"] / rows,
-                            "cycles_per_wave_inst_per_simd": VALU_CYC_PER_WAVE_INST,
-                            "ceiling_source": "profiles/r03_ubench_issue.txt (tools/ubench_issue.hip, this GPU model)",
-                            "issue_frac_profiled": tj["SQ_INSTS_VALU_per_launch"] * VALU_CYC_PER_WAVE_INST / (N_SIMDS * cyc),
-                            "source": "instruction count: committed profile profiles/fill_traffic.json (rocprofv3 --pmc "
-                                      "SQ_INSTS_VALU GRBM_GUI_ACTIVE, device-resident single launch); durations: this run"}
+            if same_kernel and tj.get("SQ_INSTS_VALU_per_launch") and tj.get("workload_rows"):
+                # what actually binds the fill (SURVEY 8(d) caveat): VALU issue slots.  The instruction count of a row
+                # is a property of (kernel instance, template set) -- every row of every chunk runs the same slot loop
+                # and tail -- counted once by rocprofv3 --pmc SQ_INSTS_VALU on the C2 workload (committed profile) and
+                # scaled by this run's rows; the durations are measured in this run.
+                cyc = tj["GRBM_GUI_ACTIVE_per_launch"] / 8.0
+                per_row = tj["SQ_INSTS_VALU_per_launch"] / tj["workload_rows"]
+                valu = {"wave_insts_per_launch": per_row * rows / max(d["fill_launches"] / K, 1.0),
+                        "insts_per_row": per_row,
+                        "cycles_per_wave_inst_per_simd": VALU_CYC_PER_WAVE_INST,
+                        "ceiling_source": "profiles/r03_ubench_issue.txt (tools/ubench_issue.hip, this GPU model)",
+                        "issue_frac_profiled": tj["SQ_INSTS_VALU_per_launch"] * VALU_CYC_PER_WAVE_INST / (N_SIMDS * cyc),
+                        "source": "instructions per row: committed profile profiles/fill_traffic.json (rocprofv3 --pmc "
+                                  "SQ_INSTS_VALU GRBM_GUI_ACTIVE, device-resident single launch of C2) x the rows of this "
+                                  "run; durations: this run"}
         except Exception:
             traffic = None
     kname = ("sd_fast_fill_wide" if info["cells_per_lane"] > 64 else "sd_fast_fill") if info["family"] == "fast" else "sd_generic_fill"

@@ -2059,6 +2059,14 @@ int sd_stream_collect(sd_stream* s, sd_rec** rows, int64_t** row_off, int64_t* n
         rc = s->pipe.pop();
         if (rc) set_err(errbuf, errlen, s->pipe.eb);
     }
+    if (rc != SD_OK) {
+        // batches of this or a later job may still be in flight and their sinks hold pointers to the jobs: wait for
+        // every one of them before a job is freed (as sd_stream_submit's error path does), then drop all jobs
+        (void)s->pipe.drain();
+        s->jobs.clear();
+        s->collect_s += now_s() - t0;
+        return rc;
+    }
     if (rc == SD_OK && job->oom) { set_err(errbuf, errlen, "out of host memory"); rc = SD_ERR_INTERNAL; }
     if (rc == SD_OK) {
         if (!job->rows) job->rows = static_cast<sd_rec*>(std::malloc(sizeof(sd_rec)));
@@ -2190,6 +2198,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     };
     sd::FastaFile rf, mf;
     rc = rf.open(reads_fa, p->threads, err);                                  // main.cpp:394
+    if (rc == SD_OK && world == 1) rc = rf.validate(0, rf.recs.size(), p->threads, err);   // reads are checked first, as there
     if (rc == SD_OK) rc = mf.open(monomers_fa, p->threads, err);              // main.cpp:395
     if (rc == SD_OK) rc = mf.validate(0, mf.recs.size(), p->threads, err);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
@@ -2234,8 +2243,12 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         r_hi = rank + 1 == world ? all_reads.size() : std::min(bound(rank + 1), all_reads.size());
         if (r_hi < r_lo) r_hi = r_lo;
     }
-    rc = rf.validate(r_lo, r_hi, p->threads, err);
+    if (world > 1) rc = rf.validate(r_lo, r_hi, p->threads, err);   // a rank checks the reads it touches (the launcher exchanges failures)
     if (rc) { set_err(errbuf, errlen, err); return rc; }
+    // main.cpp:343 (load_fasta): the N warning, once per file, on stderr
+    for (const auto& ff : {std::make_pair(&rf, reads_fa), std::make_pair(&mf, monomers_fa)})
+        if (ff.first->has_n && rank == 0)
+            std::fprintf(stderr, "WARNING: sequences in %s contain N symbol. It will be counted as a separate symbol in scoring!\n", ff.second);
     lap("FASTA index + alphabet check");
     std::vector<ReadView> reads(all_reads.begin() + (long)r_lo, all_reads.begin() + (long)r_hi);
     if (info) { info[0] = (int64_t)r_lo; info[1] = (int64_t)r_hi; info[2] = (int64_t)all_reads.size(); info[3] = 0; }
@@ -2289,7 +2302,11 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     std::deque<Work> wq;
     bool wq_done = false;
     std::atomic<int> sink_rc{SD_OK};
-    std::string sink_err;
+    std::string sink_err;     // written under wq_m by whichever thread fails first (driver or sink thread)
+    auto sink_fail = [&](int code, const std::string& msg) {
+        std::lock_guard<std::mutex> lk(wq_m);
+        if (sink_rc.load() == SD_OK) { sink_err = msg; sink_rc.store(code); }
+    };
     double t_fmt = 0, t_post = 0, t_io = 0;
     auto sink_loop = [&]() {
         sd::HostPool::lane() = 1;   // this thread's parallel loops run on the second pool, beside the driver's
@@ -2332,13 +2349,11 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
                 t_post += now_s() - t0;
                 t0 = now_s();
                 if (r2) {
-                    sink_err = e2;
-                    sink_rc.store(r2);
+                    sink_fail(r2, e2);
                 } else if (std::fwrite(raw.data(), 1, raw.size(), fr) != raw.size() ||
                            std::fwrite(fin.data(), 1, fin.size(), ff) != fin.size() ||
                            std::fwrite(alt.data(), 1, alt.size(), fa) != alt.size()) {
-                    sink_err = std::string("short write to ") + raw_tsv_out;
-                    sink_rc.store(SD_ERR_IO);
+                    sink_fail(SD_ERR_IO, std::string("short write to ") + raw_tsv_out);
                 }
                 t_io += now_s() - t0;
             }
@@ -2356,7 +2371,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         job.bid = pipe.cur_ident.id;
         job.bidh = pipe.cur_ident.idh;
         job.add(c0, c1, recs, roff);
-        if (job.oom) { sink_err = "out of host memory"; sink_rc.store(SD_ERR_INTERNAL); return; }
+        if (job.oom) { sink_fail(SD_ERR_INTERNAL, "out of host memory"); return; }
         const size_t r1 = job.next_read;
         if (r1 == r0) return;
         Work w;

@@ -33,6 +33,29 @@ def weak_range(items_per_rank, rank):
     return rank * items_per_rank, (rank + 1) * items_per_rank
 
 
+def strong_share(config, rank, world_size, n_reads=0, seq_len=0, part_size=5000, overlap=500):
+    """What `rank` does of ONE job split over `world_size` GPUs (strong scaling; `bench.py --scaling strong`), exactly
+    as the multi-process command line splits it -- no data-path collective in either form:
+      "c3"  a set of reads (BASELINE config 3): contiguous blocks of reads, as run_files_sharded deals them when all
+            reads have the same length -> ("reads", lo, hi);
+      "c5"  one huge sequence (BASELINE config 5): contiguous blocks of the global chunk table (main.cpp:70-81), as
+            decompose_files_sharded -> ("chunks", lo, hi, n_chunks)."""
+    if config == "c3":
+        lo, hi = block_range(int(n_reads), rank, world_size)
+        return ("reads", lo, hi)
+    if config == "c5":
+        from . import lib
+        n_chunks = lib.chunk_table_size([int(seq_len)], part_size, overlap)
+        lo, hi = block_range(n_chunks, rank, world_size)
+        return ("chunks", lo, hi, n_chunks)
+    raise ValueError("strong_share: config must be c3 or c5")
+
+
+def job_rate(dist, total_units, my_seconds, device="cpu"):
+    """Whole-job rate of a strong-scaling run: the job's units over the time of its slowest rank."""
+    return float(total_units) / max_over_ranks(dist, my_seconds, device)
+
+
 def init_process_group(backend=None):
     """Initialise torch.distributed when launched with WORLD_SIZE > 1; returns the module or None."""
     rank, local_rank, ws = world()
@@ -160,29 +183,49 @@ def decompose_files_sharded(reads_fa, monomers_fa, raw_tsv_out, dist, range_fn=N
     failure, res = None, None
     try:
         res = fn(reads_fa, monomers_fa, rank, ws, **params)
-    except lib.SdError as e:
-        failure = (e.code, e.msg)
-    status = [None] * ws
-    dist.all_gather_object(status, failure)
-    failure = next((s for s in status if s is not None), None)
-    if failure is not None:
-        raise lib.SdError(*failure)
+    except BaseException as e:   # ANY failure is exchanged: a rank that left the collective sequence would hang the others
+        failure = _status_of(e)
+    _raise_first(dist, ws, failure)
     recs, off, lo, hi, n_chunks = res
     box = [None] * ws if rank == 0 else None
     dist.gather_object((lo, recs, off), box, dst=0)
-    if rank != 0:
-        return None
-    parts = sorted(box, key=lambda t: t[0])
-    all_recs = np.concatenate([p[1] for p in parts])
-    offs, base = [np.zeros(1, dtype=np.int64)], 0
-    for _, r, o in parts:
-        offs.append(o[1:] + base)
-        base += len(r)
-    all_off = np.concatenate(offs)
-    assert len(all_off) == n_chunks + 1
-    keep = {k: v for k, v in params.items() if k in ("scoring", "part_size", "overlap", "threads")}
-    lib.assemble_files_tsv(reads_fa, monomers_fa, all_recs, all_off, raw_tsv_out, **keep)
-    return True
+    failure = None
+    if rank == 0:
+        try:
+            parts = sorted(box, key=lambda t: t[0])
+            all_recs = np.concatenate([p[1] for p in parts])
+            offs, base = [np.zeros(1, dtype=np.int64)], 0
+            for _, r, o in parts:
+                offs.append(o[1:] + base)
+                base += len(r)
+            all_off = np.concatenate(offs)
+            assert len(all_off) == n_chunks + 1
+            keep = {k: v for k, v in params.items() if k in ("scoring", "part_size", "overlap", "threads")}
+            lib.assemble_files_tsv(reads_fa, monomers_fa, all_recs, all_off, raw_tsv_out, **keep)
+        except BaseException as e:
+            failure = _status_of(e)
+    _raise_first(dist, ws, failure)   # rank 0's assembly failing is everybody's failure too
+    return True if rank == 0 else None
+
+
+def _status_of(e):
+    """(code, message) of an exception for the status exchange; anything that is not an SdError travels as
+    SD_ERR_INTERNAL with its type in the text."""
+    from . import lib
+    if isinstance(e, lib.SdError):
+        return (e.code, e.msg)
+    return (lib.SD_ERR_INTERNAL, "%s: %s" % (type(e).__name__, e))
+
+
+def _raise_first(dist, ws, failure):
+    """All ranks exchange their status; the lowest failing rank's failure is raised on every rank."""
+    from . import lib
+    status = [None] * ws
+    dist.all_gather_object(status, failure)
+    first = next((s for s in status if s is not None), None)
+    if first is not None:
+        raise lib.SdError(*first)
+    return status
 
 
 def _copy_into(src, dst, offset):
@@ -227,28 +270,42 @@ def run_files_sharded(reads_fa, monomers_fa, raw_out, final_out, alt_out, dist, 
     parts = ["%s.part%d" % (p, rank) for p in outs]
     failure = None
     try:
-        fn(reads_fa, monomers_fa, rank, ws, *parts, **params)
-    except lib.SdError as e:
-        failure = (e.code, e.msg)
-    status = [None] * ws
-    dist.all_gather_object(status, failure)
-    first = next((s for s in status if s is not None), None)
-    if first is not None:
-        for p in parts:
-            if os.path.exists(p):
+        try:
+            fn(reads_fa, monomers_fa, rank, ws, *parts, **params)
+        except BaseException as e:   # not only SdError: a rank that raised past the exchange would leave the others waiting
+            failure = _status_of(e)
+        status = [None] * ws
+        dist.all_gather_object(status, failure)
+        first = next((s for s in status if s is not None), None)
+        if first is not None:
+            if all(s is not None and s[0] == lib.SD_ERR_UNSUPPORTED for s in status):
+                return "unsplittable"
+            raise lib.SdError(*first)
+        # every later step that can fail locally (stat, truncate, copy) reports through the same exchange
+        sizes, failure = [None] * ws, None
+        try:
+            mine = [os.path.getsize(p) for p in parts]
+        except BaseException as e:
+            mine, failure = None, _status_of(e)
+        dist.all_gather_object(sizes, mine)
+        if failure is None and rank == 0 and all(sz is not None for sz in sizes):
+            try:
+                for k, p in enumerate(outs):
+                    with open(p, "wb") as f:
+                        f.truncate(sum(sz[k] for sz in sizes))
+            except BaseException as e:
+                failure = _status_of(e)
+        _raise_first(dist, ws, failure)     # also the barrier in front of the copies
+        try:
+            for k, p in enumerate(outs):
+                _copy_into(parts[k], p, sum(sz[k] for sz in sizes[:rank]))
+        except BaseException as e:
+            failure = _status_of(e)
+        _raise_first(dist, ws, failure)
+        return True
+    finally:
+        for p in parts:   # whatever happened, no .partN file stays behind
+            try:
                 os.remove(p)
-        if all(s is not None and s[0] == lib.SD_ERR_UNSUPPORTED for s in status):
-            return "unsplittable"
-        raise lib.SdError(*first)
-    sizes = [None] * ws
-    dist.all_gather_object(sizes, [os.path.getsize(p) for p in parts])
-    if rank == 0:
-        for k, p in enumerate(outs):
-            with open(p, "wb") as f:
-                f.truncate(sum(sz[k] for sz in sizes))
-    dist.barrier()
-    for k, p in enumerate(outs):
-        _copy_into(parts[k], p, sum(sz[k] for sz in sizes[:rank]))
-        os.remove(parts[k])
-    dist.barrier()
-    return True
+            except OSError:
+                pass

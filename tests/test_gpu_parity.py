@@ -3,6 +3,7 @@
   * the CPU oracle on fresh seeded inputs,
 bit-exact (integer / index work).  Runs only on a real MI355X: `pytest -m gpu`."""
 import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -54,10 +55,8 @@ def test_auto_family_picks_fast_for_default_config(tmp_path):
     assert _decompose_case(c, lib.KERNEL_AUTO, tmp_path) == c["raw"]
 
 
-@pytest.mark.parametrize("name", case_names(include_errors=True))
+@pytest.mark.parametrize("name", [n for n in case_names(include_errors=True) if n.startswith("err_")])
 def test_error_cases(name, tmp_path):
-    if not name.startswith("err_"):
-        pytest.skip("not an error case")
     c = load_case(name)
     with pytest.raises(lib.SdError) as e:
         _decompose_case(c, lib.KERNEL_AUTO, tmp_path)
@@ -189,7 +188,9 @@ def test_fuzz_regressions(oracle, case):
     d = os.path.join(FUZZ, case)
     rn, rs, _ = lib.fasta_load(os.path.join(d, "r.fa"))
     mn, ms, _ = lib.fasta_load(os.path.join(d, "m.fa"))
-    sc, part, ov, ed = eval(open(os.path.join(d, "params.txt")).read())
+    with open(os.path.join(d, "params.json")) as f:
+        pj = json.load(f)
+    sc, part, ov, ed = tuple(pj["scoring"]), pj["part_size"], pj["overlap"], pj["ed_thr"]
     exp = oracle.decompose(rn, rs, mn, ms, threads=8, sc=sc, part=part, overlap=ov, ed_thr=ed)
     for e2 in sorted({ed, -1}):
         for sub in (ms, ms[:1]):
@@ -424,8 +425,12 @@ def test_cli_two_processes_on_one_gpu(tmp_path, data):
         cmd = [sys.executable, os.path.join(ROOT, "bin", "stringdecomposer"), rfa,
                mfa, "-o", out, "-t", "4", "--second-best"]
         if nproc > 1:
+            import socket
+            with socket.socket() as sk:     # an ephemeral port: a fixed one collides with a run that is still closing
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-                   "--master-addr", "127.0.0.1", "--master-port", "29631"] + cmd[1:]
+                   "--master-addr", "127.0.0.1", "--master-port", str(port)] + cmd[1:]
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         assert p.returncode == 0, p.stdout.decode()[-2000:]
         outs.append(out)
@@ -780,8 +785,12 @@ def test_bench_line_contract():
     assert j["value"] > 1e8 and abs(j["value"] - 120 * 50000 / (j["ms_per_step"] / 1e3)) / j["value"] < 1e-6
     assert "workload" in j["config"] and "model" not in j["config"]
     r = j["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["isolated_frac"] > 0 and r["path_frac"] > 0
+    # the fill is VALU bound (measured issue ceiling); the notional HBM figure north_star asks for rides along
+    assert r["bound"] == "valu" and r["unit"] == "G wave-inst/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0 < r["frac"] < 1 and 0 < r["isolated_frac"] < 1
+    h = r["hbm_notional"]
+    assert h["unit"] == "GB/s" and h["peak"] == 8000.0 and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-9
+    assert h["isolated_frac"] > 0 and h["path_frac"] > 0
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["parity_on_sample"] is True and c["cores"] >= 1 and c["value"] > 0
     assert j["other_pipe_mode"]["pipe_mode"] == 0 and j["device_resident"]["bp_per_s"] > 0

@@ -288,3 +288,86 @@ def test_read_granular_sharding_world_size_2(tmp_path):
             with open(a, "rb") as f, open(os.path.join(d, b), "rb") as g:
                 assert f.read() == g.read()
         assert not any(".part" in f for f in os.listdir(d))
+
+
+def _run_fn_rank1_oserror(reads_fa, monomers_fa, rank, ws, raw_out, final_out, alt_out, **kw):
+    """rank 1 fails with something that is NOT an SdError after writing a part file; rank 0 succeeds."""
+    r = _checker_run_files_range(reads_fa, monomers_fa, rank, ws, raw_out, final_out, alt_out, **kw)
+    if rank == 1:
+        raise OSError(28, "No space left on device")
+    return r
+
+
+def _oserror_worker(rank, ws, port, q, d):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ws),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from stringdecomposer_amd import lib
+    dist = shard.init_process_group("gloo")
+    out = os.path.join(d, "o")
+    try:
+        shard.run_files_sharded(os.path.join(d, "many.fa"), os.path.join(d, "m.fa"), out + "_raw.tsv", out + ".tsv",
+                                out + "_alt.tsv", dist, run_fn=_run_fn_rank1_oserror, second_best=False,
+                                scoring=(-1, -1, -1, 1), part_size=500, overlap=100, threads=2)
+        q.put((rank, "ok", None))
+    except lib.SdError as e:
+        q.put((rank, "err", (e.code, e.msg)))
+    shard.barrier(dist)     # both ranks are still in step: a rank that had left the exchange would hang here
+    dist.destroy_process_group()
+
+
+def test_a_non_sd_error_on_one_rank_is_raised_on_every_rank(tmp_path):
+    """only SdError used to reach the status exchange; an OSError on one rank left the others waiting in
+    all_gather_object until the gloo timeout, with .partN files behind.  Now any exception travels as SD_ERR_INTERNAL
+    and the part files are removed on every path."""
+    from stringdecomposer_amd import lib
+    mn, ms = synth.make_monomers(3, seed=2)
+    ms = [m[:60] for m in ms]
+    names, seqs = synth.make_reads(ms, 6, read_len=900, seed=5)
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "many.fa"), names, seqs, width=70)
+    synth.write_fasta(os.path.join(d, "m.fa"), mn, ms)
+    ws, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_oserror_worker, args=(r, ws, port, q, d)) for r in range(ws)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(ws))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == ["err", "err"]
+    assert all(r[2][0] == lib.SD_ERR_INTERNAL and "OSError" in r[2][1] for r in res)
+    assert not any(".part" in f for f in os.listdir(d))
+
+
+def _strong_worker(rank, ws, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ws),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist = shard.init_process_group("gloo")
+    c3 = shard.strong_share("c3", rank, ws, n_reads=1001)
+    c5 = shard.strong_share("c5", rank, ws, seq_len=2_000_123)
+    rate = shard.job_rate(dist, 1000.0, 1.0 + rank)     # the job is as slow as its slowest rank
+    q.put((rank, c3, c5, rate))
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_shares_world_size_2():
+    """`bench.py --scaling strong`: ONE job split like the multi-process command line splits it -- blocks of reads
+    (C3) or of the global chunk table (C5) that tile the job exactly -- and a whole-job rate over the MAX time."""
+    from stringdecomposer_amd import lib
+    ws, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_strong_worker, args=(r, ws, port, q)) for r in range(ws)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(ws))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [("reads", 0, 501), ("reads", 501, 1001)]
+    n_chunks = lib.chunk_table_size([2_000_123])
+    assert n_chunks == len(lib.chunk_plan(2_000_123, 5000, 500))
+    assert res[0][2] == ("chunks", 0, (n_chunks + 1) // 2, n_chunks) and res[1][2] == ("chunks", (n_chunks + 1) // 2, n_chunks, n_chunks)
+    assert all(abs(r[3] - 500.0) < 1e-9 for r in res)

@@ -2,6 +2,7 @@
 """Randomised parity campaign (developer tool, needs a GPU): random template sets, scorings,
 chunk sizes, N densities and --ed_thr values through libsd_hip vs the CPU oracle.
 usage: python tools/fuzz_gpu.py [cases] [seed] [log file to append the summary to]"""
+import json
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -98,7 +99,7 @@ for case in range(cases):
         os.makedirs(d, exist_ok=True)
         synth.write_fasta(os.path.join(d, "r.fa"), rn, reads)
         synth.write_fasta(os.path.join(d, "m.fa"), mn, ms)
-        open(os.path.join(d, "params.txt"), "w").write(repr((sc, part, ov, ed)))
+        json.dump({"scoring": list(sc), "part_size": part, "overlap": ov, "ed_thr": ed}, open(os.path.join(d, "params.json"), "w"))
 summary = "fuzz: seed %d, %d cases, %d mismatches, %.1fs" % (seed, cases, bad, time.time() - t0)
 print(summary)
 if len(sys.argv) > 3:   # append to a log (copied to profiles/ after the run): which build, which seeds
