@@ -138,6 +138,21 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
                            TextBuf& alt, std::string& err, const uint32_t* id, const uint32_t* idh) {
     fin.clear();
     alt.clear();
+    std::vector<std::string> pf, pa;
+    const int rc = process_parts(reads, n_reads, rows, row_off, pf, pa, err, id, idh);
+    if (rc) return rc;
+    const double t_c = now_seconds();
+    gather_text(pf, threads, fin);
+    gather_text(pa, threads, alt);
+    t_concat += now_seconds() - t_c;
+    return SD_OK;
+}
+
+int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off,
+                                 std::vector<std::string>& pf, std::vector<std::string>& pa, std::string& err,
+                                 const uint32_t* id, const uint32_t* idh) {
+    pf.clear();
+    pa.clear();
     const int64_t nB = row_off[n_reads];
     if (nB == 0) return SD_OK;
     const double t_0 = now_seconds();
@@ -203,11 +218,19 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
     // rows -> text, in slices of blocks formatted by all threads
     const int64_t grain = second_best ? 64 : 2048;
     const int64_t n_sl = (nB + grain - 1) / grain;
-    std::vector<std::string> pf((size_t)n_sl), pa((size_t)n_sl);
+    pf.assign((size_t)n_sl, std::string());
+    pa.assign((size_t)n_sl, std::string());
+    size_t key_bytes = 0, name_max = 0;
+    for (const std::string& k : keys) key_bytes += k.size();
+    for (size_t r = 0; r < n_reads; ++r) name_max = std::max(name_max, reads[r].name_len);
     parallel_for(n_sl, threads, 1, [&](int64_t sl) {
         std::string& of = pf[(size_t)sl];
         std::string& oa = pa[(size_t)sl];
         const int64_t b1 = std::min(nB, (sl + 1) * grain);
+        // room for the slice up front: a string that doubles its way up copies (and page-faults) the text twice over
+        of.reserve((size_t)(b1 - sl * grain) * (name_max + 160));
+        if (second_best) oa.reserve((size_t)(b1 - sl * grain) * (key_bytes + (size_t)nK * (name_max + 36)));
+        std::vector<double> kbuf((size_t)nK), hbuf((size_t)T);
         for (int64_t b = sl * grain; b < b1; ++b) {
             const sd_rec& x = rows[b];
             const PostRead& rd = reads[(size_t)read_of[(size_t)b]];
@@ -217,16 +240,12 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
             const std::string* h0n = nullptr;
             const std::string* h1n = nullptr;
             const double* kv = nullptr;
-            std::vector<double> kbuf;
-            std::vector<double> hbuf;
             if (!second_best) {
                 score = id ? ident_percent(id[b]) : vals[(size_t)b];
             } else {
-                kbuf.resize((size_t)nK);
                 if (id) {
                     const uint32_t* v = id + (size_t)b * T;
                     for (int k = 0; k < nK; ++k) kbuf[(size_t)k] = ident_percent(v[kcol[(size_t)k]]);
-                    hbuf.resize((size_t)T);
                     const uint32_t* hw = idh + (size_t)b * T;
                     for (int j = 0; j < T; ++j) hbuf[(size_t)j] = ident_percent(hw[j]);
                 } else {
@@ -283,13 +302,9 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
             }
         }
     });
-    const double t_c = now_seconds();
-    gather_text(pf, threads, fin);
-    gather_text(pa, threads, alt);
     t_prepare += t_a - t_0;
     t_identity += t_b - t_a;
-    t_format += t_c - t_b;
-    t_concat += now_seconds() - t_c;
+    t_format += now_seconds() - t_b;
     return SD_OK;
 }
 

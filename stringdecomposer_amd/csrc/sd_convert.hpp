@@ -31,6 +31,10 @@ class PostProcessor {
     int process(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off, TextBuf& fin,
                 TextBuf& alt, std::string& err, const uint32_t* id = nullptr,
                 const uint32_t* idh = nullptr);   // fin / alt are REPLACED by the text of this batch
+    // the same, as the slices the threads formatted (in order; the caller writes them without a gather copy)
+    int process_parts(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off,
+                      std::vector<std::string>& fin_parts, std::vector<std::string>& alt_parts, std::string& err,
+                      const uint32_t* id = nullptr, const uint32_t* idh = nullptr);
     const std::vector<std::string>& interleaved_seqs() const { return il_seq; }   // m0, m0', m1, m1', ... (main.py:79-84)
     const std::vector<int32_t>& own_interleaved() const { return own_il32; }      // DP template -> interleaved index
     int tmpl_of_name(const std::string& nm) const;   // first template of that name in the DP's order, -1 if none

@@ -5,6 +5,9 @@
 // kernels (sd_generic.hip, sd_fast.hip); there is no CPU implementation of it in this library.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -2256,11 +2259,19 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     sd::PostProcessor pp;
     rc = pp.init(monos, min_identity, second_best != 0, lr_coef, p->device, p->threads, err);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
-    FILE* fr = std::fopen(raw_tsv_out, "wb");
-    FILE* ff = fr ? std::fopen(final_tsv_out, "wb") : nullptr;
-    FILE* fa = ff ? std::fopen(alt_tsv_out, "wb") : nullptr;
-    if (!fr || !ff || !fa) {
-        for (FILE* f : {fr, ff, fa}) if (f) std::fclose(f);
+    // the three outputs as plain descriptors: every batch's text is written by all host threads with pwrite at its
+    // offset (sd::write_parts) -- the copy into the page cache is what a 300-MB _alt batch costs
+    const int fr = ::open(raw_tsv_out, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    const int ff = fr >= 0 ? ::open(final_tsv_out, O_WRONLY | O_CREAT | O_TRUNC, 0666) : -1;
+    const int fa = ff >= 0 ? ::open(alt_tsv_out, O_WRONLY | O_CREAT | O_TRUNC, 0666) : -1;
+    int64_t off_r = 0, off_f = 0, off_a = 0;
+    auto close_all = [&]() {
+        bool ok = true;
+        for (int f : {fr, ff, fa}) if (f >= 0 && ::close(f) != 0) ok = false;
+        return ok;
+    };
+    if (fr < 0 || ff < 0 || fa < 0) {
+        close_all();
         set_err(errbuf, errlen, std::string("cannot write ") + raw_tsv_out);
         return SD_ERR_IO;
     }
@@ -2271,7 +2282,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     if (info) info[3] = (int64_t)job.table.size();
     job.row_off = static_cast<int64_t*>(std::calloc(reads.size() + 1, sizeof(int64_t)));
     if (!job.row_off) {
-        for (FILE* f : {fr, ff, fa}) std::fclose(f);
+        close_all();
         set_err(errbuf, errlen, "out of host memory");
         return SD_ERR_INTERNAL;
     }
@@ -2310,7 +2321,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     double t_fmt = 0, t_post = 0, t_io = 0;
     auto sink_loop = [&]() {
         sd::HostPool::lane() = 1;   // this thread's parallel loops run on the second pool, beside the driver's
-        sd::TextBuf raw, fin, alt;
+        std::vector<std::string> fin_parts, alt_parts;
         std::vector<sd::PostRead> preads;
         for (;;) {
             Work w;
@@ -2338,21 +2349,20 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
                     sd::format_rows(parts[(size_t)x], reads[sl.r].name, reads[sl.r].name_len, ts.tnames, w.rows + sl.a,
                                     (size_t)(sl.b - sl.a), sl.a > off[sl.r - w.r0] ? w.rows[sl.a - 1].end : 0);
                 });
-                sd::gather_text(parts, p->threads, raw);
                 t_fmt += now_s() - t0;
                 t0 = now_s();
                 preads.clear();
                 for (size_t r = w.r0; r < w.r1; ++r)
                     preads.push_back(sd::PostRead{reads[r].name, reads[r].name_len, reads[r].seq, reads[r].len});
                 std::string e2;
-                const int r2 = pp.process(preads.data(), preads.size(), w.rows, off, fin, alt, e2, w.id, second_best ? w.idh : nullptr);
+                const int r2 = pp.process_parts(preads.data(), preads.size(), w.rows, off, fin_parts, alt_parts, e2, w.id,
+                                                second_best ? w.idh : nullptr);
                 t_post += now_s() - t0;
                 t0 = now_s();
                 if (r2) {
                     sink_fail(r2, e2);
-                } else if (std::fwrite(raw.data(), 1, raw.size(), fr) != raw.size() ||
-                           std::fwrite(fin.data(), 1, fin.size(), ff) != fin.size() ||
-                           std::fwrite(alt.data(), 1, alt.size(), fa) != alt.size()) {
+                } else if (!sd::write_parts(fr, off_r, parts, p->threads) || !sd::write_parts(ff, off_f, fin_parts, p->threads) ||
+                           !sd::write_parts(fa, off_a, alt_parts, p->threads)) {
                     sink_fail(SD_ERR_IO, std::string("short write to ") + raw_tsv_out);
                 }
                 t_io += now_s() - t0;
@@ -2417,8 +2427,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     wq_cv.notify_all();
     sink_thread.join();
     if (rc == SD_OK && sink_rc.load()) { rc = sink_rc.load(); err = sink_err; }
-    const bool w1 = std::fclose(fr) == 0, w2 = std::fclose(ff) == 0, w3 = std::fclose(fa) == 0;
-    if (rc == SD_OK && !(w1 && w2 && w3)) { rc = SD_ERR_IO; err = std::string("short write to ") + raw_tsv_out; }
+    if (!close_all() && rc == SD_OK) { rc = SD_ERR_IO; err = std::string("short write to ") + raw_tsv_out; }
     if (timing)
         std::fprintf(stderr, "[sd timing] %zu batches: pack+enqueue %.1f ms, wait %.1f ms, raw text %.1f ms, post-processing %.1f ms, "
                      "file writes %.1f ms, total %.1f ms\n", batches.size(), pipe.pack_s * 1e3, pipe.wait_s * 1e3, t_fmt * 1e3,

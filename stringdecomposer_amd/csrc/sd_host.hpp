@@ -322,6 +322,26 @@ inline void gather_text(const std::vector<std::string>& parts, int threads, Text
     });
 }
 
+// parts -> the file `fd` at `off` (advanced by the total), written by up to `threads` threads with pwrite: the copy
+// into the page cache is the cost of a TSV write (300 MB of _alt rows per --second-best batch), and it parallelises
+inline bool write_parts(int fd, int64_t& off, const std::vector<std::string>& parts, int threads) {
+    std::vector<int64_t> at(parts.size() + 1, off);
+    for (size_t i = 0; i < parts.size(); ++i) at[i + 1] = at[i] + (int64_t)parts[i].size();
+    std::vector<uint8_t> bad(parts.size(), 0);
+    parallel_for((int64_t)parts.size(), threads, 1, [&](int64_t i) {
+        const std::string& p = parts[(size_t)i];
+        size_t done = 0;
+        while (done < p.size()) {
+            const ssize_t k = ::pwrite(fd, p.data() + done, p.size() - done, (off_t)(at[(size_t)i] + (int64_t)done));
+            if (k <= 0) { bad[(size_t)i] = 1; return; }
+            done += (size_t)k;
+        }
+    });
+    off = at[parts.size()];
+    for (uint8_t b : bad) if (b) return false;
+    return true;
+}
+
 // 2-bit packing of one chunk (16 bases per dword, base i at bits 2*(i&15)); returns true if the chunk
 // contains N (whose 2-bit code is 0; the N mask carries it).  Eight bases per 64-bit step: for the
 // validated alphabet ((c >> 1) ^ (c >> 2)) & 3 maps A,C,G,T to 0,1,2,3 and N to 0.
