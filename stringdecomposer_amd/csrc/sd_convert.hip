@@ -4,6 +4,7 @@
 // identities come from the device kernel (sd_nw.hip) when a device is given, from the host
 // implementation (sd_post.hip) otherwise or for input the kernel does not take.
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <chrono>
 #include <cstdint>
@@ -197,6 +198,21 @@ int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd
             spans.emplace_back(reads[r].seq, reads[r].len);
             pos += reads[r].len;
         }
+    }
+    {
+        // edlib computes the path of a long alignment with Hirschberg's split instead of its block traceback once
+        // (2*8+4) * ceil(|query| / 64) * |target| reaches 1 MB (edlib.cpp:1186-1190): ~19.6 kb against a 171-bp
+        // monomer.  Its choice among equally good paths -- hence the '=' count and the identity -- may then differ
+        // from the traceback priorities this implementation reproduces.  Cannot happen with the default 5.5-kb
+        // chunks (-b >= 19000 or kb-long monomers); say so once instead of differing silently.
+        size_t tmax = 1;
+        for (const std::string& t : il_seq) tmax = std::max(tmax, t.size());
+        int64_t worst = 0;
+        for (int64_t b = 0; b < nB; ++b) worst = std::max<int64_t>(worst, seg_len[(size_t)b]);
+        static std::atomic<bool> warned{false};
+        if ((int64_t)20 * ((worst + 63) / 64) * (int64_t)tmax >= (1 << 20) && !warned.exchange(true))
+            std::fprintf(stderr, "WARNING: a block of %lld bp is long enough for edlib to switch to Hirschberg's algorithm "
+                         "(edlib.cpp:1186); its identity may differ from the reference's in the last digits\n", (long long)worst);
     }
     const double t_a = now_seconds();
     RawVec<double> vals, hvals;
