@@ -182,12 +182,14 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
             // per-row scalars of the block, one row per lane (read once, then v_readlane per row)
             const int rl = a + lane;
             const bool rvalid = rl >= 1 && rl <= i;
-            const int vBd = rvalid ? 4 * (Bof(rl) + del - (rl - 1) * ins) + 1 : 0;
-            const int vR = rvalid ? rc.code(rl) : 0;
+            // both in one word -- (start term << 3) | read symbol -- so that a row costs ONE v_readlane (the split is
+            // scalar work); |start term| < 2^26 for every scoring the fast family takes
+            const int vBR = rvalid ? (((4 * (Bof(rl) + del - (rl - 1) * ins) + 1) << 3) | rc.code(rl)) : 0;
             for (int r_i = rstart; r_i <= i; ++r_i) {
-                const int r = __builtin_amdgcn_readlane(vR, r_i - a);
-                const int32_t Bd2 = __builtin_amdgcn_readlane(vBd, r_i - a);
-                const int32_t pdEdge = lane_up_neg(T[QQ - 1]);
+                const int br = __builtin_amdgcn_readlane(vBR, r_i - a);
+                const int r = br & 7;
+                const int32_t Bd2 = br >> 3;
+                const int32_t pdEdge = lane_up_min(T[QQ - 1]);   // lane 0: identity of the max with Bd2 below
                 int32_t loc[QQ];
                 int32_t pd = pdEdge;
                 int32_t mm4[QQP];
@@ -199,7 +201,11 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
                 }
 #pragma unroll
                 for (int q = 0; q < QQ; ++q) {
-                    const int32_t v = max(pd, Bd2) + mm4[q];   // diag (tag 1) / start (tag 0); lane 0: pd = -inf
+                    // diag (tag 1) / start (tag 0).  q == 0: pd comes from the lane below through DPP; with the start term
+                    // in a VGPR the move and the max are ONE v_max_i32_dpp (lane 0 keeps the start term: max(identity, .))
+                    int32_t Bq = Bd2;
+                    if (q == 0) asm volatile("" : "+v"(Bq));
+                    const int32_t v = max(pd, Bq) + mm4[q];
                     const int32_t w = T[q];                    // insertion (tag 2): the stored value itself
                     if (q == 0) {
                         // k == 0 (lane 0): the fill never takes the insertion there, but the reference's
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
                     }
                     pd = T[q];
                 }
-                const int32_t X = lane_up_neg(wave_prefix_max(loc[QQ - 1] | 3));
+                const int32_t X = lane_up_min(wave_prefix_max(loc[QQ - 1] | 3));   // only ever an operand of max
                 uint32_t bits = 0;
 #pragma unroll
                 for (int q = 0; q < QQ; ++q) {
@@ -638,7 +644,8 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
     #ifndef SD_FILL_WPC
 #define SD_FILL_WPC 16   // resident fill waves per CU (4 per SIMD)
 #endif
-    const int grid = std::min((n_chunks + NW - 1) / NW, (SD_FILL_WPC / NW) * n_cu);  // persistent
+    int grid = std::min((n_chunks + NW - 1) / NW, (SD_FILL_WPC / NW) * n_cu);  // persistent
+    if (const char* ev = getenv("SD_FILL_GRID")) grid = std::max(1, atoi(ev));   // developer knob
     // `queue` points at a zeroed work-queue head that no earlier launch has used (sd_engine hands out a fresh
     // one per run): no memset kernel sits between the launches of a stream
     if (plan.wide && plan.waves > 1) {
@@ -698,7 +705,8 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
                        const uint16_t* kpos, const int32_t* nkept) {
     int bpc = 8;
     if (const char* ev = getenv("SD_TRACE_BPC")) bpc = std::max(1, atoi(ev));  // developer knob
-    const int grid = std::min((n_chunks + 3) / 4, bpc * n_cu);  // persistent: 8 workgroups of 4 waves per CU
+    int grid = std::min((n_chunks + 3) / 4, bpc * n_cu);  // persistent: 8 workgroups of 4 waves per CU
+    if (const char* ev = getenv("SD_TRACE_GRID")) grid = std::max(1, atoi(ev));   // developer knob
 #define SD_TRACE(QQ)                                                                              \
     hipLaunchKernelGGL(sd_fast_trace<QQ>, dim3(grid), dim3(256), 0, st, chunks, n_chunks, bases2, \
                        nmask, slot_of, tcodes, lane_consts, toff, tlen, sc, plan.P, B, argV, ckpt, \

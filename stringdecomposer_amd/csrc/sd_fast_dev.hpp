@@ -59,6 +59,12 @@ __device__ __forceinline__ int wave_max(int v) {
 #endif
 }
 
+// value of lane l-1; lane 0 gets INT_MIN, the identity of max: a following max(., y) folds with the move into ONE
+// v_max_i32_dpp (no constant to materialise, no separate v_mov_b32_dpp).  Only for values that feed a max directly.
+__device__ __forceinline__ int lane_up_min(int x) {
+    return __builtin_amdgcn_update_dpp(INT_MIN, x, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+}
+
 // value of lane l-1; lane 0 gets -inf
 __device__ __forceinline__ int lane_up_neg(int x) {
     return __builtin_amdgcn_update_dpp(NEG_INF32, x, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
