@@ -820,3 +820,54 @@ def test_f16_range_guard_trips_and_the_batch_is_repeated_with_integer_cells(orac
     tn = mn + [m + "'" for m in mn]
     assert b"".join(lib.format_rows(n, tn, r) for n, r in zip(rn, rows)) == want
     assert lib.guard_trips() > t1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("second_best", [False, True])
+def test_in_stream_identities_equal_the_text_based_path_across_batches(tmp_path, second_best):
+    """The identities of the final TSV come in-stream with the records of every device batch (csrc/sd_ident.hip) and
+    follow them through the seam merge; here the job is cut into many small batches, so that reads span batches (the
+    carry path of RowJob) and chunk seams drop records, and the three files must equal those of the text-based path of
+    round 2 (SD_FLAG_NO_STREAM_IDENT) byte for byte -- which the reference-CLI goldens pin."""
+    mn, ms = synth.make_monomers(6, seed=21)
+    rn, rs = synth.make_reads(ms, 14, read_len=9000, seed=22)
+    rs[3] = rs[3][:700] + b"N" * 40 + rs[3][740:2500]            # N inside blocks, a short read
+    rs[7] = rs[7][:200]                                            # shorter than a chunk
+    rfa, mfa = str(tmp_path / "r.fa"), str(tmp_path / "m.fa")
+    synth.write_fasta(rfa, rn, rs, width=70)
+    synth.write_fasta(mfa, mn, ms)
+    outs = {}
+    for tag, flags in (("stream", 0), ("text", lib.FLAG_NO_STREAM_IDENT)):
+        o = [str(tmp_path / ("%s_%s.tsv" % (tag, x))) for x in ("raw", "final", "alt")]
+        lib.run_files(rfa, mfa, o[0], o[1], o[2], second_best=second_best, threads=4, part_size=1000, overlap=200,
+                      max_batch_rows=7000, flags=flags)
+        st = lib.last_run_stats()
+        assert st["batches"] >= 10
+        if tag == "stream":
+            assert st["ident_pairs"] > 0 and st["text_identity_ms"] < 1e-3
+        else:
+            assert st["ident_pairs"] == 0 and st["text_identity_ms"] > 0
+        outs[tag] = [open(x, "rb").read() for x in o]
+    assert outs["stream"] == outs["text"]
+    assert outs["stream"][1].count(b"\n") > 500
+
+
+@pytest.mark.gpu
+def test_in_stream_identities_fall_back_when_a_batch_has_too_many_records(tmp_path):
+    """A batch with more records than the identity outputs have room for (one per 48 rows: 20-bp monomers give one per
+    ~20) is post-processed from the read text instead; same files."""
+    st0 = synth.Stream(5, 77)
+    ms = [synth._to_ascii(st0.below(20 + k, 4)) for k in range(4)]
+    mn = ["s%d" % k for k in range(4)]
+    rn, rs = synth.make_reads(ms, 3, read_len=120000, seed=9)
+    rfa, mfa = str(tmp_path / "r.fa"), str(tmp_path / "m.fa")
+    synth.write_fasta(rfa, rn, rs, width=0)
+    synth.write_fasta(mfa, mn, ms)
+    outs = []
+    for flags in (0, lib.FLAG_NO_STREAM_IDENT):
+        o = [str(tmp_path / ("%d_%s.tsv" % (flags, x))) for x in ("raw", "final", "alt")]
+        lib.run_files(rfa, mfa, o[0], o[1], o[2], second_best=False, threads=4, flags=flags)
+        if flags == 0:
+            assert lib.last_run_stats()["text_identity_ms"] > 0     # the in-stream words were not used
+        outs.append([open(x, "rb").read() for x in o])
+    assert outs[0] == outs[1] and outs[0][1].count(b"\n") > 5000
