@@ -136,11 +136,12 @@ inline double ident_percent(uint32_t w) {
 }  // namespace
 
 int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off, TextBuf& fin,
-                           TextBuf& alt, std::string& err, const uint32_t* id, const uint32_t* idh) {
+                           TextBuf& alt, std::string& err, const IdentRef* ident) {
     fin.clear();
     alt.clear();
-    std::vector<std::string> pf, pa;
-    const int rc = process_parts(reads, n_reads, rows, row_off, pf, pa, err, id, idh);
+    std::vector<std::string> pf;
+    std::vector<TextBuf> pa;
+    const int rc = process_parts(reads, n_reads, rows, row_off, pf, pa, err, ident);
     if (rc) return rc;
     const double t_c = now_seconds();
     gather_text(pf, threads, fin);
@@ -150,8 +151,8 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
 }
 
 int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off,
-                                 std::vector<std::string>& pf, std::vector<std::string>& pa, std::string& err,
-                                 const uint32_t* id, const uint32_t* idh) {
+                                 std::vector<std::string>& pf, std::vector<TextBuf>& pa, std::string& err,
+                                 const IdentRef* ident) {
     pf.clear();
     pa.clear();
     const int64_t nB = row_off[n_reads];
@@ -159,24 +160,34 @@ int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd
     const double t_0 = now_seconds();
     const int T = (int)il_seq.size();
     const int nK = (int)keys.size();
-    if (id && (!second_best || idh)) {
+    const int per = second_best ? T : 1;
+    bool have = ident && ident->id && (!second_best || ident->idh);
+    // words of row b (plain / compressed)
+    auto words = [&](int64_t b, bool homo) -> const uint32_t* {
+        if (!ident->src) return (homo ? ident->idh : ident->id) + (size_t)b * (size_t)per;
+        const int64_t sx = ident->src[b];
+        return sx >= 0 ? (homo ? ident->idh : ident->id) + (size_t)sx * (size_t)per
+                       : (homo ? ident->xidh : ident->xid) + (size_t)(-1 - sx) * (size_t)per;
+    };
+    if (have) {
         // every word computed?  (0xffffffff: a pair the kernel left out; dist + matches == 0 cannot be an alignment)
-        const int64_t nw = second_best ? nB * T : nB;
-        std::vector<uint8_t> bad((size_t)((nw + 65535) / 65536), 0);
+        std::vector<uint8_t> bad((size_t)((nB + 4095) / 4096), 0);
         parallel_for((int64_t)bad.size(), threads, 1, [&](int64_t blk) {
-            const int64_t e = std::min<int64_t>(nw, (blk + 1) * 65536);
-            uint8_t b = 0;
-            for (int64_t x = blk * 65536; x < e; ++x) {
-                b |= (uint8_t)(id[x] == 0xffffffffu || id[x] == 0u);
-                if (idh) b |= (uint8_t)(idh[x] == 0xffffffffu || idh[x] == 0u);
+            const int64_t e = std::min<int64_t>(nB, (blk + 1) * 4096);
+            uint8_t bb = 0;
+            for (int64_t b = blk * 4096; b < e; ++b) {
+                const uint32_t* v = words(b, false);
+                for (int x = 0; x < per; ++x) bb |= (uint8_t)(v[x] == 0xffffffffu || v[x] == 0u);
+                if (second_best) {
+                    const uint32_t* h = words(b, true);
+                    for (int x = 0; x < per; ++x) bb |= (uint8_t)(h[x] == 0xffffffffu || h[x] == 0u);
+                }
             }
-            bad[(size_t)blk] = b;
+            bad[(size_t)blk] = bb;
         });
-        for (uint8_t b : bad) if (b) { id = nullptr; break; }
-    } else {
-        id = nullptr;
+        for (uint8_t bb : bad) if (bb) { have = false; break; }
     }
-    if (!id) idh = nullptr;
+    const bool id = have;   // (name kept: "identities came with the rows")
     // text = the reads that have blocks, concatenated; blocks never cross a read
     std::vector<std::pair<const char*, int64_t>> spans;
     std::vector<int64_t> seg_start((size_t)nB);
@@ -235,17 +246,21 @@ int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd
     const int64_t grain = second_best ? 64 : 2048;
     const int64_t n_sl = (nB + grain - 1) / grain;
     pf.assign((size_t)n_sl, std::string());
-    pa.assign((size_t)n_sl, std::string());
+    pa.assign((size_t)n_sl, TextBuf());
     size_t key_bytes = 0, name_max = 0;
     for (const std::string& k : keys) key_bytes += k.size();
     for (size_t r = 0; r < n_reads; ++r) name_max = std::max(name_max, reads[r].name_len);
     parallel_for(n_sl, threads, 1, [&](int64_t sl) {
         std::string& of = pf[(size_t)sl];
-        std::string& oa = pa[(size_t)sl];
+        TextBuf& oa = pa[(size_t)sl];
         const int64_t b1 = std::min(nB, (sl + 1) * grain);
         // room for the slice up front: a string that doubles its way up copies (and page-faults) the text twice over
         of.reserve((size_t)(b1 - sl * grain) * (name_max + 160));
-        if (second_best) oa.reserve((size_t)(b1 - sl * grain) * (key_bytes + (size_t)nK * (name_max + 36)));
+        // _alt rows (nK per block, 300 MB per C4 batch) are written through a pointer into an uninitialised buffer
+        // sized for the worst case: name + key + two 11-digit ints + a 48-byte number + 6 separators per row
+        const size_t alt_row_max = name_max + 11 + 11 + 48 + 8;
+        if (second_best) oa.resize((size_t)(b1 - sl * grain) * (key_bytes + (size_t)nK * alt_row_max));
+        char* wa = oa.data();
         std::vector<double> kbuf((size_t)nK), hbuf((size_t)T);
         for (int64_t b = sl * grain; b < b1; ++b) {
             const sd_rec& x = rows[b];
@@ -257,12 +272,12 @@ int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd
             const std::string* h1n = nullptr;
             const double* kv = nullptr;
             if (!second_best) {
-                score = id ? ident_percent(id[b]) : vals[(size_t)b];
+                score = id ? ident_percent(words(b, false)[0]) : vals[(size_t)b];
             } else {
                 if (id) {
-                    const uint32_t* v = id + (size_t)b * T;
+                    const uint32_t* v = words(b, false);
                     for (int k = 0; k < nK; ++k) kbuf[(size_t)k] = ident_percent(v[kcol[(size_t)k]]);
-                    const uint32_t* hw = idh + (size_t)b * T;
+                    const uint32_t* hw = words(b, true);
                     for (int j = 0; j < T; ++j) hbuf[(size_t)j] = ident_percent(hw[j]);
                 } else {
                     const double* v = &vals[(size_t)b * T];
@@ -307,16 +322,26 @@ int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd
             of.push_back(logit > 0 ? '+' : '?');
             of.push_back('\n');
             if (second_best) {   // main.py:161-165: one row per name of the dict
+                char mid[32];    // "\t<start>\t<end>\t": the same for the nK rows of the block
+                size_t ml = 0;
+                {
+                    std::string t;
+                    t.push_back('\t'); put_int(t, x.start); t.push_back('\t'); put_int(t, x.end); t.push_back('\t');
+                    ml = t.size();
+                    std::memcpy(mid, t.data(), ml);
+                }
                 for (int k = 0; k < nK; ++k) {
-                    oa.append(rd.name, rd.name_len); oa.push_back('\t');
-                    oa.append(keys[(size_t)k]); oa.push_back('\t');
-                    put_int(oa, x.start); oa.push_back('\t');
-                    put_int(oa, x.end); oa.push_back('\t');
-                    put_f2(oa, kv[k]);
-                    oa.append(k == ko ? "\t*\n" : "\t-\n", 3);
+                    std::memcpy(wa, rd.name, rd.name_len); wa += rd.name_len;
+                    *wa++ = '\t';
+                    const std::string& key = keys[(size_t)k];
+                    std::memcpy(wa, key.data(), key.size()); wa += key.size();
+                    std::memcpy(wa, mid, ml); wa += ml;
+                    wa = put_fixed2_at(wa, kv[k]);
+                    std::memcpy(wa, k == ko ? "\t*\n" : "\t-\n", 3); wa += 3;
                 }
             }
         }
+        if (second_best) oa.resize((size_t)(wa - oa.data()));
     });
     t_prepare += t_a - t_0;
     t_identity += t_b - t_a;

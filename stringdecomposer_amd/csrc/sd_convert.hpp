@@ -17,6 +17,18 @@ struct PostRead {
     const char* seq; int64_t len;       // upper-case sequence (main.py:66-67)
 };
 
+// Identities that came with the rows from the device (sd_ident.hip): one word (dist << 16) | matches per row (light
+// mode: the row's own monomer) or per (row, interleaved monomer) pair, plain (id) / homopolymer-compressed (idh).
+// src == nullptr: row b's words start at id + b * per.  Otherwise src[b] >= 0: record src[b] of id / idh; src[b] < 0:
+// entry -1 - src[b] of xid / xidh (rows of a read that began in an earlier device batch).
+struct IdentRef {
+    const uint32_t* id = nullptr;
+    const uint32_t* idh = nullptr;
+    const int64_t* src = nullptr;
+    const uint32_t* xid = nullptr;
+    const uint32_t* xidh = nullptr;
+};
+
 class PostProcessor {
   public:
     // monomers in file order (names = first header token, sequences upper-case); device < 0: host identities
@@ -29,12 +41,11 @@ class PostProcessor {
     // (dist << 16) | matches per row (light mode: the row's own monomer) or per (row, interleaved monomer) pair,
     // plain / homopolymer-compressed; rows without a computed word send the batch through the text-based path.
     int process(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off, TextBuf& fin,
-                TextBuf& alt, std::string& err, const uint32_t* id = nullptr,
-                const uint32_t* idh = nullptr);   // fin / alt are REPLACED by the text of this batch
+                TextBuf& alt, std::string& err, const IdentRef* ident = nullptr);   // fin / alt are REPLACED
     // the same, as the slices the threads formatted (in order; the caller writes them without a gather copy)
     int process_parts(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off,
-                      std::vector<std::string>& fin_parts, std::vector<std::string>& alt_parts, std::string& err,
-                      const uint32_t* id = nullptr, const uint32_t* idh = nullptr);
+                      std::vector<std::string>& fin_parts, std::vector<TextBuf>& alt_parts, std::string& err,
+                      const IdentRef* ident = nullptr);
     const std::vector<std::string>& interleaved_seqs() const { return il_seq; }   // m0, m0', m1, m1', ... (main.py:79-84)
     const std::vector<int32_t>& own_interleaved() const { return own_il32; }      // DP template -> interleaved index
     int tmpl_of_name(const std::string& nm) const;   // first template of that name in the DP's order, -1 if none

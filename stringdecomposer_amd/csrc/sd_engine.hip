@@ -100,6 +100,50 @@ struct AllocTimer {
     ~AllocTimer() { g_alloc_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
+// Page-locked blocks that change hands: the identity words of a batch (up to 2 x 84 MB with --second-best) go with
+// the batch's rows to the thread that turns them into text, while the engine already fetches the next batch; a freed
+// block waits here for the next taker instead of going through hipHostFree / hipHostMalloc (milliseconds per 10 MB).
+struct PinPool {
+    struct Blk { void* p; size_t bytes; };
+    std::mutex m;
+    std::vector<Blk> free_;
+    void* take(size_t bytes, size_t& got) {
+        {
+            std::lock_guard<std::mutex> g(m);
+            size_t best = free_.size();
+            for (size_t i = 0; i < free_.size(); ++i)
+                if (free_[i].bytes >= bytes && (best == free_.size() || free_[i].bytes < free_[best].bytes)) best = i;
+            if (best < free_.size()) {
+                Blk b = free_[best];
+                free_.erase(free_.begin() + (long)best);
+                got = b.bytes;
+                return b.p;
+            }
+        }
+        const size_t want = bytes + bytes / 8 + 4096;
+        void* q = nullptr;
+        AllocTimer at;
+        SD_HIP(hipHostMalloc(&q, want, hipHostMallocDefault));
+        got = want;
+        return q;
+    }
+    void give(void* p, size_t bytes) {
+        if (!p) return;
+        std::lock_guard<std::mutex> g(m);
+        free_.push_back(Blk{p, bytes});
+        while (free_.size() > 6) {   // keep a handful; the oldest goes back to the runtime
+            (void)hipHostFree(free_.front().p);
+            free_.erase(free_.begin());
+        }
+    }
+    void release_all() {
+        std::lock_guard<std::mutex> g(m);
+        for (Blk& b : free_) (void)hipHostFree(b.p);
+        free_.clear();
+    }
+};
+PinPool g_pinpool;
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -255,7 +299,9 @@ struct sd_engine {
     DevBuf<int> d_ilongcnt, d_ickpos;
     DevBuf<uint4> d_ick;
     DevBuf<uint32_t> d_ident, d_identh;
-    PinBuf<uint32_t> h_ident, h_identh;
+    uint32_t* h_ident = nullptr;                 // pinned blocks from g_pinpool, owned until a sink takes them
+    uint32_t* h_identh = nullptr;
+    size_t h_ident_bytes = 0, h_identh_bytes = 0;
     int64_t ident_cap = 0;                       // records the identity outputs have room for
     bool ident_valid = false;                    // the last fetch brought identities for every record
     sd::IdentArgs ia_plain{}, ia_homo{};
@@ -276,6 +322,8 @@ struct sd_engine {
         for (hipEvent_t e : ev_trace) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_run0, ev_run1, ev_cmp0, ev_cmp1, ev_in, ev_id0, ev_id1})
             if (e) (void)hipEventDestroy(e);
+        g_pinpool.give(h_ident, h_ident_bytes);
+        g_pinpool.give(h_identh, h_identh_bytes);
     }
 
     size_t workspace_bytes() const {
@@ -1065,11 +1113,20 @@ static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errle
             SD_HIP(hipMemcpyAsync(e->h_recs.p, e->d_dense.p, sizeof(sd_rec) * (size_t)total, hipMemcpyDeviceToHost, cs));
             if (e->ident_valid) {
                 const size_t per = e->ident_mode == 2 ? (size_t)e->iT : 1;
-                e->h_ident.alloc((size_t)total * per);
-                SD_HIP(hipMemcpyAsync(e->h_ident.p, e->d_ident.p, sizeof(uint32_t) * (size_t)total * per, hipMemcpyDeviceToHost, cs));
+                const size_t nb = sizeof(uint32_t) * (size_t)total * per;
+                if (e->h_ident_bytes < nb) {
+                    g_pinpool.give(e->h_ident, e->h_ident_bytes);
+                    e->h_ident = nullptr;
+                    e->h_ident = static_cast<uint32_t*>(g_pinpool.take(nb, e->h_ident_bytes));
+                }
+                SD_HIP(hipMemcpyAsync(e->h_ident, e->d_ident.p, nb, hipMemcpyDeviceToHost, cs));
                 if (e->ident_mode == 2) {
-                    e->h_identh.alloc((size_t)total * per);
-                    SD_HIP(hipMemcpyAsync(e->h_identh.p, e->d_identh.p, sizeof(uint32_t) * (size_t)total * per, hipMemcpyDeviceToHost, cs));
+                    if (e->h_identh_bytes < nb) {
+                        g_pinpool.give(e->h_identh, e->h_identh_bytes);
+                        e->h_identh = nullptr;
+                        e->h_identh = static_cast<uint32_t*>(g_pinpool.take(nb, e->h_identh_bytes));
+                    }
+                    SD_HIP(hipMemcpyAsync(e->h_identh, e->d_identh.p, nb, hipMemcpyDeviceToHost, cs));
                 }
             }
             SD_HIP(hipStreamSynchronize(cs));
@@ -1229,7 +1286,19 @@ struct Pipeline {
     RecSink sinks[NSMAX];
     std::function<void(sd_engine*)> on_engine;     // called once for every engine the pipeline creates
     // identities that came with the batch a sink is being called for (in-stream, sd_ident.hip); id == nullptr: none
-    struct IdentOut { const uint32_t* id = nullptr; const uint32_t* idh = nullptr; int per = 0; } cur_ident;
+    // a sink may TAKE the blocks (take_ident: they are then its to give back to g_pinpool): the engine fetches its
+    // next batch into other blocks
+    struct IdentOut { uint32_t* id = nullptr; uint32_t* idh = nullptr; int per = 0; size_t id_bytes = 0, idh_bytes = 0; } cur_ident;
+    sd_engine* cur_engine = nullptr;
+    IdentOut take_ident() {
+        IdentOut o = cur_ident;
+        if (cur_engine && o.id) {
+            cur_engine->h_ident = nullptr; cur_engine->h_ident_bytes = 0;
+            if (o.idh) { cur_engine->h_identh = nullptr; cur_engine->h_identh_bytes = 0; }
+        }
+        cur_ident = IdentOut{};
+        return o;
+    }
     uint64_t pushed = 0, popped = 0;
     char eb[1024] = {0};
     // accumulated over all batches: HIP-event kernel times (ms) and host stage times (s)
@@ -1345,11 +1414,15 @@ struct Pipeline {
         rows += eng[k]->rows;
         t0 = now_s();
         cur_ident = IdentOut{};
+        cur_engine = eng[k];
         if (eng[k]->ident_valid)
-            cur_ident = IdentOut{eng[k]->h_ident.p, eng[k]->ident_mode == 2 ? eng[k]->h_identh.p : nullptr,
-                                 eng[k]->ident_mode == 2 ? eng[k]->iT : 1};
+            cur_ident = IdentOut{eng[k]->h_ident, eng[k]->ident_mode == 2 ? eng[k]->h_identh : nullptr,
+                                 eng[k]->ident_mode == 2 ? eng[k]->iT : 1, eng[k]->h_ident_bytes,
+                                 eng[k]->ident_mode == 2 ? eng[k]->h_identh_bytes : 0};
         if (sinks[k]) sinks[k](eng[k]->h_recs.p, eng[k]->h_roff.p, eng[k]->chunks.size());
         sinks[k] = nullptr;
+        cur_ident = IdentOut{};
+        cur_engine = nullptr;
         sink_s += now_s() - t0;
         return SD_OK;
     }
@@ -1593,7 +1666,7 @@ int sd_decompose_files(const char* reads_fa, const char* monomers_fa, const sd_p
 // -------------------------------------------------------------------------------------------
 // chunk-range form: multi-GPU sharding of one job, one process per GPU
 // -------------------------------------------------------------------------------------------
-void sd_release_cache(void) { g_pool.release_all(); }
+void sd_release_cache(void) { g_pool.release_all(); g_pinpool.release_all(); }
 
 int64_t sd_chunk_table_size(const int64_t* read_lens, int32_t n_reads, int32_t part_size, int32_t overlap) {
     if (!read_lens || n_reads < 0 || part_size <= 0 || overlap < 0) return -1;
@@ -1828,18 +1901,20 @@ struct RowJob {
     int32_t chunks_seen = 0;      // chunks of next_read already in carry
     int batches_left = 0;
     bool oom = false;
-    // In-stream identities (sd_ident.hip) follow their records through the merge: `per` words per record in up to two
-    // arrays (plain / homopolymer-compressed).  per == 0: not tracked.  bid / bidh = the arrays of the batch being
-    // added (set by the caller before add); rid / ridh = the words of the assembled rows, [n_rows][per], malloc'ed.
+    // In-stream identities (sd_ident.hip) follow their records through the merge BY REFERENCE: `per` words per record
+    // in up to two arrays (plain / homopolymer-compressed) that stay where the fetch put them (pinned).  per == 0: not
+    // tracked.  bid / bidh = the arrays of the batch being added (set by the caller before add).  rsrc[row] >= 0: record
+    // index in those arrays; < 0: -1 - k, entry k of xid / xidh -- the words of rows of a read that began in an
+    // earlier batch, carried by value.
     int per = 0;
     const uint32_t* bid = nullptr;
     const uint32_t* bidh = nullptr;
-    uint32_t* rid = nullptr;
-    uint32_t* ridh = nullptr;
+    int64_t* rsrc = nullptr;      // malloc'ed with rows
+    std::vector<uint32_t> xid, xidh;
     bool ident_ok = true;         // every batch of the rows assembled so far came with identities
     std::vector<uint32_t> carry_id, carry_idh;
     std::vector<int64_t> src_tmp, carry_src;
-    ~RowJob() { std::free(rows); std::free(row_off); std::free(rid); std::free(ridh); }
+    ~RowJob() { std::free(rows); std::free(row_off); std::free(rsrc); }
     void reserve(size_t need) {
         if (need <= cap_rows) return;
         size_t nc = std::max<size_t>(need, cap_rows * 2 + 4096);
@@ -1847,20 +1922,11 @@ struct RowJob {
         if (!q) { oom = true; return; }
         rows = q;
         if (per) {
-            uint32_t* a = static_cast<uint32_t*>(std::realloc(rid, nc * (size_t)per * sizeof(uint32_t)));
+            int64_t* a = static_cast<int64_t*>(std::realloc(rsrc, nc * sizeof(int64_t)));
             if (!a) { oom = true; return; }
-            rid = a;
-            uint32_t* h = static_cast<uint32_t*>(std::realloc(ridh, nc * (size_t)per * sizeof(uint32_t)));
-            if (!h) { oom = true; return; }
-            ridh = h;
+            rsrc = a;
         }
         cap_rows = nc;
-    }
-    // words of record `x` of the current batch / of the carry -> the words of row `row`
-    void put_ident(size_t row, const uint32_t* from, const uint32_t* fromh, int64_t x) {
-        if (!per) return;
-        if (from) std::memcpy(rid + row * (size_t)per, from + (size_t)x * (size_t)per, (size_t)per * sizeof(uint32_t));
-        if (fromh) std::memcpy(ridh + row * (size_t)per, fromh + (size_t)x * (size_t)per, (size_t)per * sizeof(uint32_t));
     }
     void carry_push(const sd_rec& t, int64_t x) {
         carry.push_back(t);
@@ -1891,7 +1957,13 @@ struct RowJob {
             reserve(n_rows + n);
             if (oom) return;
             if (n) std::memcpy(rows + n_rows, carry.data(), n * sizeof(sd_rec));
-            for (size_t k = 0; k < n; ++k) put_ident(n_rows + k, carry_id.data(), carry_idh.data(), carry_src[k]);
+            if (per)
+                for (size_t k = 0; k < n; ++k) {
+                    const size_t from = (size_t)carry_src[k] * (size_t)per, xk = xid.size() / (size_t)per;
+                    xid.insert(xid.end(), carry_id.begin() + (long)from, carry_id.begin() + (long)(from + (size_t)per));
+                    xidh.insert(xidh.end(), carry_idh.begin() + (long)from, carry_idh.begin() + (long)(from + (size_t)per));
+                    rsrc[n_rows + k] = -1 - (int64_t)xk;
+                }
             n_rows += n;
             row_off[next_read + 1] = (int64_t)n_rows;
             carry.clear();
@@ -1941,12 +2013,11 @@ struct RowJob {
                 n_rows += it.n;
                 row_off[it.read + 1] = (int64_t)n_rows;
             }
-            if (per && bid)   // the identity words of the kept records, gathered by all threads (2 T words per row with --second-best)
-                sd::parallel_for((int64_t)items.size(), threads, 8, [&](int64_t q) {
-                    const Item& it = items[(size_t)q];
-                    const int64_t* sp = src_tmp.data() + (roff[it.ca - c0] - lo);
-                    for (size_t k = 0; k < it.n; ++k) put_ident(at[(size_t)q] + k, bid, bidh, sp[k]);
-                });
+            if (per)   // where the identity words of the kept records are (the words themselves stay in the batch's arrays)
+                for (size_t q = 0; q < items.size(); ++q) {
+                    const Item& it = items[q];
+                    std::memcpy(rsrc + at[q], src_tmp.data() + (roff[it.ca - c0] - lo), it.n * sizeof(int64_t));
+                }
             next_read = r;
             c = cc;
         }
@@ -2261,9 +2332,9 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     if (rc) { set_err(errbuf, errlen, err); return rc; }
     // the three outputs as plain descriptors: every batch's text is written by all host threads with pwrite at its
     // offset (sd::write_parts) -- the copy into the page cache is what a 300-MB _alt batch costs
-    const int fr = ::open(raw_tsv_out, O_WRONLY | O_CREAT | O_TRUNC, 0666);
-    const int ff = fr >= 0 ? ::open(final_tsv_out, O_WRONLY | O_CREAT | O_TRUNC, 0666) : -1;
-    const int fa = ff >= 0 ? ::open(alt_tsv_out, O_WRONLY | O_CREAT | O_TRUNC, 0666) : -1;
+    const int fr = ::open(raw_tsv_out, O_RDWR | O_CREAT | O_TRUNC, 0666);   // O_RDWR: write_parts maps the new range
+    const int ff = fr >= 0 ? ::open(final_tsv_out, O_RDWR | O_CREAT | O_TRUNC, 0666) : -1;
+    const int fa = ff >= 0 ? ::open(alt_tsv_out, O_RDWR | O_CREAT | O_TRUNC, 0666) : -1;
     int64_t off_r = 0, off_f = 0, off_a = 0;
     auto close_all = [&]() {
         bool ok = true;
@@ -2307,7 +2378,12 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     // The rows of a batch are assembled on the driver thread (they come out of the engine's pinned buffer, which
     // the next load reuses) and handed to a second host thread that turns them into the three texts and writes
     // them, while the driver packs and enqueues the next batch.  At most two batches wait in the hand-over.
-    struct Work { size_t r0, r1; sd_rec* rows; std::vector<int64_t> off; uint32_t* id; uint32_t* idh; };
+    // identities of the rows: the batch's pinned arrays (taken from the pipeline, given back to the pool when the text is
+    // written), where each row's words are (src), and the words of carried rows by value (xid / xidh)
+    struct Work {
+        size_t r0, r1; sd_rec* rows; std::vector<int64_t> off;
+        Pipeline::IdentOut ident; int64_t* src; std::vector<uint32_t> xid, xidh; bool have_ident;
+    };
     std::mutex wq_m;
     std::condition_variable wq_cv;
     std::deque<Work> wq;
@@ -2321,7 +2397,8 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     double t_fmt = 0, t_post = 0, t_io = 0;
     auto sink_loop = [&]() {
         sd::HostPool::lane() = 1;   // this thread's parallel loops run on the second pool, beside the driver's
-        std::vector<std::string> fin_parts, alt_parts;
+        std::vector<std::string> fin_parts;
+        std::vector<sd::TextBuf> alt_parts;
         std::vector<sd::PostRead> preads;
         for (;;) {
             Work w;
@@ -2355,8 +2432,11 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
                 for (size_t r = w.r0; r < w.r1; ++r)
                     preads.push_back(sd::PostRead{reads[r].name, reads[r].name_len, reads[r].seq, reads[r].len});
                 std::string e2;
-                const int r2 = pp.process_parts(preads.data(), preads.size(), w.rows, off, fin_parts, alt_parts, e2, w.id,
-                                                second_best ? w.idh : nullptr);
+                sd::IdentRef iref;
+                if (w.have_ident)
+                    iref = sd::IdentRef{w.ident.id, second_best ? w.ident.idh : nullptr, w.src, w.xid.data(), w.xidh.data()};
+                const int r2 = pp.process_parts(preads.data(), preads.size(), w.rows, off, fin_parts, alt_parts, e2,
+                                                w.have_ident ? &iref : nullptr);
                 t_post += now_s() - t0;
                 t0 = now_s();
                 if (r2) {
@@ -2368,8 +2448,9 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
                 t_io += now_s() - t0;
             }
             std::free(w.rows);
-            std::free(w.id);
-            std::free(w.idh);
+            std::free(w.src);
+            g_pinpool.give(w.ident.id, w.ident.id_bytes);
+            g_pinpool.give(w.ident.idh, w.ident.idh_bytes);
         }
     };
     std::thread sink_thread(sink_loop);
@@ -2391,10 +2472,15 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         w.off.assign(job.row_off + r0, job.row_off + r1 + 1);
         // identities that came with the batches of these rows; a batch without them (more records than the outputs
         // had room for) sends the whole hand-over through the text-based identities
-        w.id = job.per && job.ident_ok ? job.rid : nullptr;
-        w.idh = job.per && job.ident_ok ? job.ridh : nullptr;
-        if (!w.id) { std::free(job.rid); std::free(job.ridh); }
-        job.rid = job.ridh = nullptr;
+        w.have_ident = job.per && job.ident_ok;
+        w.src = job.rsrc;
+        job.rsrc = nullptr;
+        w.xid.swap(job.xid);
+        w.xidh.swap(job.xidh);
+        job.xid.clear();
+        job.xidh.clear();
+        w.ident = Pipeline::IdentOut{};
+        if (w.have_ident && job.bid) w.ident = pipe.take_ident();   // the rows point into the batch's pinned arrays
         job.ident_ok = job.carry.empty() || job.bid != nullptr;
         job.rows = nullptr;       // the next batch assembles into a fresh (or recycled) buffer
         job.cap_rows = 0;

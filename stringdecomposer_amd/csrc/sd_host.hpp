@@ -190,6 +190,34 @@ inline void put_fixed2(std::string& o, double v) {
     o.append(buf + p, (size_t)(32 - p));
 }
 
+// the same text written at `w` (room for 48 bytes), returns the end
+inline char* put_fixed2_at(char* w, double v) {
+    uint64_t bits;
+    std::memcpy(&bits, &v, sizeof bits);
+    const int ex = (int)((bits >> 52) & 0x7ff);
+    uint64_t m = bits & ((1ull << 52) - 1);
+    if (ex == 0x7ff || ex >= 1023 + 40) return w + std::snprintf(w, 48, "%.2f", v);
+    int sh;
+    if (ex) { m |= 1ull << 52; sh = 1075 - ex; } else sh = 1074;
+    const unsigned __int128 num = (unsigned __int128)m * 100u;
+    uint64_t q = 0;
+    if (sh < 64) {
+        const uint64_t n64 = (uint64_t)num;
+        q = n64 >> sh;
+        const uint64_t rem = n64 & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+        if (rem > half || (rem == half && (q & 1))) ++q;
+    }
+    char buf[32];
+    int p = 32;
+    buf[--p] = (char)('0' + q % 10); q /= 10;
+    buf[--p] = (char)('0' + q % 10); q /= 10;
+    buf[--p] = '.';
+    do { buf[--p] = (char)('0' + q % 10); q /= 10; } while (q);
+    if (bits >> 63) buf[--p] = '-';
+    std::memcpy(w, buf + p, (size_t)(32 - p));
+    return w + (32 - p);
+}
+
 // SaveBatch (main.cpp:272-285).  The reference prints to_string(float identity) == "%f"; the
 // identity is an integer-valued float (|v| < 1e6 < 2^24 by the range check in the engine), so
 // "%f" is exactly "<int>.000000".
@@ -313,7 +341,8 @@ inline void parallel_for(int64_t n, int threads, int64_t grain, F&& body) {
 }
 
 // out = concatenation of parts, copied by up to `threads` threads (parts are typically 0.1-1 MB each)
-inline void gather_text(const std::vector<std::string>& parts, int threads, TextBuf& out) {
+template <class Part>
+inline void gather_text(const std::vector<Part>& parts, int threads, TextBuf& out) {
     std::vector<size_t> off(parts.size() + 1, 0);
     for (size_t i = 0; i < parts.size(); ++i) off[i + 1] = off[i] + parts[i].size();
     out.resize(off[parts.size()]);
@@ -322,14 +351,33 @@ inline void gather_text(const std::vector<std::string>& parts, int threads, Text
     });
 }
 
-// parts -> the file `fd` at `off` (advanced by the total), written by up to `threads` threads with pwrite: the copy
-// into the page cache is the cost of a TSV write (300 MB of _alt rows per --second-best batch), and it parallelises
-inline bool write_parts(int fd, int64_t& off, const std::vector<std::string>& parts, int threads) {
+// parts -> the file `fd` at `off` (advanced by the total).  The cost of a TSV write is the copy into the page cache
+// (300 MB of _alt rows per --second-best batch), and write(2) / pwrite(2) serialise on the inode: large texts are copied
+// by all threads through a shared mapping of the file's new range instead (each thread faults its own pages in);
+// small ones, and files that cannot be mapped, go through pwrite.
+template <class Part>
+inline bool write_parts(int fd, int64_t& off, const std::vector<Part>& parts, int threads) {
     std::vector<int64_t> at(parts.size() + 1, off);
     for (size_t i = 0; i < parts.size(); ++i) at[i + 1] = at[i] + (int64_t)parts[i].size();
+    const int64_t total = at[parts.size()] - off;
+    if (total >= (4 << 20) && ::ftruncate(fd, (off_t)(off + total)) == 0) {
+        const long pg = ::sysconf(_SC_PAGESIZE);
+        const int64_t m0 = off / pg * pg;
+        void* mp = ::mmap(nullptr, (size_t)(off + total - m0), PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)m0);
+        if (mp != MAP_FAILED) {
+            char* base = static_cast<char*>(mp) - m0;   // base + file offset
+            parallel_for((int64_t)parts.size(), threads, 1, [&](int64_t i) {
+                const Part& p = parts[(size_t)i];
+                if (p.size()) std::memcpy(base + at[(size_t)i], p.data(), p.size());
+            });
+            ::munmap(mp, (size_t)(off + total - m0));
+            off += total;
+            return true;
+        }
+    }
     std::vector<uint8_t> bad(parts.size(), 0);
     parallel_for((int64_t)parts.size(), threads, 1, [&](int64_t i) {
-        const std::string& p = parts[(size_t)i];
+        const Part& p = parts[(size_t)i];
         size_t done = 0;
         while (done < p.size()) {
             const ssize_t k = ::pwrite(fd, p.data() + done, p.size() - done, (off_t)(at[(size_t)i] + (int64_t)done));
@@ -338,7 +386,7 @@ inline bool write_parts(int fd, int64_t& off, const std::vector<std::string>& pa
         }
     });
     off = at[parts.size()];
-    for (uint8_t b : bad) if (b) return false;
+    for (uint8_t b2 : bad) if (b2) return false;
     return true;
 }
 
