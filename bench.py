@@ -204,7 +204,7 @@ def bench_c4_second_best(args):
                "roofline": roofline,
                "kernel_ms_per_step": {k: acc[k] / K for k in ("fill_ms", "trace_ms", "compact_ms", "ident_ms")},
                "host_ms_per_step": {k: acc[k] / K for k in ("pack_ms", "wait_ms", "raw_text_ms", "post_ms", "io_ms",
-                                                            "text_identity_ms", "final_text_ms", "total_ms", "alloc_ms")},
+                                                            "text_identity_ms", "final_text_ms", "total_ms", "setup_ms", "assemble_ms")},
                "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     finally:

@@ -1031,6 +1031,7 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                 SD_HIP(hipEventRecord(e->ev_id0, ts));
                 e->ia_plain.dense = e->ia_homo.dense = e->d_dense.p;            // (a fetch may have grown them)
                 e->ia_plain.rec_chunk = e->ia_homo.rec_chunk = e->d_recchunk.p;
+                e->ia_plain.dense_cap = e->ia_homo.dense_cap = e->dense_cap;
                 sd::launch_ident(ts, e->ia_plain);
                 if (e->ident_mode == 2) sd::launch_ident(ts, e->ia_homo);
                 SD_HIP(hipEventRecord(e->ev_id1, ts));
@@ -2249,7 +2250,7 @@ int32_t sd_pack_bases(const char* seq, int64_t n, uint32_t* words, uint32_t* nma
 // before anything is written; the caller then shards by chunk range instead.
 // stage times of the last sd_run_files / sd_run_files_range call of this process (sd_last_run_stats)
 static std::mutex g_last_m;
-static double g_last_run[16] = {0};
+static double g_last_run[24] = {0};
 
 static int run_files_impl(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank, int32_t world,
                           const char* raw_tsv_out, const char* final_tsv_out, const char* alt_tsv_out,
@@ -2375,6 +2376,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     std::vector<std::pair<size_t, size_t>> batches;
     if (rc == SD_OK) plan_batches(job.table, 0, job.table.size(), pipe.row_budget(), 1, batches);
     lap("chunk table, engine");
+    const double t_setup = now_s() - t_begin;
     // The rows of a batch are assembled on the driver thread (they come out of the engine's pinned buffer, which
     // the next load reuses) and handed to a second host thread that turns them into the three texts and writes
     // them, while the driver packs and enqueues the next batch.  At most two batches wait in the hand-over.
@@ -2525,10 +2527,10 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
                      pp.t_prepare * 1e3, pp.t_identity * 1e3, pp.t_format * 1e3, pp.t_concat * 1e3);
     {
         std::lock_guard<std::mutex> lk(g_last_m);
-        const double v[16] = {pipe.fill_ms, pipe.trace_ms, pipe.compact_ms, pipe.ident_ms, (double)pipe.ident_pairs,
+        const double v[24] = {pipe.fill_ms, pipe.trace_ms, pipe.compact_ms, pipe.ident_ms, (double)pipe.ident_pairs,
                               (double)pipe.batches, (double)pipe.rows, pipe.pack_s * 1e3, pipe.wait_s * 1e3, t_fmt * 1e3,
                               t_post * 1e3, t_io * 1e3, pp.t_identity * 1e3, pp.t_format * 1e3, (now_s() - t_begin) * 1e3,
-                              (double)g_alloc_ns.load() / 1e6};
+                              (double)g_alloc_ns.load() / 1e6, t_setup * 1e3, pipe.sink_s * 1e3, 0, 0, 0, 0, 0, 0};
         std::memcpy(g_last_run, v, sizeof v);
     }
     if (timing) {
@@ -2541,7 +2543,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     return SD_OK;
 }
 
-void sd_last_run_stats(double out[16]) {
+void sd_last_run_stats(double out[24]) {
     std::lock_guard<std::mutex> lk(g_last_m);
     std::memcpy(out, g_last_run, sizeof g_last_run);
 }

@@ -26,7 +26,12 @@ __global__ __launch_bounds__(256, 3) void sd_ident_pairs(IdentArgs a, int use_li
         for (int idx = threadIdx.x; idx < a.Tmask * 5 * K; idx += blockDim.x) speq[idx] = a.peq[idx];
         __syncthreads();
     }
-    const int64_t n_all = min(*a.total, a.rec_cap);
+    // A batch with more records than the outputs or the compaction have room for is post-processed from the read text
+    // (sd_engine.hip: ident_valid); its compact records are then incomplete -- the compaction skips the chunks that do
+    // not fit -- and must not be touched.
+    const int64_t n_tot = *a.total;
+    if (n_tot > a.rec_cap || n_tot > a.dense_cap) return;
+    const int64_t n_all = n_tot;
     const int64_t n_rec = use_list ? (int64_t)min(*a.long_cnt, (int)min(a.rec_cap, (int64_t)0x7fffffff)) : n_all;
     const int64_t n_pairs = n_rec * a.T;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

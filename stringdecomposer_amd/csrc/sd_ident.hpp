@@ -18,6 +18,7 @@ struct IdentArgs {
     const int32_t* rec_chunk;       // chunk of every compact record
     const int64_t* total;           // device: number of compact records (roff[C])
     int64_t rec_cap;                // records the outputs have room for
+    int64_t dense_cap;              // records the compaction had room for (beyond it `dense` is not written)
     int T;                          // templates per record: 1 (own template, `own` maps the DP's template index) or all
     const int32_t* own;
     const unsigned long long* peq;  // [Tmask][5][K], top-aligned (nw_build_masks)

@@ -242,10 +242,11 @@ def run_files(reads_fa, monomers_fa, raw_tsv_out, final_tsv_out, alt_tsv_out, mi
 def last_run_stats():
     """Stage times of the last run_files / run_files_range call of this process (sd_last_run_stats)."""
     L = load()
-    v = (C.c_double * 16)()
+    v = (C.c_double * 24)()
     L.sd_last_run_stats(v)
     keys = ("fill_ms", "trace_ms", "compact_ms", "ident_ms", "ident_pairs", "batches", "rows", "pack_ms", "wait_ms",
-            "raw_text_ms", "post_ms", "io_ms", "text_identity_ms", "final_text_ms", "total_ms", "alloc_ms")
+            "raw_text_ms", "post_ms", "io_ms", "text_identity_ms", "final_text_ms", "total_ms", "alloc_ms", "setup_ms",
+            "assemble_ms")
     return dict(zip(keys, [float(x) for x in v]))
 
 

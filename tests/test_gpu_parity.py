@@ -853,11 +853,14 @@ def test_in_stream_identities_equal_the_text_based_path_across_batches(tmp_path,
 
 
 @pytest.mark.gpu
-def test_in_stream_identities_fall_back_when_a_batch_has_too_many_records(tmp_path):
+@pytest.mark.parametrize("mlen", [20, 3])
+def test_in_stream_identities_fall_back_when_a_batch_has_too_many_records(tmp_path, mlen):
     """A batch with more records than the identity outputs have room for (one per 48 rows: 20-bp monomers give one per
-    ~20) is post-processed from the read text instead; same files."""
+    ~20) is post-processed from the read text instead; same files.  With 3-bp monomers the records do not even fit the
+    compaction's first buffer (one per 16 rows): the identity kernel must not touch the incomplete compact records
+    (tools/fuzz_final.py found a GPU memory fault there)."""
     st0 = synth.Stream(5, 77)
-    ms = [synth._to_ascii(st0.below(20 + k, 4)) for k in range(4)]
+    ms = [synth._to_ascii(st0.below(mlen + k, 4)) for k in range(4)]
     mn = ["s%d" % k for k in range(4)]
     rn, rs = synth.make_reads(ms, 3, read_len=120000, seed=9)
     rfa, mfa = str(tmp_path / "r.fa"), str(tmp_path / "m.fa")
@@ -871,3 +874,7 @@ def test_in_stream_identities_fall_back_when_a_batch_has_too_many_records(tmp_pa
             assert lib.last_run_stats()["text_identity_ms"] > 0     # the in-stream words were not used
         outs.append([open(x, "rb").read() for x in o])
     assert outs[0] == outs[1] and outs[0][1].count(b"\n") > 5000
+    for sb in (True,):    # and every template per record
+        o = [str(tmp_path / ("sb_%s.tsv" % x)) for x in ("raw", "final", "alt")]
+        lib.run_files(rfa, mfa, o[0], o[1], o[2], second_best=sb, threads=4)
+        assert open(o[0], "rb").read() == outs[0][0]
