@@ -318,7 +318,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--kernel", choices=["auto", "generic", "fast"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-reads", type=int, default=32)
+    ap.add_argument("--cpu-sample-reads", type=int, default=200,
+                    help="reads of the benchmark set the reference CPU path is timed on and compared with (200 x 50 kb = 10 Mbp: "
+                         "~25 s of `dp -t 8`)")
     ap.add_argument("--timed-only", action="store_true",
                     help="only the timed region (no second pipe mode, no device-resident repeat): for profilers, so "
                          "that per-kernel averages are those of the timed launches")

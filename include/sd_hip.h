@@ -58,6 +58,8 @@ typedef struct sd_params {
 #define SD_FLAG_NO_EDTHR_COMPACT 4 /* --ed_thr with > 128 templates: every chunk on the W-wave ranked kernel        */
 #define SD_FLAG_FILTER_GENERAL 8   /* --ed_thr: the general prefilter kernel instead of the uniform one             */
 #define SD_FLAG_NO_STREAM_IDENT 16 /* sd_run_files: identities from the read text in the post-processing (round 2)  */
+#define SD_FLAG_PROGRESS 32        /* sd_run_files: the reference binary's progress lines on stderr ("Scores: ...",
+                                      "Prepared reads", "<p>%: Aligned <read>", main.cpp:82,115,393); the command line sets it */
 
 void sd_params_default(sd_params* p); /* -1,-1,-1,1 / 5000 / 500 / -1 / 1 / 0 / auto */
 

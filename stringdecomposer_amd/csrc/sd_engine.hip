@@ -606,9 +606,14 @@ int sd_engine_create(sd_engine** out, const sd_params* p, const char* const* mon
         }
         e->device = p->device;
         {
-            hipDeviceProp_t prop;
-            SD_HIP(hipGetDeviceProperties(&prop, p->device));
-            e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            // (hipGetDeviceProperties fills a 1.5-KB struct from the driver: milliseconds; one attribute is enough)
+            static std::atomic<int> cu_of[64];
+            int ncu = (p->device >= 0 && p->device < 64) ? cu_of[p->device].load() : 0;
+            if (ncu <= 0) {
+                SD_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device));
+                if (p->device >= 0 && p->device < 64) cu_of[p->device].store(ncu);
+            }
+            e->n_cu = ncu > 0 ? ncu : 256;
             e->d_queue.alloc(sd_engine::QS * (size_t)sd_engine::QN);
             SD_HIP(hipMemset(e->d_queue.p, 0, sizeof(int) * sd_engine::QS * (size_t)sd_engine::QN));
         }
@@ -2272,6 +2277,9 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         t_prev = t;
     };
     sd::FastaFile rf, mf;
+    const bool progress = (p->reserved[1] & SD_FLAG_PROGRESS) != 0 && rank == 0;
+    if (progress)   // main.cpp:393
+        std::fprintf(stderr, "Scores: insertion=%d deletion=%d mismatch=%d match=%d\n", p->ins, p->del, p->mismatch, p->match);
     rc = rf.open(reads_fa, p->threads, err);                                  // main.cpp:394
     if (rc == SD_OK && world == 1) rc = rf.validate(0, rf.recs.size(), p->threads, err);   // reads are checked first, as there
     if (rc == SD_OK) rc = mf.open(monomers_fa, p->threads, err);              // main.cpp:395
@@ -2377,6 +2385,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     if (rc == SD_OK) plan_batches(job.table, 0, job.table.size(), pipe.row_budget(), 1, batches);
     lap("chunk table, engine");
     const double t_setup = now_s() - t_begin;
+    if (progress) std::fprintf(stderr, "Prepared reads\n");   // main.cpp:82
     // The rows of a batch are assembled on the driver thread (they come out of the engine's pinned buffer, which
     // the next load reuses) and handed to a second host thread that turns them into the three texts and writes
     // them, while the driver packs and enqueues the next batch.  At most two batches wait in the hand-over.
@@ -2413,6 +2422,17 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
             }
             wq_cv.notify_all();
             if (sink_rc.load() == SD_OK) {
+                if (progress) {   // main.cpp:115, one line per read, written per hand-over
+                    std::string pl;
+                    const size_t n_all = reads.size();
+                    for (size_t r = w.r0; r < w.r1; ++r) {
+                        sd::put_int(pl, (int64_t)((r + 1) * 100 / n_all));
+                        pl.append("%: Aligned ");
+                        pl.append(reads[r].name, reads[r].name_len);
+                        pl.push_back('\n');
+                    }
+                    (void)std::fwrite(pl.data(), 1, pl.size(), stderr);
+                }
                 double t0 = now_s();
                 // raw TSV (SaveBatch, main.cpp:272-285): slices of <= 32 k rows, so that a chromosome-sized read is
                 // formatted by all threads; a slice needs the end of the row before it

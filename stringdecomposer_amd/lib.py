@@ -159,7 +159,7 @@ def _strs(seq):
     return arr
 
 
-FLAG_NO_F16, FLAG_FULL_FLOOR, FLAG_NO_EDTHR_COMPACT, FLAG_FILTER_GENERAL, FLAG_NO_STREAM_IDENT = 1, 2, 4, 8, 16
+FLAG_NO_F16, FLAG_FULL_FLOOR, FLAG_NO_EDTHR_COMPACT, FLAG_FILTER_GENERAL, FLAG_NO_STREAM_IDENT, FLAG_PROGRESS = 1, 2, 4, 8, 16, 32
 
 
 def make_params(scoring=(-1, -1, -1, 1), part_size=5000, overlap=500, ed_thr=-1, threads=1,

@@ -379,7 +379,7 @@ def run(sequences, monomers, num_threads, scoring, batch_size, raw_file, ed_thr,
         dist = shard.init_process_group("gloo")
         dev = local_rank % max(lib.device_count(), 1)
         common = dict(scoring=(ins, dels, mm, match), part_size=int(batch_size), overlap=int(overlap), ed_thr=int(ed_thr),
-                      threads=int(num_threads), kernel=kernel, device=dev)
+                      threads=int(num_threads), kernel=kernel, device=dev, flags=lib.FLAG_PROGRESS)
         try:
             ok = None
             if final_file is not None:
@@ -399,7 +399,8 @@ def run(sequences, monomers, num_threads, scoring, batch_size, raw_file, ed_thr,
         lib.run_files(sequences, monomers, raw_file, final_file, final_file[:-len(".tsv")] + "_alt.tsv",
                       min_identity=min_identity, second_best=second_best, lr_coef=_lr_coef(),
                       scoring=(ins, dels, mm, match), part_size=int(batch_size), overlap=int(overlap),
-                      ed_thr=int(ed_thr), threads=int(num_threads), device=device, kernel=kernel)
+                      ed_thr=int(ed_thr), threads=int(num_threads), device=device, kernel=kernel,
+                      flags=lib.FLAG_PROGRESS)   # the dp binary's progress lines on stderr (main.cpp:82,115,393)
         return True
     lib.decompose_files(sequences, monomers, raw_file, scoring=(ins, dels, mm, match),
                         part_size=int(batch_size), overlap=int(overlap), ed_thr=int(ed_thr),
