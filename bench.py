@@ -331,6 +331,9 @@ def main():
                          "(clean per-kernel spans), 1 = traceback overlap only; the other of {2, 0} is timed as well and "
                          "reported as other_pipe_mode")
     ap.add_argument("--resident-stream", choices=["null", "new"], default="null")
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="host threads of a rank (default: its share of the usable CPUs, at most 32); e.g. 2 = what a rank gets on a "
+                         "16-CPU box shared by 8 ranks")
     ap.add_argument("--sub-batches", type=int, default=1,
                     help="device batches per step (two batches are in flight, across steps; 1 is fastest: the "
                          "persistent kernels want >= 2 chunks per resident wave)")
@@ -376,7 +379,7 @@ def main():
     kernel = {"auto": 0, "generic": 1, "fast": 2}[args.kernel]
     # host threads of this rank: its share of the CPUs the container may actually use (threads beyond a cgroup
     # quota only get the whole process group throttled)
-    threads = max(1, min(32, usable_cores() // max(ws, 1)))
+    threads = args.host_threads if args.host_threads > 0 else max(1, min(32, usable_cores() // max(ws, 1)))
     K = max(args.steps, 1)
 
     # ---- the timed region: SURVEY.md 8(d) -- sequences in host memory -> chunk -> 2-bit pack -> H2D ->
