@@ -437,7 +437,7 @@ static int engine_pick_family(sd_engine* e, bool allow_f16, std::string& err) {
     if (family == 0) family = fast_ok ? 2 : 1;
     if (family == 2 && !fast_ok) { err = "fast kernel family not applicable: " + why; return SD_ERR_UNSUPPORTED; }
     if (family != 1 && family != 2) { err = "bad kernel family"; return SD_ERR_PARAM; }
-    if (p->ed_thr > -1 && e->Lmax > 512) { err = "--ed_thr supports templates of up to 512 bp"; return SD_ERR_UNSUPPORTED; }
+    if (p->ed_thr > -1 && e->Lmax > 2048) { err = "--ed_thr supports templates of up to 2048 bp"; return SD_ERR_UNSUPPORTED; }
     if (e->T > 65534) { err = "more than 65534 templates"; return SD_ERR_UNSUPPORTED; }
     e->family = family;
     e->d_toff.upload(e->toff);

@@ -38,10 +38,11 @@ __global__ __launch_bounds__(256) void sd_hw_dist(const ChunkDesc* __restrict__ 
                                                   const unsigned long long* __restrict__ peq,
                                                   const int32_t* __restrict__ tlen,
                                                   int32_t* __restrict__ dist, int lds_templates) {
+    constexpr int PS = W <= 8 ? 8 : W;             // words per (template, symbol) row of peq (build_peq)
     extern __shared__ unsigned long long speq[];   // [min(T, lds_templates)][5][W]
     for (int idx = threadIdx.x; idx < lds_templates * 5 * W; idx += blockDim.x) {
         const int j = idx / (5 * W), rem = idx % (5 * W);
-        speq[idx] = peq[(size_t)j * 40 + (size_t)(rem / W) * 8 + (rem % W)];
+        speq[idx] = peq[(size_t)j * 5 * PS + (size_t)(rem / W) * PS + (rem % W)];
     }
     __syncthreads();
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void sd_hw_dist(const ChunkDesc* __restrict__ 
     const unsigned long long lastBit = 1ull << ((m - 1) & 63);
     const bool in_lds = j < lds_templates;
     const unsigned long long* pq_l = speq + (size_t)j * 5 * W;
-    const unsigned long long* pq_g = peq + (size_t)j * 40;
+    const unsigned long long* pq_g = peq + (size_t)j * 5 * PS;
     unsigned long long Pv[W], Mv[W];
 #pragma unroll
     for (int b = 0; b < W; ++b) { Pv[b] = ~0ull; Mv[b] = 0ull; }
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void sd_hw_dist(const ChunkDesc* __restrict__ 
 #pragma unroll
         for (int b = 0; b < W; ++b) {
             if (b <= lastW) {
-                unsigned long long Eq = in_lds ? pq_l[r * W + b] : pq_g[r * 8 + b];
+                unsigned long long Eq = in_lds ? pq_l[r * W + b] : pq_g[r * PS + b];
                 const unsigned long long pv = Pv[b], mv = Mv[b];
                 const unsigned long long Xv = Eq | mv;
                 if (hin < 0) Eq |= 1ull;
@@ -241,10 +242,15 @@ __global__ void sd_fill_u32(uint32_t* p, size_t n, uint32_t v) {
     if (i < n) p[i] = v;
 }
 
+// match masks of the prefilter: [template][5 symbols][PS words], PS = 8 for templates of up to 512 bp (the layout the
+// uniform kernel and the fast family know), 16 / 32 for sets with a longer template (up to 2048 bp: generic family)
 void build_peq(const std::vector<std::string>& tseq, std::vector<unsigned long long>& peq) {
-    peq.assign(tseq.size() * 40, 0ull);
+    size_t lmax = 1;
+    for (const std::string& t : tseq) lmax = std::max(lmax, t.size());
+    const size_t PS = lmax <= 512 ? 8 : lmax <= 1024 ? 16 : 32;
+    peq.assign(tseq.size() * 5 * PS, 0ull);
     for (size_t j = 0; j < tseq.size(); ++j)
-        for (size_t k = 0; k < tseq[j].size() && k < 512; ++k) {
+        for (size_t k = 0; k < tseq[j].size() && k < 64 * PS; ++k) {
             int code;
             switch (tseq[j][k]) {
                 case 'A': code = 0; break;
@@ -253,7 +259,7 @@ void build_peq(const std::vector<std::string>& tseq, std::vector<unsigned long l
                 case 'T': code = 3; break;
                 default: code = 4; break;
             }
-            peq[j * 40 + (size_t)code * 8 + (k >> 6)] |= 1ull << (k & 63);
+            peq[(j * 5 + (size_t)code) * PS + (k >> 6)] |= 1ull << (k & 63);
         }
 }
 
@@ -320,7 +326,8 @@ void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, 
 #undef SD_HWU
     }
     if (!done) {
-    if (W <= 1) SD_HW(1) else if (W == 2) SD_HW(2) else if (W == 3) SD_HW(3) else if (W == 4) SD_HW(4) else SD_HW(8)
+    if (W <= 1) SD_HW(1) else if (W == 2) SD_HW(2) else if (W == 3) SD_HW(3) else if (W == 4) SD_HW(4)
+    else if (W <= 8) SD_HW(8) else if (W <= 16) SD_HW(16) else SD_HW(32)   // 16 / 32 words: templates of up to 1024 / 2048 bp
     }
 #undef SD_HW
     hipLaunchKernelGGL(sd_rank_keep, dim3(grid), dim3(256), 0, st, n_chunks, T, ed_thr, dist, end_vlane, end_off,

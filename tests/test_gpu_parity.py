@@ -906,3 +906,28 @@ def test_in_stream_identities_fall_back_when_a_batch_has_too_many_records(tmp_pa
         o = [str(tmp_path / ("sb_%s.tsv" % x)) for x in ("raw", "final", "alt")]
         lib.run_files(rfa, mfa, o[0], o[1], o[2], second_best=sb, threads=4)
         assert open(o[0], "rb").read() == outs[0][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lo,hi", [(520, 900), (1100, 2000)])
+def test_ed_thr_with_monomers_longer_than_512_bp(oracle, lo, hi):
+    """main.cpp:128-149 runs edlib's prefilter for any monomer length; round 2 returned SD_ERR_UNSUPPORTED beyond 512 bp.
+    The prefilter kernel now takes templates of up to 2048 bp (16 / 32 words per template); such sets run on the
+    generic family."""
+    st = synth.Stream(99, lo)
+    ms = _random_monomers(st, 3, lo, hi)
+    mn = ["L%d" % j for j in range(3)]
+    reads = []
+    for r in range(2):
+        parts = []
+        while sum(len(x) for x in parts) < 4000 + 2500 * r:
+            j = int(st.below(1, 3)[0])
+            codes = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), np.frombuffer(ms[j], dtype=np.uint8))
+            x = synth._to_ascii(synth.mutate(codes, st, 0.06, 0.03, 0.03))
+            parts.append(synth.revcomp_bytes(x) if st.below(1, 2)[0] else x)
+        reads.append(b"".join(parts))
+    rn = ["r0", "r1"]
+    for ed in (0, 150, 900):
+        exp = oracle.decompose(rn, reads, mn, ms, threads=8, part=3000, overlap=400, ed_thr=ed)
+        got = lib.decompose(rn, reads, mn, ms, part_size=3000, overlap=400, ed_thr=ed)
+        assert got == exp, (lo, hi, ed)
