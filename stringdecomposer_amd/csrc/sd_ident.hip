@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, 3) void sd_ident_pairs(IdentArgs a, int use_li
     const int64_t n_pairs = n_rec * a.T;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    uint4* ckl = reinterpret_cast<uint4*>(a.ck) + (size_t)blockIdx.x * (size_t)cap * K * 256 + threadIdx.x;
+    uint32_t* ckl = reinterpret_cast<uint32_t*>(a.ck) + (size_t)blockIdx.x * (size_t)cap * K * 4 * 256 + threadIdx.x;
     int* ckp = a.ckpos + (size_t)blockIdx.x * (size_t)cap * 256 + threadIdx.x;
     for (int64_t p = gid; p < n_pairs; p += stride) {
         const int64_t xl = p / a.T;
@@ -57,9 +57,12 @@ __global__ __launch_bounds__(256, 3) void sd_ident_pairs(IdentArgs a, int use_li
         }
         const ChunkDesc cd = a.chunks[a.rec_chunk[x]];
         NwQueryPacked q{a.bases2 + cd.woff, cd.noff >= 0 ? a.nmask + cd.noff : nullptr, rec.start};
-        const uint2* eqt = reinterpret_cast<const uint2*>(eq_lds ? speq + (size_t)t * 5 * K : a.peq + (size_t)t * 5 * K);
+        // two instantiations, so that the masks are read with ds_read from LDS (a pointer that may be either LDS or
+        // global makes every mask read a FLAT load with 64-bit address arithmetic per column)
         int d = 0, m = 0;
-        const bool ok = nw_pair<K>(q, ql, eqt, tl, a.homo != 0, ckl, ckp, (size_t)256, cap, d, m);
+        bool ok;
+        if (eq_lds) ok = nw_pair<K>(q, ql, reinterpret_cast<const uint2*>(speq + (size_t)t * 5 * K), tl, a.homo != 0, ckl, ckp, (size_t)256, cap, d, m);
+        else ok = nw_pair<K>(q, ql, reinterpret_cast<const uint2*>(a.peq + (size_t)t * 5 * K), tl, a.homo != 0, ckl, ckp, (size_t)256, cap, d, m);
         a.out[o] = (ok && d < 65536 && m < 65536) ? (((uint32_t)d << 16) | (uint32_t)m) : IDENT_NONE;
     }
 }

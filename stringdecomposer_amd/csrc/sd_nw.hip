@@ -45,9 +45,9 @@ __global__ __launch_bounds__(256, 3) void sd_nw_pairs(const uint8_t* __restrict_
     const int64_t n_pairs = pair_tmpl ? n_seg : n_seg * (int64_t)T;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // checkpoints of this lane: [workgroup][slot][word][thread] x 16 B -- a wave writes one contiguous KB per
-    // (slot, word)
-    uint4* ckl = ck + (size_t)blockIdx.x * (size_t)cap * K * 256 + threadIdx.x;
+    // checkpoints of this lane: [workgroup][slot][word][component][thread] dwords -- a wave writes 256 contiguous
+    // bytes per (slot, word, component)
+    uint32_t* ckl = reinterpret_cast<uint32_t*>(ck) + (size_t)blockIdx.x * (size_t)cap * K * 4 * 256 + threadIdx.x;
     int* ckp = ckpos + (size_t)blockIdx.x * (size_t)cap * 256 + threadIdx.x;
     for (int64_t p = gid; p < n_pairs; p += stride) {
         const int64_t sl = pair_tmpl ? p : p / T;
@@ -61,10 +61,11 @@ __global__ __launch_bounds__(256, 3) void sd_nw_pairs(const uint8_t* __restrict_
             matches[o] = 0;
             continue;
         }
-        const uint2* eqt = reinterpret_cast<const uint2*>(eq_lds ? speq + (size_t)t * 5 * K : peq + (size_t)t * 5 * K);
         NwQueryAscii q{seq, seg_start[s]};
         int d = -2, m = 0;
-        (void)nw_pair<K>(q, ql, eqt, tl, homo != 0, ckl, ckp, (size_t)256, cap, d, m);
+        // two instantiations: masks in LDS are read with ds_read (see sd_ident.hip)
+        if (eq_lds) (void)nw_pair<K>(q, ql, reinterpret_cast<const uint2*>(speq + (size_t)t * 5 * K), tl, homo != 0, ckl, ckp, (size_t)256, cap, d, m);
+        else (void)nw_pair<K>(q, ql, reinterpret_cast<const uint2*>(peq + (size_t)t * 5 * K), tl, homo != 0, ckl, ckp, (size_t)256, cap, d, m);
         dist[o] = d;       // -2: more columns than the launch has checkpoint slots for (the host driver sizes them)
         matches[o] = m;
     }

@@ -129,12 +129,14 @@ struct NwQueryPacked {
 
 // The pair: ql query symbols (before compression), template masks eqt ([5][K] words, LDS or global), template
 // length tl (1 <= tl <= 64 K), homo = homopolymer-compress the query on the fly (main.py:87-92; the templates are
-// compressed by the host).  ck / ckpos: this lane's checkpoint slots, element stride `ckstride` (uint4 units for
-// ck: slot s, word b at ck[(s * K + b) * ckstride]; ints for ckpos: ckpos[s * ckstride]); `cap` slots.
+// compressed by the host).  ck / ckpos: this lane's checkpoint slots, element stride `ckstride` in dwords: component
+// x (PvL, PvH, MvL, MvH) of word b of slot s at ck[((s * K + b) * 4 + x) * ckstride] -- planar dwords, so that a
+// wave's store is 256 contiguous bytes AND the four components need not sit in consecutive registers (as one 16-byte
+// store per word they cost a dozen register moves per column to keep them there); ckpos[s * ckstride]; `cap` slots.
 // Returns false when the pair needs more than `cap` checkpoints (nothing computed).
 template <int K, class Query>
 __device__ __forceinline__ bool nw_pair(Query& q, int ql, const uint2* __restrict__ eqt, int tl, bool homo,
-                                        uint4* __restrict__ ck, int* __restrict__ ckpos, size_t ckstride, int cap,
+                                        uint32_t* __restrict__ ck, int* __restrict__ ckpos, size_t ckstride, int cap,
                                         int& dist_out, int& matches_out) {
     constexpr int S = nw_block_cols(K);
     const int pad = 64 * K - tl;           // padding rows below the template
@@ -152,17 +154,21 @@ __device__ __forceinline__ bool nw_pair(Query& q, int ql, const uint2* __restric
     NwState<K> st;
     init(st);
     int score = tl, c = 0, prev = -1;
+    int left = S + 1, slot = -1;   // columns until the next checkpoint / slot it goes to (no division by S per column)
     for (int i = 0; i < ql; ++i) {
         const int r = q.code(i);
         const bool skip = homo && r == prev;
         prev = r;
         if (skip) continue;
-        if (c > 0 && (c % S) == 0) {
-            const int slot = c / S - 1;
+        if (--left == 0) {         // c > 0 && c % S == 0
+            left = S;
+            ++slot;
             if (slot >= cap) return false;
 #pragma unroll
-            for (int b = 0; b < K; ++b)
-                ck[((size_t)slot * K + b) * ckstride] = make_uint4(st.PvL[b], st.PvH[b], st.MvL[b], st.MvH[b]);
+            for (int b = 0; b < K; ++b) {
+                uint32_t* w = ck + ((size_t)slot * K + b) * 4 * ckstride;
+                w[0] = st.PvL[b]; w[ckstride] = st.PvH[b]; w[2 * ckstride] = st.MvL[b]; w[3 * ckstride] = st.MvH[b];
+            }
             if (homo) ckpos[(size_t)slot * ckstride] = i;   // plain: column c is symbol c
         }
         score += nw_column<K, false>(st, eqt + r * K, nullptr, nullptr);
@@ -178,28 +184,43 @@ __device__ __forceinline__ bool nw_pair(Query& q, int ql, const uint2* __restric
         } else {
 #pragma unroll
             for (int b = 0; b < K; ++b) {
-                const uint4 v = ck[((size_t)(blk - 1) * K + b) * ckstride];
-                st.PvL[b] = v.x; st.PvH[b] = v.y; st.MvL[b] = v.z; st.MvH[b] = v.w;
+                const uint32_t* w = ck + ((size_t)(blk - 1) * K + b) * 4 * ckstride;
+                st.PvL[b] = w[0]; st.PvH[b] = w[ckstride]; st.MvL[b] = w[2 * ckstride]; st.MvH[b] = w[3 * ckstride];
             }
             i = homo ? ckpos[(size_t)(blk - 1) * ckstride] : blk * S;
         }
         const int ncol = min(S, c - blk * S);
+        // All S columns of the block are computed, also those behind the last column of the pair (the final block is
+        // usually partial): the walk below skips them, and nothing after the block reads the state -- an unconditional
+        // column keeps "Pv after column x" in ONE set of registers that is both the history entry and the input of
+        // column x + 1 (a predicated one costs a register copy per vector and column).
         uint32_t hPhL[S][K], hPhH[S][K], hPvL[S][K], hPvH[S][K];
         int pv = i > 0 ? q.code(i - 1) : -1;
 #pragma unroll
         for (int x = 0; x < S; ++x) {
+            int r = 0;
             if (x < ncol) {
-                int r;
                 do {   // next kept symbol (the first symbol of a block is kept by construction of pass 1)
                     r = q.code(i++);
                     const bool skip = homo && r == pv;
                     pv = r;
                     if (!skip) break;
                 } while (true);
-                (void)nw_column<K, true>(st, eqt + r * K, hPhL[x], hPhH[x]);
             }
+            NwState<K> in;
 #pragma unroll
-            for (int b = 0; b < K; ++b) { hPvL[x][b] = st.PvL[b]; hPvH[x][b] = st.PvH[b]; }
+            for (int b2 = 0; b2 < K; ++b2) {
+                in.PvL[b2] = x == 0 ? st.PvL[b2] : hPvL[x > 0 ? x - 1 : 0][b2];
+                in.PvH[b2] = x == 0 ? st.PvH[b2] : hPvH[x > 0 ? x - 1 : 0][b2];
+                in.MvL[b2] = st.MvL[b2];
+                in.MvH[b2] = st.MvH[b2];
+            }
+            (void)nw_column<K, true>(in, eqt + r * K, hPhL[x], hPhH[x]);
+#pragma unroll
+            for (int b2 = 0; b2 < K; ++b2) {
+                hPvL[x][b2] = in.PvL[b2]; hPvH[x][b2] = in.PvH[b2];
+                st.MvL[b2] = in.MvL[b2]; st.MvH[b2] = in.MvH[b2];
+            }
         }
 #pragma unroll
         for (int x = S - 1; x >= 0; --x) {
