@@ -160,26 +160,29 @@ struct CellOps {
 // About P + 6 packed ops per 128 rows.  Idle planes (no template) hold -inf in every slot and are exempt.
 template <int P>
 struct F16Guard {
-    uint32_t limneg = 0, limpos = 0;   // per lane and plane: {-lim or -inf}, {+lim}
+    uint32_t pos2 = 0, neg2 = 0;       // packed {+lim, +lim} / {-lim, -lim}: SGPRs (readfirstlane), not hoisted VGPR constants
     bool bad = false;                  // wave-uniform, sticky over the chunk
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ uint32_t mn(uint32_t a, uint32_t b) {
         return __builtin_bit_cast(uint32_t, __builtin_elementwise_minimum(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b)));
     }
-    // after row 0: `last` = a slot that is finite on every plane holding a template
-    __device__ __forceinline__ void start(uint32_t last, int lim) {
+    __device__ __forceinline__ void start(uint32_t, int lim_) {
         bad = false;
-        limpos = CellOps<true>::splat(lim);
-        const uint32_t nl = CellOps<true>::splat(-lim);
-        const uint32_t lo = (last & 0xffffu) == 0xFC00u ? 0xFC00u : (nl & 0xffffu);
-        const uint32_t hi = (last >> 16) == 0xFC00u ? 0xFC000000u : (nl & 0xffff0000u);
-        limneg = lo | hi;
+        pos2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)CellOps<true>::splat(lim_));
+        neg2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)CellOps<true>::splat(-lim_));
     }
+    // The per-lane lower limit {-lim, or -inf on a plane without a template} is rebuilt from the last slot at every
+    // check (a plane is idle exactly when that slot is -inf, at any row) instead of living in a register: the fill's
+    // 96 VGPRs are what lets two traceback waves share a SIMD with four fill waves in the overlapped stream mode.
     __device__ __forceinline__ void check_low(const uint32_t (&L)[P]) {
         uint32_t m = L[0];
 #pragma unroll
         for (int s = 1; s < P; ++s) m = mn(m, L[s]);
-        const uint32_t t = CellOps<true>::mx(m, limneg);
+        const uint32_t last = L[P - 1];
+        const uint32_t nl = neg2;
+        const uint32_t lo = (last & 0xffffu) == 0xFC00u ? 0xFC00u : (nl & 0xffffu);
+        const uint32_t hi = (last >> 16) == 0xFC00u ? 0xFC000000u : (nl & 0xffff0000u);
+        const uint32_t t = CellOps<true>::mx(m, lo | hi);
         bad = bad || __ballot(t != m) != 0ull;
     }
     __device__ __forceinline__ void check_high(const uint32_t (&L)[P]) {
@@ -187,7 +190,7 @@ struct F16Guard {
 #pragma unroll
         for (int s = 1; s + 1 < P; s += 2) m = CellOps<true>::mx3(m, L[s], L[s + 1]);
         if ((P & 1) == 0) m = CellOps<true>::mx(m, L[P - 1]);
-        const uint32_t t = mn(m, limpos);
+        const uint32_t t = mn(m, pos2);
         bad = bad || __ballot(t != m) != 0ull;
     }
     __device__ __forceinline__ void finish(int* flag) {
