@@ -153,15 +153,25 @@ __device__ __forceinline__ bool nw_pair(Query& q, int ql, const uint2* __restric
     // ---- pass 1: forward, checkpoints of the state ENTERING columns S, 2S, ...
     NwState<K> st;
     init(st);
-    int score = tl, c = 0, prev = -1;
-    int left = S + 1, slot = -1;   // columns until the next checkpoint / slot it goes to (no division by S per column)
-    for (int i = 0; i < ql; ++i) {
-        const int r = q.code(i);
-        const bool skip = homo && r == prev;
-        prev = r;
-        if (skip) continue;
-        if (--left == 0) {         // c > 0 && c % S == 0
-            left = S;
+    // One trip per block of S columns, the columns statically unrolled: the state is renamed from column to column
+    // instead of being copied back into loop-carried registers (a dozen v_mov per column in a column-per-trip loop).
+    // A block starts at its first kept symbol; its later columns are executed unconditionally -- past the end of the
+    // query with a dummy symbol and without counting -- which can only happen in the last block, whose exit state
+    // nobody reads.
+    int score = tl, c = 0, prev = -1, slot = -1, i = 0;
+    auto next_kept = [&](int& r) -> bool {     // consumes symbols up to and including the next kept one
+        while (i < ql) {
+            r = q.code(i++);
+            const bool skip = homo && r == prev;
+            prev = r;
+            if (!skip) return true;
+        }
+        return false;
+    };
+    while (true) {
+        int r0 = 0;
+        if (!next_kept(r0)) break;
+        if (c > 0) {   // c is a multiple of S: checkpoint of the state entering column c
             ++slot;
             if (slot >= cap) return false;
 #pragma unroll
@@ -169,10 +179,18 @@ __device__ __forceinline__ bool nw_pair(Query& q, int ql, const uint2* __restric
                 uint32_t* w = ck + ((size_t)slot * K + b) * 4 * ckstride;
                 w[0] = st.PvL[b]; w[ckstride] = st.PvH[b]; w[2 * ckstride] = st.MvL[b]; w[3 * ckstride] = st.MvH[b];
             }
-            if (homo) ckpos[(size_t)slot * ckstride] = i;   // plain: column c is symbol c
+            if (homo) ckpos[(size_t)slot * ckstride] = i - 1;   // where the block's first symbol is (plain: column c is symbol c)
         }
-        score += nw_column<K, false>(st, eqt + r * K, nullptr, nullptr);
+        score += nw_column<K, false>(st, eqt + r0 * K, nullptr, nullptr);
         ++c;
+#pragma unroll
+        for (int x = 1; x < S; ++x) {
+            int r = 0;
+            const bool got = next_kept(r);
+            const int h = nw_column<K, false>(st, eqt + (got ? r : 0) * K, nullptr, nullptr);
+            score += got ? h : 0;
+            c += got ? 1 : 0;
+        }
     }
     // ---- pass 2: blocks from the last to the first; walk with edlib's priority up > left > diagonal
     int row = tl, nL = 0;
