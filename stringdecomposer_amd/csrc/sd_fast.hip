@@ -41,8 +41,11 @@ namespace sd {
 #ifndef SD_TRACE_ADAPT
 #define SD_TRACE_ADAPT 1
 #endif
+// waves per traceback workgroup: the per-wave LDS (moves + table) is 4.5 KB up to QK = 8, 36 KB at QK = 32
+constexpr int trace_waves_per_group(int QK) { return QK <= 8 ? 4 : 1; }
+
 template <int QK>
-__global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_trace(
+__global__ __launch_bounds__(64 * trace_waves_per_group(QK), (QK <= 4 ? SD_TRACE_MINW : QK <= 8 ? 2 : 1)) void sd_fast_trace(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ slot_of,
     const uint8_t* __restrict__ tcodes, const uint32_t* __restrict__ lane_consts,
@@ -52,10 +55,14 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
     DevRec* __restrict__ recs, int32_t* __restrict__ rec_cnt, int* __restrict__ queue,
     const int* __restrict__ order, int ckf16, int bshift, int W, const uint16_t* __restrict__ klist,
     const uint16_t* __restrict__ kpos, const int32_t* __restrict__ nkept, int T) {
-    constexpr int QP = QK <= 4 ? 4 : 8;       // cells per lane rounded up to whole int4 loads
-    using pt_t = std::conditional_t<(QK <= 4), uint8_t, uint16_t>;
-    __shared__ pt_t pt_all[4][FAST_R][64];      // 2-bit moves of the lane's cells
-    __shared__ int16_t mt_all[4][5][64][QP];    // (mm - del) of the lane's cells for the 5 read symbols
+    // QK = ceil(Lmax / 64) cells per lane: 1..8 for templates of up to 512 bp; 16 / 32 for the long ones (up to 2048 bp:
+    // a handful of templates, each over up to 32 virtual lanes of the fill)
+    constexpr int QP = QK <= 4 ? 4 : QK <= 8 ? 8 : QK <= 16 ? 16 : 32;   // cells per lane rounded up to whole 8-byte loads
+    constexpr int NWV = trace_waves_per_group(QK);
+    using pt_t = std::conditional_t<(QK <= 4), uint8_t, std::conditional_t<(QK <= 8), uint16_t,
+                 std::conditional_t<(QK <= 16), uint32_t, unsigned long long>>>;
+    __shared__ pt_t pt_all[NWV][FAST_R][64];      // 2-bit moves of the lane's cells
+    __shared__ int16_t mt_all[NWV][5][64][QP];    // (mm - del) of the lane's cells for the 5 read symbols
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     pt_t(*pt)[64] = pt_all[wave];
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
         //     deletion:      (left cell's result) | 3
         auto block = [&](auto qq_c, const Cells cl, const int i_in, const int k_in) -> Pos {
             constexpr int QQ = decltype(qq_c)::value;
-            constexpr int QQP = QQ <= 4 ? 4 : 8;
+            constexpr int QQP = QQ <= 4 ? 4 : QQ <= 8 ? 8 : QQ <= 16 ? 16 : 32;
             int i = i_in, k = k_in;
             const int* code = cl.code;
             const int* slot = cl.slot;
@@ -152,12 +159,12 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
                 }
                 const int32_t X = lane_up_neg(wave_prefix_max(run));
                 int32_t left = X;
-                uint32_t bits = 0;
+                unsigned long long bits = 0;
 #pragma unroll
                 for (int q = 0; q < QQ; ++q) {
                     const int32_t Ef = max(loc[q], X);
                     const int tg = Ef == left ? 3 : 0;  // k == 0: left = -inf
-                    bits |= (uint32_t)tg << (2 * q);
+                    bits |= (unsigned long long)tg << (2 * q);
                     left = Ef;
                     T[q] = 4 * Ef + 2;
                 }
@@ -218,14 +225,19 @@ __global__ __launch_bounds__(256, (QK <= 4 ? SD_TRACE_MINW : 2)) void sd_fast_tr
                     pd = T[q];
                 }
                 const int32_t X = lane_up_min(wave_prefix_max(loc[QQ - 1] | 3));   // only ever an operand of max
-                uint32_t bits = 0;
+                uint32_t bits = 0, bitsHi = 0;   // the tags of up to 16 / of the cells 16.. of the lane
 #pragma unroll
                 for (int q = 0; q < QQ; ++q) {
                     const int32_t Ef = max(loc[q], X);
-                    bits = __builtin_amdgcn_alignbit((uint32_t)Ef, bits, 2);   // tag into the top, oldest cell lowest
+                    if (q < 16) bits = __builtin_amdgcn_alignbit((uint32_t)Ef, bits, 2);   // tag into the top, oldest cell lowest
+                    else bitsHi = __builtin_amdgcn_alignbit((uint32_t)Ef, bitsHi, 2);
                     asm("v_and_or_b32 %0, %1, -4, 2" : "=v"(T[q]) : "v"(Ef));   // (Ef & ~3) | 2 in one op
                 }
-                pt[r_i - a][lane] = (pt_t)(bits >> (32 - 2 * QQ));
+                if constexpr (QQ <= 16) {
+                    pt[r_i - a][lane] = (pt_t)(bits >> (32 - 2 * QQ));
+                } else {
+                    pt[r_i - a][lane] = (pt_t)((unsigned long long)bits | ((unsigned long long)(bitsHi >> (64 - 2 * QQ)) << 32));
+                }
             }
             // walk inside the block (wave-uniform)
             while (i >= a) {
@@ -319,7 +331,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
                        (int64_t)FAST_REBASE * ab(sc.ins) + 8 * (int64_t)maxabs + 8;
     if (ub > 12000) { why = "scores too large for int16 cells"; return false; }
     plan.range_bound = (int)ub;
-    if (Lmax > 64 * 8) { why = "template longer than 512 bp"; return false; }
+    if (Lmax > 64 * 32) { why = "template longer than 2048 bp"; return false; }
 
     // narrow layout: the smallest slot counts P whose lanes fit the two planes; the first three are candidates,
     // the one with the fewest cell ops per row wins (2P + the FL level its lanes allow, see below)
@@ -465,6 +477,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     plan.Qk = (Lmax + 63) / 64;
     if (plan.Qk == 5) plan.Qk = 6;
     if (plan.Qk == 7) plan.Qk = 8;
+    if (plan.Qk > 8) plan.Qk = plan.Qk <= 16 ? 16 : 32;
     plan.vlane0.assign((size_t)T, 0);
     int Vmax = 1;
     if (W > 1) {
@@ -706,9 +719,10 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
     int bpc = 8;
     if (const char* ev = getenv("SD_TRACE_BPC")) bpc = std::max(1, atoi(ev));  // developer knob
     int grid = std::min((n_chunks + 3) / 4, bpc * n_cu);  // persistent: 8 workgroups of 4 waves per CU
+    if (plan.Qk > 8) grid = std::min(n_chunks, 4 * n_cu);   // long templates: one wave per workgroup (36 KB of LDS each)
     if (const char* ev = getenv("SD_TRACE_GRID")) grid = std::max(1, atoi(ev));   // developer knob
 #define SD_TRACE(QQ)                                                                              \
-    hipLaunchKernelGGL(sd_fast_trace<QQ>, dim3(grid), dim3(256), 0, st, chunks, n_chunks, bases2, \
+    hipLaunchKernelGGL(sd_fast_trace<QQ>, dim3(grid), dim3(64 * trace_waves_per_group(QQ)), 0, st, chunks, n_chunks, bases2, \
                        nmask, slot_of, tcodes, lane_consts, toff, tlen, sc, plan.P, B, argV, ckpt, \
                        ckbase, recs, rec_cnt, queue, order, plan.f16 ? 1 : 0, plan.bshift, plan.waves, klist, kpos, \
                        nkept, plan.T)
@@ -718,7 +732,9 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
         case 3: SD_TRACE(3); break;
         case 4: SD_TRACE(4); break;
         case 6: SD_TRACE(6); break;
-        default: SD_TRACE(8); break;
+        case 8: SD_TRACE(8); break;
+        case 16: SD_TRACE(16); break;
+        default: SD_TRACE(32); break;
     }
 #undef SD_TRACE
 }

@@ -915,19 +915,29 @@ def test_ed_thr_with_monomers_longer_than_512_bp(oracle, lo, hi):
     The prefilter kernel now takes templates of up to 2048 bp (16 / 32 words per template); such sets run on the
     generic family."""
     st = synth.Stream(99, lo)
-    ms = _random_monomers(st, 3, lo, hi)
-    mn = ["L%d" % j for j in range(3)]
+    nmono = 3 if hi <= 1000 else 2      # the narrow layout holds 128 virtual lanes x 64 slots = 8192 template cells
+    ms = _random_monomers(st, nmono, lo, hi)
+    mn = ["L%d" % j for j in range(nmono)]
     reads = []
     for r in range(2):
         parts = []
         while sum(len(x) for x in parts) < 4000 + 2500 * r:
-            j = int(st.below(1, 3)[0])
+            j = int(st.below(1, nmono)[0])
             codes = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), np.frombuffer(ms[j], dtype=np.uint8))
             x = synth._to_ascii(synth.mutate(codes, st, 0.06, 0.03, 0.03))
             parts.append(synth.revcomp_bytes(x) if st.below(1, 2)[0] else x)
         reads.append(b"".join(parts))
     rn = ["r0", "r1"]
-    for ed in (0, 150, 900):
+    # round 3: such sets run on the FAST family too (up to 32 virtual lanes per template, traceback with 16 / 32 cells
+    # per lane); the generic family stays the independent second implementation
+    e = lib.Engine(ms)
+    assert e.info()["family"] == "fast"
+    e.close()
+    for ed in (-1, 0, 150, 900):
         exp = oracle.decompose(rn, reads, mn, ms, threads=8, part=3000, overlap=400, ed_thr=ed)
         got = lib.decompose(rn, reads, mn, ms, part_size=3000, overlap=400, ed_thr=ed)
         assert got == exp, (lo, hi, ed)
+        gen = lib.decompose(rn, reads, mn, ms, part_size=3000, overlap=400, ed_thr=ed, kernel=lib.KERNEL_GENERIC)
+        assert gen == exp, (lo, hi, ed, "generic")
+    exp = oracle.decompose(rn, reads, mn, ms, threads=8, sc=(-2, -3, -4, 2))
+    assert lib.decompose(rn, reads, mn, ms, scoring=(-2, -3, -4, 2)) == exp
