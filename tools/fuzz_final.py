@@ -34,7 +34,7 @@ t0 = time.time()
 tmp = tempfile.mkdtemp(prefix="sd_fuzz_final_")
 for case in range(cases):
     nm = 1 + rnd(10)
-    lo, hi = [(20, 60), (100, 200), (160, 180), (250, 420), (2, 12)][rnd(5)]
+    lo, hi = [(20, 60), (100, 200), (160, 180), (250, 420), (2, 12), (600, 1400)][rnd(6)]   # the last: host identities (> 512 bp)
     anc = st.below(hi + 8, 4)
     ms, mn = [], []
     for j in range(nm):
