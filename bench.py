@@ -489,25 +489,28 @@ def main():
         try:
             with open(tf) as f:
                 tj = json.load(f)
-            same_kernel = (tj.get("kernel_family") == info["family"] and tj.get("cells", info["cells"]) == info["cells"] and
-                           tj.get("cells_per_lane", 35) == info["cells_per_lane"] and tj.get("sum_template_len", 4096) == sumL)
-            if same_kernel and tj.get("workload_rows") == rows:
-                traffic = tj.get("hbm_bytes_per_launch")
-            if same_kernel and tj.get("SQ_INSTS_VALU_per_launch") and tj.get("workload_rows"):
-                # what actually binds the fill (SURVEY 8(d) caveat): VALU issue slots.  The instruction count of a row
-                # is a property of (kernel instance, template set) -- every row of every chunk runs the same slot loop
-                # and tail -- counted once by rocprofv3 --pmc SQ_INSTS_VALU on the C2 workload (committed profile) and
-                # scaled by this run's rows; the durations are measured in this run.
-                cyc = tj["GRBM_GUI_ACTIVE_per_launch"] / 8.0
-                per_row = tj["SQ_INSTS_VALU_per_launch"] / tj["workload_rows"]
-                valu = {"wave_insts_per_launch": per_row * rows / max(d["fill_launches"] / K, 1.0),
-                        "insts_per_row": per_row,
-                        "cycles_per_wave_inst_per_simd": VALU_CYC_PER_WAVE_INST,
-                        "ceiling_source": "profiles/r03_ubench_issue.txt (tools/ubench_issue.hip, this GPU model)",
-                        "issue_frac_profiled": tj["SQ_INSTS_VALU_per_launch"] * VALU_CYC_PER_WAVE_INST / (N_SIMDS * cyc),
-                        "source": "instructions per row: committed profile profiles/fill_traffic.json (rocprofv3 --pmc "
-                                  "SQ_INSTS_VALU GRBM_GUI_ACTIVE, device-resident single launch of C2) x the rows of this "
-                                  "run; durations: this run"}
+            # the C2 entry at the top level, further workloads (the 64-monomer wide kernel) under "other_workloads"
+            for tj in [tj] + list(tj.get("other_workloads", [])):
+                same_kernel = (tj.get("kernel_family") == info["family"] and tj.get("cells", info["cells"]) == info["cells"] and
+                               tj.get("cells_per_lane", 35) == info["cells_per_lane"] and tj.get("sum_template_len", 4096) == sumL)
+                if same_kernel and tj.get("workload_rows") == rows and tj.get("hbm_bytes_per_launch"):
+                    traffic = tj.get("hbm_bytes_per_launch")
+                if same_kernel and tj.get("SQ_INSTS_VALU_per_launch") and tj.get("workload_rows"):
+                    # what actually binds the fill (SURVEY 8(d) caveat): VALU issue slots.  The instruction count of a row
+                    # is a property of (kernel instance, template set) -- every row of every chunk runs the same slot loop
+                    # and tail -- counted once by rocprofv3 --pmc SQ_INSTS_VALU on this workload (committed profile) and
+                    # scaled by this run's rows; the durations are measured in this run.
+                    per_row = tj["SQ_INSTS_VALU_per_launch"] / tj["workload_rows"]
+                    valu = {"wave_insts_per_launch": per_row * rows / max(d["fill_launches"] / K, 1.0),
+                            "insts_per_row": per_row,
+                            "cycles_per_wave_inst_per_simd": VALU_CYC_PER_WAVE_INST,
+                            "ceiling_source": "profiles/r03_ubench_issue.txt (tools/ubench_issue.hip, this GPU model)",
+                            "issue_frac_profiled": None if not tj.get("GRBM_GUI_ACTIVE_per_launch") else
+                            tj["SQ_INSTS_VALU_per_launch"] * VALU_CYC_PER_WAVE_INST / (N_SIMDS * tj["GRBM_GUI_ACTIVE_per_launch"] / 8.0),
+                            "source": "instructions per row: committed profile profiles/fill_traffic.json (rocprofv3 --pmc "
+                                      "SQ_INSTS_VALU, device-resident single launch of %s) x the rows of this "
+                                      "run; durations: this run" % tj.get("kernel_instance", "the fill")}
+                    break
         except Exception:
             traffic = None
     kname = ("sd_fast_fill_wide" if info["cells_per_lane"] > 64 else "sd_fast_fill") if info["family"] == "fast" else "sd_generic_fill"
@@ -542,7 +545,8 @@ def main():
         "isolated_avg_launch_ms": res_fill_s * 1e3 if res_steps else None,
         "valu_issue": valu, "hbm_notional": hbm_notional,
         "binding_resource": "VALU issue slots: packed-f16 / DPP / SDWA wave64 instructions issue once per 4.1 cycles per "
-                            "SIMD on gfx950 (measured), the fill is 116 of them per row",
+                            "SIMD on gfx950 (measured), the fill is %s of them per row" % (
+                                "%.0f" % valu["insts_per_row"] if valu else "116 (C2) / 584 (128 templates)"),
         "cells_per_s": rows * sumL * K / launches / fill_s if fill_s > 0 else 0.0})
 
     out = {

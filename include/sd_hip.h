@@ -121,11 +121,12 @@ int sd_run_files_range(const char* reads_fa, const char* monomers_fa, const sd_p
  * [2] compaction, [3] in-stream identity kernels (HIP events, summed over the batches), [4] identity pairs computed
  * in-stream, [5] device batches, [6] DP rows, [7] pack + enqueue, [8] waits for the device, [9] raw text,
  * [10] post-processing, [11] file writes, [12] text-based identities (0 when they all came in-stream), [13] final /
- * _alt text, [14] whole call, [15] device / pinned allocations.  Measurement only (bench.py, tools/). */
+ * _alt text, [14] whole call, [15] device / pinned allocations, [16] engine / pipeline set-up, [17] per-read assembly,
+ * [18..23] 0.  Measurement only (bench.py, tools/). */
+void sd_last_run_stats(double out[24]);
 /* Batches of this process that were repeated with integer cells because the fp16 range guard of a fill tripped
  * (0 unless sd_params.reserved[2] lowers the limit, or the layout plan's range bound is wrong). */
 int64_t sd_guard_trips(void);
-void sd_last_run_stats(double out[16]);
 
 /* convert_tsv (main.py:168-184) alone: an existing raw TSV + the two FASTA files -> final TSV and _alt TSV,
  * streamed in batches of reads.  device < 0: host identities (sd_identity_segments). */

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
     const uint32_t* __restrict__ crank) {
     static_assert(P % 16 == 0, "wide variant streams the table 16 slots at a time");
     constexpr int G = P / 16;
-    extern __shared__ uint32_t lds[];  // [5][G][2 halves][64][4]
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [5][G][2 halves][64][4]
     constexpr int TBL = 5 * G * 512;
     for (int idx = threadIdx.x * 4; idx < TBL; idx += blockDim.x * 4)
         *reinterpret_cast<uint4*>(&lds[idx]) = *reinterpret_cast<const uint4*>(&table[idx]);
@@ -88,11 +88,18 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
     int base = 0, Brel = 0, tp = 0;
     int accBV = 0;
 
-    auto load_group = [&](int r, int g, int buf, uint32_t& after) {
-        uint32_t off = (uint32_t)((r * G + g) * 512 + lane * 4);
-        asm volatile("" : "+v"(off), "+v"(after));
-        const uint4 q0 = *reinterpret_cast<const uint4*>(lds + off);
-        const uint4 q1 = *reinterpret_cast<const uint4*>(lds + off + 256);
+    // one address per row (table row of the read symbol + this lane's 16 bytes); the groups and halves are
+    // immediate offsets of ds_read_b128.  `after` pins the loads behind the value it names.
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    using lds_u4 = __attribute__((address_space(3))) const u32x4_t;
+    const uint32_t lds_lane = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)lds + lane * 16;
+    uint32_t rowoff = 0;   // LDS byte address
+    auto set_row = [&](int r) { rowoff = (uint32_t)(r * (G * 2048)) + lds_lane; };
+    auto load_group = [&](int g, int buf, uint32_t& after) {
+        asm volatile("" : "+v"(rowoff), "+v"(after));
+        lds_u4* t = (lds_u4*)(uintptr_t)rowoff;
+        const u32x4_t q0 = t[g * 128];
+        const u32x4_t q1 = t[g * 128 + 64];
         tbg[buf][0] = q0.x; tbg[buf][1] = q0.y; tbg[buf][2] = q0.z; tbg[buf][3] = q0.w;
         tbg[buf][4] = q1.x; tbg[buf][5] = q1.y; tbg[buf][6] = q1.z; tbg[buf][7] = q1.w;
     };
@@ -134,7 +141,8 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
         uint32_t run = 0;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            load_group(r0, g, 0, pin);
+            if (g == 0) set_row(r0);
+            load_group(g, 0, pin);
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int q = 16 * g + s;
@@ -153,9 +161,9 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
     }
     int rnext = rs.code(1);  // read symbol of the next row; its group 0 is prefetched into tbg[0]
     rs.advance(1);
-    load_group(rnext, 0, 0, L[P - 1]);
+    set_row(rnext);
+    load_group(0, 0, L[P - 1]);
     for (int i = 1; i < n; ++i) {
-        const int rcur = rnext;
         if ((i & (FAST_R - 1)) == 0) {
             if ((i & (FAST_REBASE - 1)) == 0) {
                 const uint32_t d2 = CO::splat(Brel - tp * sc.ins);
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
                     else asm("v_pk_max_f16 %0, %1, %2" : "=v"(u) : "v"(L[q - 1]), "s"(KBs));
                     u_[q] = u;
                     t_[q] = cvt_bf8x2(tbg[(q >> 4) & 1][(q & 15) >> 1], q & 1, one_s);
-                    if ((q & 15) == 2 && (q >> 4) + 1 < G) load_group(rcur, (q >> 4) + 1, ((q >> 4) + 1) & 1, t_[q]);
+                    if ((q & 15) == 2 && (q >> 4) + 1 < G) load_group((q >> 4) + 1, ((q >> 4) + 1) & 1, t_[q]);
                 }
                 // pin the skew: this step's scalar operands are "redefined" here, so the compiler cannot batch
                 // the u / table conversions of later slots first (that would need 2P registers).  Scalar pins:
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
                 // every virtual lane starts a template: slot 0 has no diagonal / chain input
                 u_[q] = q == 0 ? KB : pk_max(L[q - 1], KB);
                 // stream the next 16 slots of the table one group ahead of their first use
-                if ((q & 15) == 2 && (q >> 4) + 1 < G) load_group(rcur, (q >> 4) + 1, ((q >> 4) + 1) & 1, u_[q]);
+                if ((q & 15) == 2 && (q >> 4) + 1 < G) load_group((q >> 4) + 1, ((q >> 4) + 1) & 1, u_[q]);
             }
             // pin the skew: the next step's inputs (KB) become available only after this step's
             // chain update, so the compiler cannot batch all u/v first (that needs 2P registers)
@@ -241,7 +249,8 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
         }
         rnext = rs.code(i + 1);
         rs.advance(i + 1);
-        load_group(rnext, 0, 0, L[P - 1]);
+        set_row(rnext);
+        load_group(0, 0, L[P - 1]);
         ++tp;
         reduce_ends(L[P - 1], i + 1);
     }

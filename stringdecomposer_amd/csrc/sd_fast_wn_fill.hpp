@@ -42,7 +42,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     static_assert(P % 16 == 0, "the code table is streamed 16 slots at a time");
     static_assert(!(COMPACT && RANKED), "the compacted form needs no ranks");
     constexpr int G = P / 16;
-    extern __shared__ uint32_t lds[];  // [W][G][2 halves][64 lanes][4 dwords] codes, then the exchange area
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [W][G][2 halves][64 lanes][4 dwords] codes, then the exchange area
     if (n_ptr) n_chunks = *n_ptr;      // the size of a chunk class is known on the device only
     const int Wb = COMPACT ? (int)(blockDim.x >> 6) : W;   // waves of this workgroup; W stays the checkpoint stride
     const int TBL = Wb * G * 512;
@@ -110,11 +110,15 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
         int base = 0, Brel = 0, tp = 0;
         int accBV = 0;
 
+        // one LDS address per lane; groups and halves are immediate offsets of ds_read_b128
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    using lds_u4 = __attribute__((address_space(3))) const u32x4_t;
+        uint32_t cbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)myc + lane * 16;
         auto load_group = [&](int g, int buf, uint32_t& after) {
-            uint32_t off = (uint32_t)(g * 512 + lane * 4);
-            asm volatile("" : "+v"(off), "+v"(after));
-            const uint4 q0 = *reinterpret_cast<const uint4*>(myc + off);
-            const uint4 q1 = *reinterpret_cast<const uint4*>(myc + off + 256);
+            asm volatile("" : "+v"(cbase), "+v"(after));
+            lds_u4* t = (lds_u4*)(uintptr_t)cbase;
+            const u32x4_t q0 = t[g * 128];
+            const u32x4_t q1 = t[g * 128 + 64];
             cg[buf][0] = q0.x; cg[buf][1] = q0.y; cg[buf][2] = q0.z; cg[buf][3] = q0.w;
             cg[buf][4] = q1.x; cg[buf][5] = q1.y; cg[buf][6] = q1.z; cg[buf][7] = q1.w;
         };
