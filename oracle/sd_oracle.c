@@ -584,33 +584,91 @@ int sdo_decompose_files_ex(const char* reads_fa, const char* monomers_fa, int th
 /* ------------------------------------------------------------------------------------------ */
 /* Unit-cost NW identity (restates what main.py:29-60 obtains from edlib NW + extended CIGAR)   */
 /* ------------------------------------------------------------------------------------------ */
+/* '=' and all columns of the path edlib reports for one (sub)problem whose distance is known to be the optimum:
+ * edlib.cpp:1164-1213 (obtainAlignment).  Small problems: block traceback, priority up ('I') > left ('D') > diagonal
+ * (edlib.cpp:945-1130, restated on the full matrix).  Once (2*8+4) * ceil(qlen/64) * tlen + 8 * tlen reaches 1 MB
+ * edlib splits the TARGET in halves (Hirschberg, edlib.cpp:1234-1400): with L[i] = distance of query[0..i) to the
+ * left half and R[i] = distance of query[i..) to the right half it takes the SMALLEST 0-based row index x in
+ * 0..qlen-2 with L[x+1] + R[x+1] == best, else x = -1 if lw + R[0] == best, else x = qlen-1 if L[qlen] + rw == best
+ * (edlib.cpp:1315-1349; its banded columns hold every cell of an optimal path exactly), and concatenates the paths
+ * of (query[0..x], left half) and (query[x+1..], right half). */
+static void nw_column(const char* q, int qlen, const char* t, int tlen, int rev, int32_t* out) {
+    /* out[i] = distance of the first i symbols of q to the first tlen symbols of t (rev: both read from the end) */
+    int32_t* prev = (int32_t*)malloc(sizeof(int32_t) * (size_t)(qlen + 1));
+    for (int i = 0; i <= qlen; ++i) out[i] = i;
+    for (int c = 1; c <= tlen; ++c) {
+        memcpy(prev, out, sizeof(int32_t) * (size_t)(qlen + 1));
+        out[0] = c;
+        const char tc = rev ? t[-(c - 1)] : t[c - 1];
+        for (int i = 1; i <= qlen; ++i) {
+            const char qc = rev ? q[-(i - 1)] : q[i - 1];
+            int d = prev[i - 1] + (qc == tc ? 0 : 1);
+            int u = out[i - 1] + 1;
+            int l = prev[i] + 1;
+            int m = d < u ? d : u;
+            out[i] = m < l ? m : l;
+        }
+    }
+    free(prev);
+}
+
+static int nw_path(const char* q, int qlen, const char* t, int tlen, int best, int* matches, int* columns) {
+    if (qlen == 0 || tlen == 0) { *columns += qlen + tlen; return 0; }
+    const long long blocks = (qlen + 63) / 64;
+    if (20ll * blocks * tlen + 8ll * tlen < 1024 * 1024) {
+        const int W = tlen + 1;
+        int32_t* D = (int32_t*)malloc(sizeof(int32_t) * (size_t)(qlen + 1) * (size_t)W);
+        for (int c = 0; c <= tlen; ++c) D[c] = c;
+        for (int r = 1; r <= qlen; ++r) {
+            D[(size_t)r * W] = r;
+            for (int c = 1; c <= tlen; ++c) {
+                int d = D[(size_t)(r - 1) * W + c - 1] + (q[r - 1] == t[c - 1] ? 0 : 1);
+                int u = D[(size_t)(r - 1) * W + c] + 1;
+                int l = D[(size_t)r * W + c - 1] + 1;
+                int m = d < u ? d : u;
+                D[(size_t)r * W + c] = m < l ? m : l;
+            }
+        }
+        int r = qlen, c = tlen;
+        while (r > 0 || c > 0) {
+            int cur = D[(size_t)r * W + c];
+            if (r > 0 && D[(size_t)(r - 1) * W + c] + 1 == cur) { --r; }               /* up: 'I' */
+            else if (c > 0 && D[(size_t)r * W + c - 1] + 1 == cur) { --c; }            /* left: 'D' */
+            else { if (D[(size_t)(r - 1) * W + c - 1] == cur) ++*matches; --r; --c; } /* '=' or 'X' */
+            ++*columns;
+        }
+        int ed = D[(size_t)qlen * W + tlen];
+        free(D);
+        return ed == best ? 0 : -1;
+    }
+    const int lw = tlen / 2, rw = tlen - lw;
+    int32_t* L = (int32_t*)malloc(sizeof(int32_t) * (size_t)(qlen + 1));
+    int32_t* Rr = (int32_t*)malloc(sizeof(int32_t) * (size_t)(qlen + 1));
+    nw_column(q, qlen, t, lw, 0, L);
+    nw_column(q + qlen - 1, qlen, t + tlen - 1, rw, 1, Rr);   /* Rr[k] = last k query symbols vs the right half */
+    int x = -2, ls = 0, rs = 0;
+    for (int i = 0; i <= qlen - 2 && x == -2; ++i)
+        if (L[i + 1] + Rr[qlen - (i + 1)] == best) { x = i; ls = L[i + 1]; rs = Rr[qlen - (i + 1)]; }
+    if (x == -2 && lw + Rr[qlen] == best) { x = -1; ls = lw; rs = Rr[qlen]; }
+    if (x == -2 && L[qlen] + rw == best) { x = qlen - 1; ls = L[qlen]; rs = rw; }
+    free(L);
+    free(Rr);
+    if (x == -2) return -1;
+    const int ul = x + 1;
+    if (nw_path(q, ul, t, lw, ls, matches, columns)) return -1;
+    return nw_path(q + ul, qlen - ul, t + lw, rw, rs, matches, columns);
+}
+
 int sdo_nw_identity(const char* q, int qlen, const char* t, int tlen, int* matches, int* columns) {
     if (matches) *matches = 0;
     if (columns) *columns = 0;
     if (qlen == 0 || tlen == 0) return -1;
-    const int W = tlen + 1;
-    int32_t* D = (int32_t*)malloc(sizeof(int32_t) * (size_t)(qlen + 1) * (size_t)W);
-    for (int c = 0; c <= tlen; ++c) D[c] = c;
-    for (int r = 1; r <= qlen; ++r) {
-        D[(size_t)r * W] = r;
-        for (int c = 1; c <= tlen; ++c) {
-            int d = D[(size_t)(r - 1) * W + c - 1] + (q[r - 1] == t[c - 1] ? 0 : 1);
-            int u = D[(size_t)(r - 1) * W + c] + 1;
-            int l = D[(size_t)r * W + c - 1] + 1;
-            int m = d < u ? d : u;
-            D[(size_t)r * W + c] = m < l ? m : l;
-        }
-    }
-    int r = qlen, c = tlen, m = 0, cols = 0;
-    while (r > 0 || c > 0) {
-        int cur = D[(size_t)r * W + c];
-        if (r > 0 && D[(size_t)(r - 1) * W + c] + 1 == cur) { --r; }               /* up: 'I' */
-        else if (c > 0 && D[(size_t)r * W + c - 1] + 1 == cur) { --c; }            /* left: 'D' */
-        else { if (D[(size_t)(r - 1) * W + c - 1] == cur) ++m; --r; --c; }        /* '=' or 'X' */
-        ++cols;
-    }
-    int ed = D[(size_t)qlen * W + tlen];
-    free(D);
+    int32_t* col = (int32_t*)malloc(sizeof(int32_t) * (size_t)(qlen + 1));
+    nw_column(q, qlen, t, tlen, 0, col);
+    const int ed = col[qlen];
+    free(col);
+    int m = 0, cols = 0;
+    if (nw_path(q, qlen, t, tlen, ed, &m, &cols)) return -2;
     if (matches) *matches = m;
     if (columns) *columns = cols;
     return ed;

@@ -76,7 +76,7 @@ int PostProcessor::tmpl_of_name(const std::string& nm) const {
 // tmpl[pair[s]] only (out[s])
 int PostProcessor::identities(const std::vector<std::pair<const char*, int64_t>>& spans, const std::vector<int64_t>& seg_start,
                               const std::vector<int32_t>& seg_len, const int32_t* pair, bool homo, RawVec<double>& out,
-                              std::string& err) {
+                              std::string& err, bool host_only) {
     const int64_t n_seg = (int64_t)seg_start.size();
     const int T = (int)il_seq.size();
     const int64_t n_pairs = pair ? n_seg : n_seg * T;
@@ -85,7 +85,7 @@ int PostProcessor::identities(const std::vector<std::pair<const char*, int64_t>>
     d.resize((size_t)n_pairs);
     m.resize((size_t)n_pairs);
     int rc = SD_ERR_UNSUPPORTED;
-    if (device >= 0) {
+    if (device >= 0 && !host_only) {
         rc = nw_identity_device(spans, seg_start.data(), seg_len.data(), n_seg, il_seq, pair, homo, device, threads, d.data(), m.data());
         if (rc != SD_OK && rc != SD_ERR_UNSUPPORTED) { err = "identity kernel failed (rc " + std::to_string(rc) + ")"; return rc; }
     }
@@ -101,7 +101,7 @@ int PostProcessor::identities(const std::vector<std::pair<const char*, int64_t>>
         c.resize((size_t)n_pairs);
         rc = sd_identity_segments(text.data(), (int64_t)text.size(), seg_start.data(), en.data(), n_seg, tp.data(), tl.data(), T,
                                   pair, homo ? 1 : 0, threads, d.data(), m.data(), c.data());
-        if (rc != SD_OK) { err = "a block is too long for the identity computation (> 65000 bp)"; return rc; }
+        if (rc != SD_OK) { err = "identity computation failed (rc " + std::to_string(rc) + ")"; return rc; }
     }
     out.resize((size_t)n_pairs);
     parallel_for((n_pairs + 65535) / 65536, threads, 1, [&](int64_t blk) {
@@ -162,6 +162,7 @@ int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd
     const int nK = (int)keys.size();
     const int per = second_best ? T : 1;
     bool have = ident && ident->id && (!second_best || ident->idh);
+    bool host_only = false;   // the batch holds a pair edlib aligns by Hirschberg's split
     // words of row b (plain / compressed)
     auto words = [&](int64_t b, bool homo) -> const uint32_t* {
         if (!ident->src) return (homo ? ident->idh : ident->id) + (size_t)b * (size_t)per;
@@ -187,7 +188,6 @@ int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd
         });
         for (uint8_t bb : bad) if (bb) { have = false; break; }
     }
-    const bool id = have;   // (name kept: "identities came with the rows")
     // text = the reads that have blocks, concatenated; blocks never cross a read
     std::vector<std::pair<const char*, int64_t>> spans;
     std::vector<int64_t> seg_start((size_t)nB);
@@ -211,20 +211,18 @@ int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd
         }
     }
     {
-        // edlib computes the path of a long alignment with Hirschberg's split instead of its block traceback once
-        // (2*8+4) * ceil(|query| / 64) * |target| reaches 1 MB (edlib.cpp:1186-1190): ~19.6 kb against a 171-bp
-        // monomer.  Its choice among equally good paths -- hence the '=' count and the identity -- may then differ
-        // from the traceback priorities this implementation reproduces.  Cannot happen with the default 5.5-kb
-        // chunks (-b >= 19000 or kb-long monomers); say so once instead of differing silently.
+        // edlib computes the path of a long alignment with Hirschberg's split instead of its block traceback
+        // (edlib.cpp:1186-1190; ~19.6 kb against a 171-bp monomer: -b >= 19000 or kb-long monomers).  The device
+        // kernels implement the traceback only, so a batch that holds such a pair takes the host identities, which
+        // follow edlib in both cases (sd_post.hip)
         size_t tmax = 1;
         for (const std::string& t : il_seq) tmax = std::max(tmax, t.size());
         int64_t worst = 0;
         for (int64_t b = 0; b < nB; ++b) worst = std::max<int64_t>(worst, seg_len[(size_t)b]);
-        static std::atomic<bool> warned{false};
-        if ((int64_t)20 * ((worst + 63) / 64) * (int64_t)tmax >= (1 << 20) && !warned.exchange(true))
-            std::fprintf(stderr, "WARNING: a block of %lld bp is long enough for edlib to switch to Hirschberg's algorithm "
-                         "(edlib.cpp:1186); its identity may differ from the reference's in the last digits\n", (long long)worst);
+        host_only = edlib_splits(worst, (int64_t)tmax);   // (conservative: longest block x longest template)
+        if (host_only) have = false;
     }
+    const bool id = have;   // identities came with the rows
     const double t_a = now_seconds();
     RawVec<double> vals, hvals;
     int rc;
@@ -233,12 +231,12 @@ int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd
     } else if (!second_best) {
         std::vector<int32_t> pair((size_t)nB);
         for (int64_t b = 0; b < nB; ++b) pair[(size_t)b] = own_il_of_t[(size_t)rows[b].tmpl];
-        rc = identities(spans, seg_start, seg_len, pair.data(), false, vals, err);
+        rc = identities(spans, seg_start, seg_len, pair.data(), false, vals, err, host_only);
         if (rc) return rc;
     } else {
-        rc = identities(spans, seg_start, seg_len, nullptr, false, vals, err);
+        rc = identities(spans, seg_start, seg_len, nullptr, false, vals, err, host_only);
         if (rc) return rc;
-        rc = identities(spans, seg_start, seg_len, nullptr, true, hvals, err);
+        rc = identities(spans, seg_start, seg_len, nullptr, true, hvals, err, host_only);
         if (rc) return rc;
     }
     const double t_b = now_seconds();

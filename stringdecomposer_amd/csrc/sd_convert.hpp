@@ -55,7 +55,7 @@ class PostProcessor {
   private:
     int identities(const std::vector<std::pair<const char*, int64_t>>& spans, const std::vector<int64_t>& seg_start,
                    const std::vector<int32_t>& seg_len, const int32_t* pair, bool homo, RawVec<double>& out,
-                   std::string& err);
+                   std::string& err, bool host_only = false);
     std::vector<std::string> il_name, il_seq;        // interleaved m0, m0', m1, m1', ... (main.py:79-84)
     std::vector<std::string> keys;                   // distinct names in first-occurrence order
     std::vector<int> kcol;                           // key -> last interleaved index of that name

@@ -29,6 +29,13 @@
 
 namespace sd {
 
+// edlib computes the path of an alignment by its block traceback while the traceback data fits 1 MB and by
+// Hirschberg's split of the target otherwise (edlib.cpp:1186-1192): true for the second case (~19.6 kb against a
+// 171-bp monomer).  The host identities (sd_post.hip) follow both; the device kernels implement the traceback only.
+inline bool edlib_splits(int64_t qlen, int64_t tlen) {
+    return 20ll * ((qlen + 63) / 64) * tlen + 8ll * tlen >= 1024 * 1024;
+}
+
 struct Seq {
     std::string name;
     std::string seq;

@@ -234,6 +234,11 @@ int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans
     if (pair_tmpl)
         for (int64_t s = 0; s < n_seg; ++s)
             if (pair_tmpl[s] < 0 || pair_tmpl[s] >= T) return SD_ERR_PARAM;
+    {   // a pair edlib would align by Hirschberg's split (edlib.cpp:1186): the host identities follow it, this kernel does not
+        size_t traw = 1;
+        for (const std::string& t : tmpl) traw = std::max(traw, t.size());
+        if (sd::edlib_splits(qmax, (int64_t)traw)) return SD_ERR_UNSUPPORTED;
+    }
 
     std::lock_guard<std::mutex> g(g_nw.m);
     if (hipSetDevice(device) != hipSuccess) return SD_ERR_HIP;

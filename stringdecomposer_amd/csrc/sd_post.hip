@@ -16,69 +16,98 @@
 
 namespace {
 
+// longest sequence of the host identities (memory: the block traceback of a pair stays below edlib's 1 MB, the split
+// form keeps one column)
+constexpr int32_t SD_NW_HOST_MAX = 1 << 27;
+
 // Unit-cost global alignment by Myers' bit-vector algorithm (J. ACM 46(3), 1999; block form of
 // Hyyro 2003): query along the bit rows, one column per target symbol, the vertical delta vectors
 // (Pv, Mv) of every column are kept so that any D[i][j] = j + popcount(Pv_j & low_i) -
 // popcount(Mv_j & low_i) can be read back.  The traceback then applies the same rule as a
 // full-matrix walk from the bottom-right corner: up ('I', consume query) > left ('D', consume
 // target) > diagonal ('=' / 'X').  Alignment columns = edit distance + matches.
+using sd::edlib_splits;
+
 struct BitNW {
-    std::vector<uint64_t> peq;  // [5][K]
+    std::vector<uint64_t> peq;  // [classes][K]
     std::vector<uint64_t> pv, mv;  // [(tlen + 1)][K]
-    static int code(char c) {
-        switch (c) {
-            case 'A': return 0;
-            case 'C': return 1;
-            case 'G': return 2;
-            case 'T': return 3;
-            case 'N': return 4;
-            default: return 5;
+    std::vector<uint64_t> cp, cm;  // one column (column scores)
+    std::vector<int32_t> colL, colR;
+    std::string rq, rt;
+    uint16_t cls[256];
+    // symbol classes of one pair: every byte of the query its own class, bytes only the target has share class 0
+    // (they match nothing) -- edlib's alphabet is the set of bytes that occur
+    int classes(const char* q, int qlen) {
+        std::memset(cls, 0, sizeof cls);
+        int n = 1;
+        for (int i = 0; i < qlen; ++i) {
+            uint16_t& c = cls[(uint8_t)q[i]];
+            if (!c) c = (uint16_t)n++;
+        }
+        return n;
+    }
+    void build_peq(const char* q, int qlen, int K, int ncls) {
+        peq.assign((size_t)ncls * K, 0);
+        for (int i = 0; i < qlen; ++i) peq[(size_t)cls[(uint8_t)q[i]] * K + (i >> 6)] |= 1ull << (i & 63);
+    }
+    // one column step of the unit-cost global alignment (Myers / Hyyro block form), in place or into (np, nm)
+    static inline void column_step(const uint64_t* eqs, const uint64_t* pp, const uint64_t* pm, uint64_t* np, uint64_t* nm,
+                                   int K) {
+        int hin = 1;  // global alignment: D[0][j] - D[0][j-1] = 1
+        for (int b = 0; b < K; ++b) {
+            uint64_t Eq = eqs[b];
+            const uint64_t Pv = pp[b], Mv = pm[b];
+            const uint64_t Xv = Eq | Mv;
+            if (hin < 0) Eq |= 1ull;
+            const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+            uint64_t Ph = Mv | ~(Xh | Pv);
+            uint64_t Mh = Pv & Xh;
+            int hout = 0;
+            if (Ph >> 63) hout = 1;
+            if (Mh >> 63) hout = -1;
+            Ph <<= 1;
+            Mh <<= 1;
+            if (hin < 0) Mh |= 1ull;
+            if (hin > 0) Ph |= 1ull;
+            np[b] = Mh | ~(Xv | Ph);
+            nm[b] = Ph & Xv;
+            hin = hout;
         }
     }
-    void run(const char* q, int qlen, const char* t, int tlen, int32_t& dist, int32_t& matches,
-             int32_t& columns) {
-        dist = -1;
-        matches = 0;
-        columns = 0;
-        if (qlen <= 0 || tlen <= 0) return;
+    // out[i] = distance of q[0..i) to t[0..tlen), i = 0..qlen (memory: one column)
+    void column_scores(const char* q, int qlen, const char* t, int tlen, std::vector<int32_t>& out) {
         const int K = (qlen + 63) >> 6;
-        // symbols outside ACGTN can only match themselves: handled by a slow exact path
-        for (int i = 0; i < qlen; ++i)
-            if (code(q[i]) > 4) { slow(q, qlen, t, tlen, dist, matches, columns); return; }
-        for (int j = 0; j < tlen; ++j)
-            if (code(t[j]) > 4) { slow(q, qlen, t, tlen, dist, matches, columns); return; }
-        peq.assign((size_t)5 * K, 0);
-        for (int i = 0; i < qlen; ++i) peq[(size_t)code(q[i]) * K + (i >> 6)] |= 1ull << (i & 63);
+        const int ncls = classes(q, qlen);
+        build_peq(q, qlen, K, ncls);
+        cp.assign((size_t)K, ~0ull);
+        cm.assign((size_t)K, 0);
+        for (int j = 1; j <= tlen; ++j)
+            column_step(&peq[(size_t)cls[(uint8_t)t[j - 1]] * K], cp.data(), cm.data(), cp.data(), cm.data(), K);
+        out.resize((size_t)qlen + 1);
+        int v = tlen;
+        out[0] = v;
+        for (int i = 0; i < qlen; ++i) {
+            const uint64_t bit = 1ull << (i & 63);
+            v += ((cp[(size_t)(i >> 6)] & bit) ? 1 : 0) - ((cm[(size_t)(i >> 6)] & bit) ? 1 : 0);
+            out[(size_t)i + 1] = v;
+        }
+    }
+    // Unit-cost global alignment by Myers' bit-vector algorithm (J. ACM 46(3), 1999; block form of Hyyro 2003):
+    // query along the bit rows, one column per target symbol, the vertical delta vectors (Pv, Mv) of every column
+    // are kept so that any D[i][j] = j + popcount(Pv_j & low_i) - popcount(Mv_j & low_i) can be read back.  The
+    // traceback then applies the same rule as a full-matrix walk from the bottom-right corner: up ('I', consume
+    // query) > left ('D', consume target) > diagonal ('=' / 'X') -- edlib.cpp:945-1130.  Returns the distance; adds
+    // the '=' columns of the path to `matches`.
+    int traceback(const char* q, int qlen, const char* t, int tlen, int32_t& matches) {
+        const int K = (qlen + 63) >> 6;
+        const int ncls = classes(q, qlen);
+        build_peq(q, qlen, K, ncls);
         pv.resize((size_t)(tlen + 1) * K);
         mv.resize((size_t)(tlen + 1) * K);
         for (int b = 0; b < K; ++b) { pv[b] = ~0ull; mv[b] = 0; }
-        for (int j = 1; j <= tlen; ++j) {
-            const uint64_t* eqs = &peq[(size_t)code(t[j - 1]) * K];
-            const uint64_t* pp = &pv[(size_t)(j - 1) * K];
-            const uint64_t* pm = &mv[(size_t)(j - 1) * K];
-            uint64_t* np = &pv[(size_t)j * K];
-            uint64_t* nm = &mv[(size_t)j * K];
-            int hin = 1;  // global alignment: D[0][j] - D[0][j-1] = 1
-            for (int b = 0; b < K; ++b) {
-                uint64_t Eq = eqs[b];
-                const uint64_t Pv = pp[b], Mv = pm[b];
-                const uint64_t Xv = Eq | Mv;
-                if (hin < 0) Eq |= 1ull;
-                const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-                uint64_t Ph = Mv | ~(Xh | Pv);
-                uint64_t Mh = Pv & Xh;
-                int hout = 0;
-                if (Ph >> 63) hout = 1;
-                if (Mh >> 63) hout = -1;
-                Ph <<= 1;
-                Mh <<= 1;
-                if (hin < 0) Mh |= 1ull;
-                if (hin > 0) Ph |= 1ull;
-                np[b] = Mh | ~(Xv | Ph);
-                nm[b] = Ph & Xv;
-                hin = hout;
-            }
-        }
+        for (int j = 1; j <= tlen; ++j)
+            column_step(&peq[(size_t)cls[(uint8_t)t[j - 1]] * K], &pv[(size_t)(j - 1) * K], &mv[(size_t)(j - 1) * K],
+                        &pv[(size_t)j * K], &mv[(size_t)j * K], K);
         auto D = [&](int i, int j) -> int {  // i rows of the query consumed, j target symbols
             const uint64_t* P = &pv[(size_t)j * K];
             const uint64_t* M = &mv[(size_t)j * K];
@@ -93,7 +122,7 @@ struct BitNW {
         };
         int i = qlen, j = tlen, m = 0;
         int cur = D(i, j);
-        dist = cur;
+        const int dist = cur;
         while (i > 0 || j > 0) {
             int up = -1;
             if (i > 0) {  // D[i-1][j] from the vertical delta of row i in column j
@@ -110,38 +139,53 @@ struct BitNW {
             if (dg == cur) ++m;
             --i; --j; cur = dg;
         }
-        matches = m;
-        columns = dist + m;
+        matches += m;
+        return dist;
     }
-    // full-matrix version for sequences with symbols outside ACGTN (never produced by the pipeline)
-    std::vector<uint16_t> Dm;
-    void slow(const char* q, int qlen, const char* t, int tlen, int32_t& dist, int32_t& matches,
-              int32_t& columns) {
-        const size_t W = (size_t)tlen + 1;
-        Dm.resize((size_t)(qlen + 1) * W);
-        for (int c = 0; c <= tlen; ++c) Dm[(size_t)c] = (uint16_t)c;
-        for (int r = 1; r <= qlen; ++r) {
-            uint16_t* cur = &Dm[(size_t)r * W];
-            const uint16_t* up = cur - W;
-            cur[0] = (uint16_t)r;
-            for (int c = 1; c <= tlen; ++c) {
-                uint16_t v = (uint16_t)(up[c - 1] + (q[r - 1] == t[c - 1] ? 0 : 1));
-                if ((uint16_t)(up[c] + 1) < v) v = (uint16_t)(up[c] + 1);
-                if ((uint16_t)(cur[c - 1] + 1) < v) v = (uint16_t)(cur[c - 1] + 1);
-                cur[c] = v;
-            }
+    // The path edlib reports for a (sub)problem whose optimum `best` is known (obtainAlignment, edlib.cpp:1164-1213):
+    // small problems by the block traceback; once its data would reach 1 MB the TARGET is split in halves
+    // (obtainAlignmentHirschberg, edlib.cpp:1234-1400): with L[i] = distance of q[0..i) to the left half and R[k] =
+    // distance of the last k query symbols to the right half, the split row is the SMALLEST x in 0..qlen-2 with
+    // L[x+1] + R[qlen-x-1] == best, else x = -1 if lw + R[qlen] == best, else x = qlen-1 if L[qlen] + rw == best
+    // (edlib.cpp:1315-1349; its banded columns hold every cell of an optimal path exactly, so the full columns
+    // find the same row), and the paths of (q[0..x], left half) and (q[x+1..), right half) are concatenated.
+    bool path(const char* q, int qlen, const char* t, int tlen, int best, int32_t& matches) {
+        if (qlen == 0 || tlen == 0) return true;
+        if (!edlib_splits(qlen, tlen)) return traceback(q, qlen, t, tlen, matches) == best;
+        const int lw = tlen / 2, rw = tlen - lw;
+        std::vector<int32_t> L, R;
+        column_scores(q, qlen, t, lw, L);
+        std::string rq2(q, q + qlen), rt2(t + lw, t + tlen);
+        std::reverse(rq2.begin(), rq2.end());
+        std::reverse(rt2.begin(), rt2.end());
+        column_scores(rq2.data(), qlen, rt2.data(), rw, R);
+        int x = -2, ls = 0, rs = 0;
+        for (int i = 0; i <= qlen - 2; ++i)
+            if (L[(size_t)i + 1] + R[(size_t)(qlen - i - 1)] == best) { x = i; ls = L[(size_t)i + 1]; rs = R[(size_t)(qlen - i - 1)]; break; }
+        if (x == -2 && lw + R[(size_t)qlen] == best) { x = -1; ls = lw; rs = R[(size_t)qlen]; }
+        if (x == -2 && L[(size_t)qlen] + rw == best) { x = qlen - 1; ls = L[(size_t)qlen]; rs = rw; }
+        if (x == -2) return false;
+        const int ul = x + 1;
+        return path(q, ul, t, lw, ls, matches) && path(q + ul, qlen - ul, t + lw, rw, rs, matches);
+    }
+    void run(const char* q, int qlen, const char* t, int tlen, int32_t& dist, int32_t& matches,
+             int32_t& columns) {
+        dist = -1;
+        matches = 0;
+        columns = 0;
+        if (qlen <= 0 || tlen <= 0) return;
+        int32_t m = 0;
+        int d;
+        if (!edlib_splits(qlen, tlen)) {
+            d = traceback(q, qlen, t, tlen, m);
+        } else {
+            column_scores(q, qlen, t, tlen, colL);
+            d = colL[(size_t)qlen];
+            if (!path(q, qlen, t, tlen, d, m)) return;   // cannot happen: d is the optimum
         }
-        int r = qlen, c = tlen, m = 0, cols = 0;
-        while (r > 0 || c > 0) {
-            const uint16_t cur = Dm[(size_t)r * W + c];
-            if (r > 0 && (uint16_t)(Dm[(size_t)(r - 1) * W + c] + 1) == cur) { --r; }
-            else if (c > 0 && (uint16_t)(Dm[(size_t)r * W + c - 1] + 1) == cur) { --c; }
-            else { if (Dm[(size_t)(r - 1) * W + c - 1] == cur) ++m; --r; --c; }
-            ++cols;
-        }
-        dist = Dm[(size_t)qlen * W + tlen];
+        dist = d;
         matches = m;
-        columns = cols;
+        columns = d + m;
     }
 };
 
@@ -153,7 +197,7 @@ extern "C" int sd_nw_identity_batch(const char* const* queries, const int32_t* q
                                     int32_t* matches, int32_t* columns) {
     if (n_pairs < 0 || !queries || !targets || !qlens || !tlens || !matches || !columns) return SD_ERR_PARAM;
     for (int64_t i = 0; i < n_pairs; ++i)
-        if (qlens[i] > 65000 || tlens[i] > 65000) return SD_ERR_UNSUPPORTED;
+        if (qlens[i] > SD_NW_HOST_MAX || tlens[i] > SD_NW_HOST_MAX) return SD_ERR_UNSUPPORTED;
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n_pairs));
     std::atomic<int64_t> next{0};
     auto work = [&]() {
@@ -199,10 +243,10 @@ extern "C" int sd_identity_segments(const char* seq, int64_t seqlen, const int64
         !matches || !columns)
         return SD_ERR_PARAM;
     for (int64_t s = 0; s < n_seg; ++s) {
-        if (starts[s] < 0 || ends[s] >= seqlen || ends[s] - starts[s] + 1 > 65000) return SD_ERR_PARAM;
+        if (starts[s] < 0 || ends[s] >= seqlen || ends[s] - starts[s] + 1 > SD_NW_HOST_MAX) return SD_ERR_PARAM;
     }
     for (int t = 0; t < T; ++t)
-        if (tlen[t] > 65000) return SD_ERR_UNSUPPORTED;
+        if (tlen[t] > SD_NW_HOST_MAX) return SD_ERR_UNSUPPORTED;
     if (pair_tmpl)
         for (int64_t s = 0; s < n_seg; ++s)
             if (pair_tmpl[s] < 0 || pair_tmpl[s] >= T) return SD_ERR_PARAM;

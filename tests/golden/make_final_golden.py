@@ -180,6 +180,18 @@ def main():
     synth.write_fasta(os.path.join(d, "monomers.fa"), mn, ms)
     emit(work, "syn64_second_best", os.path.join(d, "reads.fa"), os.path.join(d, "monomers.fa"), ["--second-best"],
          ["final/syn64_second_best/reads.fa", "final/syn64_second_best/monomers.fa"], keep_alt=True)
+    # blocks of 21 kb and 5 kb (N runs inside a monomer; -b 30000 keeps each read in one chunk): 20 * ceil(21171 / 64) *
+    # 171 bytes of traceback data pass 1 MB, so edlib aligns the long block by Hirschberg's split (edlib.cpp:1186)
+    d = os.path.join(OUT, "long_block")
+    os.makedirs(d, exist_ok=True)
+    st = synth.Stream(3, 14)
+    ms = [synth._ACGT[st.below(171, 4)].tobytes(), synth._ACGT[st.below(168, 4)].tobytes()]
+    rs = [ms[0] * 3 + ms[0][:100] + b"N" * 21000 + ms[0][100:] + ms[1] * 2,
+          ms[1] * 4 + ms[0][:60] + b"N" * 5000 + ms[0][60:] + ms[0]]
+    synth.write_fasta(os.path.join(d, "reads.fa"), ["long0", "mid1"], rs, width=80)
+    synth.write_fasta(os.path.join(d, "monomers.fa"), ["L0", "L1"], ms)
+    emit(work, "long_block", os.path.join(d, "reads.fa"), os.path.join(d, "monomers.fa"), ["--second-best", "-b", "30000"],
+         ["final/long_block/reads.fa", "final/long_block/monomers.fa"], keep_alt=True)
     shutil.rmtree(work, ignore_errors=True)
 
 

@@ -168,6 +168,71 @@ def test_nw_identity_matches_oracle_and_edlib(oracle):
             ed.edlibFreeAlignResult(r)
 
 
+def _edlib_nw(ed):
+    class Cfg(ctypes.Structure):
+        _fields_ = [("k", ctypes.c_int), ("mode", ctypes.c_int), ("task", ctypes.c_int),
+                    ("eq", ctypes.c_void_p), ("neq", ctypes.c_int)]
+
+    class Res(ctypes.Structure):
+        _fields_ = [("status", ctypes.c_int), ("editDistance", ctypes.c_int),
+                    ("endLocations", ctypes.POINTER(ctypes.c_int)),
+                    ("startLocations", ctypes.POINTER(ctypes.c_int)),
+                    ("numLocations", ctypes.c_int),
+                    ("alignment", ctypes.POINTER(ctypes.c_ubyte)),
+                    ("alignmentLength", ctypes.c_int), ("alphabetLength", ctypes.c_int)]
+
+    ed.edlibAlign.restype = Res
+    ed.edlibAlign.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, Cfg]
+    ed.edlibFreeAlignResult.argtypes = [Res]
+
+    def align(q, t):
+        r = ed.edlibAlign(q, len(q), t, len(t), Cfg(-1, 0, 2, None, 0))   # NW, path
+        a = np.ctypeslib.as_array(r.alignment, shape=(r.alignmentLength,))
+        out = (r.editDistance, int((a == 0).sum()), r.alignmentLength)
+        ed.edlibFreeAlignResult(r)
+        return out
+    return align
+
+
+def test_nw_identity_of_long_pairs_follows_edlibs_hirschberg_split(oracle):
+    """Once (2*8+4) * ceil(|query| / 64) * |target| + 8 * |target| reaches 1 MB edlib aligns by Hirschberg's split of the
+    target instead of its block traceback (edlib.cpp:1186-1400; ~19.6 kb against a 171-bp monomer, reachable with
+    -b >= 19000): the host identities (csrc/sd_post.hip) and the oracle restate both; checked against each other and,
+    where oracle/_ref holds it, against the reference's vendored edlib itself.  Also symbols outside ACGTN and a
+    100-kb query (the 65 000-bp limit of round 2 is gone)."""
+    st = synth.Stream(11, 3)
+
+    def rnd(n, k=4):
+        return synth._ACGT[st.below(n, k)].tobytes()
+    qs, ts = [], []
+    for trial in range(16):
+        tl = [171, 600, 2000, 90][trial % 4]
+        t = rnd(tl, 4 if trial % 5 else 2)
+        ql = [20000, 6000, 3000, 70000][trial % 4] + int(st.below(1, 3000)[0])
+        mode = (trial // 4) % 4
+        if mode == 0:
+            q = rnd(ql)
+        elif mode == 1:
+            codes = np.searchsorted(synth._ACGT, np.frombuffer(t * (ql // tl + 1), dtype=np.uint8))[:ql]
+            q = synth._to_ascii(synth.mutate(codes, st, 0.1, 0.05, 0.05))
+        elif mode == 2:
+            q = rnd(ql, 2)
+        else:
+            q = rnd(ql // 2) + t + rnd(ql // 2, 3)
+        assert 20 * ((len(q) + 63) // 64) * len(t) + 8 * len(t) >= 1 << 20
+        qs.append(q)
+        ts.append(t)
+    qs += [b"ACGTRYK" * 30, b"\x01\x02\x03ACGT" * 20, b"A" * 100000, b"N" * 21000 + b"ACGT"]
+    ts += [b"ACGTRRK" * 28, b"\x03\x02\x01TGCA" * 22, b"A" * 170 + b"C", rnd(171)]
+    got = lib.nw_identity_batch(qs, ts, threads=4)
+    for q, t, g in zip(qs[:8] + qs[16:], ts[:8] + ts[16:], got[:8] + got[16:]):
+        assert tuple(g) == tuple(oracle.nw_identity(q, t)), (len(q), len(t))
+    if os.path.isfile(oracle.REF_EDLIB):
+        align = _edlib_nw(ctypes.CDLL(oracle.REF_EDLIB))
+        for q, t, g in zip(qs, ts, got):
+            assert align(q, t) == tuple(g), (len(q), len(t))
+
+
 def test_final_tsv_postprocessing_reproduces_reference_golden(tmp_path):
     """The reference's own golden file (made with --second-best, reference Makefile:17-19)."""
     c = load_case("td_default")
@@ -452,12 +517,12 @@ def test_native_post_processing_vs_unmodified_reference_cli(name, tmp_path, orac
     the oracle must hash to the reference's raw file, and sd_convert_raw_tsv (host identities) must reproduce
     the final TSV byte for byte and the _alt TSV by sha256 (the whole 2.67 MB file for the test data)."""
     c = load_final_case(name)
-    raw = oracle.decompose_files(c["reads"], c["monomers"], threads=8)
+    a = c["args"]
+    raw = oracle.decompose_files(c["reads"], c["monomers"], threads=8, part=int(a[a.index("-b") + 1]) if "-b" in a else 5000)
     assert hashlib.sha256(raw).hexdigest() == c["raw_sha256"]
     rawf, fin, alt = str(tmp_path / "raw.tsv"), str(tmp_path / "f.tsv"), str(tmp_path / "f_alt.tsv")
     with open(rawf, "wb") as f:
         f.write(raw)
-    a = c["args"]
     mi = int(a[a.index("-i") + 1]) if "-i" in a else 0
     lib.convert_raw_tsv(rawf, c["reads"], c["monomers"], fin, alt, mi, "--second-best" in a, device=-1, threads=8)
     with open(fin, "rb") as f:
