@@ -282,8 +282,9 @@ void sd_fasta_free(sd_fasta* f);
  * What main.py:29-60 (edist + aai) obtains from python-edlib: unit-cost global alignment
  * (edlib mode "NW", task "path"), number of '=' columns and total CIGAR columns.  Traceback from
  * the bottom-right corner with priority up (consume query, 'I') > left (consume target, 'D') >
- * diagonal, i.e. edlib's obtainAlignmentTraceback (edlib.cpp:945-1150).  Exact for queries below
- * ~19 kb against ~200-bp targets (above that edlib switches to Hirschberg, edlib.cpp:1186-1190).
+ * diagonal, i.e. edlib's obtainAlignmentTraceback (edlib.cpp:945-1150); pairs whose traceback data would
+ * reach 1 MB (~19.6 kb against a 171-bp target) by Hirschberg's split of the target as edlib does
+ * (edlib.cpp:1186-1400).  Any byte alphabet (a symbol matches itself only), sequences of up to 2^27.
  * matches[i] = columns[i] = 0 and dist[i] = -1 if either sequence is empty (main.py:30-33).
  * Multi-threaded over pairs (threads >= 1). */
 int sd_nw_identity_batch(const char* const* queries, const int32_t* qlens,
@@ -304,7 +305,8 @@ int sd_identity_segments(const char* seq, int64_t seqlen, const int64_t* starts,
 /* The same on the device (csrc/sd_nw.hip: one lane per (segment, template) pair, Myers bit-vectors with
  * a per-lane delta history in HBM and edlib's traceback priority): identical results.  Returns
  * SD_ERR_NO_DEVICE without a GPU and SD_ERR_UNSUPPORTED for input the kernel does not take (a symbol
- * outside ACGTN, a template longer than 512 bp, a segment longer than 65000 bp) -- callers then use
+ * outside ACGTN, a template longer than 512 bp, a segment longer than 65000 bp, a pair long enough for
+ * edlib's Hirschberg split) -- callers then use
  * sd_identity_segments.  Device buffers are kept between calls (sd_nw_release_cache frees them). */
 int sd_identity_segments_dev(const char* seq, int64_t seqlen, const int64_t* starts, const int64_t* ends,
                              int64_t n_seg, const char* const* tmpl, const int32_t* tlen, int32_t T,
