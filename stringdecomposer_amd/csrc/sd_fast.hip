@@ -672,7 +672,7 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
         return;
     }
     // min_lds (pipeline mode 2): ask for at least this much, so that a third workgroup never fits a CU
-    const size_t lds = std::max((size_t)5 * plan.P4 * 64 * sizeof(uint32_t), min_lds);
+    const size_t lds = std::max((size_t)5 * plan.P4 * 64 * sizeof(uint32_t) + 128, min_lds);   // + FairShare's words
     const bool ranked = cendoff != nullptr;
 #define SD_FILL_K(PP, RK, HF)                                                                        \
     {                                                                                                \

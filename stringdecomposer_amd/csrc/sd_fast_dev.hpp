@@ -210,6 +210,46 @@ __device__ __forceinline__ void acc_put(int& acc, int value, int slot) {
 // own, so the tail of a launch is balanced per SIMD instead of per workgroup (C2 fill 18.3 ->
 // 17.7 ms).  `order` lists the chunks longest first.  (A static strided assignment was measured
 // slower: 19.3 ms -- SIMDs do not run at identical speed.)
+// Issue fairness among the waves of a SIMD.  The SIMD issues from its oldest ready wave first, so of four waves that
+// fill equal chunks side by side the oldest runs ahead and the youngest is left with a good part of its chunk when the
+// others are done -- alone on the SIMD it is latency bound (13 cycles per instruction against 4.1 shared), and every
+// launch ends with that tail (one chunk time x ~0.25).  Every 32 rows a wave publishes the rows it still
+// has to fill (one LDS word per wave of the workgroup) and takes the issue priority (s_setprio) of its rank among the
+// workgroup's waves on the same SIMD: most rows left = highest priority.
+struct FairShare {
+    int* prog;
+    int wave, lane;
+    unsigned long long mates;   // lanes m < nw whose wave m runs on this wave's SIMD (this wave excluded)
+    const int* queue;
+    int n_chunks;
+    __device__ __forceinline__ void init(int* area, int wave_, int nw, int lane_, const int* queue_, int n_chunks_) {
+        prog = area; wave = wave_; lane = lane_; queue = queue_; n_chunks = n_chunks_;
+        int* simd = area + 16;
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 4, 2)" : "=s"(hw));
+        if (lane == 0) { simd[wave] = (int)hw; prog[wave] = 0x7fffffff; }
+        __syncthreads();
+        const int sm = lane < nw ? simd[lane] : -1;
+        mates = __ballot(sm == (int)hw && lane != wave);
+    }
+    __device__ __forceinline__ void update(int remaining) {
+        if (lane == 0) __hip_atomic_store(prog + wave, remaining, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int v = __hip_atomic_load(prog + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // only while no wave can pull another chunk (the end of the launch): before that a wave that is done simply
+        // takes the next chunk and priorities would only serialise the SIMD's waves
+        const int head = __builtin_amdgcn_readfirstlane(__hip_atomic_load(queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (head < n_chunks) { __builtin_amdgcn_s_setprio(0); return; }
+        const int rank = __popcll(__ballot(v < remaining) & mates);   // mates with fewer rows left
+        if (rank == 0) __builtin_amdgcn_s_setprio(0);
+        else if (rank == 1) __builtin_amdgcn_s_setprio(1);
+        else if (rank == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    }
+    __device__ __forceinline__ void leave() {
+        if (lane == 0) __hip_atomic_store(prog + wave, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
 struct ChunkSched {
     int* queue;
     const int* order;

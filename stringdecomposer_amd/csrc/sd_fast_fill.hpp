@@ -58,6 +58,10 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
     const int nw = (int)(blockDim.x >> 6);
     const int lane = threadIdx.x & 63;
     (void)wave; (void)nw;
+    // Issue fairness among the waves of a SIMD (FairShare, sd_fast_dev.hpp): the rows a wave still has to fill, one
+    // word per wave behind the table
+    FairShare fair;
+    fair.init(reinterpret_cast<int*>(lds + TBL), wave, nw, lane, queue, n_chunks);
     ChunkSched sched;
     sched.init(queue, order, n_chunks);
     for (int c = sched.next(); c >= 0; c = sched.next()) {
@@ -224,6 +228,7 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
 
     for (int i = 1; i < n; ++i) {
         if ((i & (FAST_R - 1)) == 0) {
+            fair.update(n - i);
             if ((i & (FAST_REBASE - 1)) == 0) {
                 // rebase the int16 state on B_i and fold the row offset tp*ins back in
                 if constexpr (HRED)
@@ -335,6 +340,7 @@ __global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
         guard.finish(sc.guard_flag);
     }
     }  // chunk queue
+    fair.leave();
 }
 
 

@@ -22,7 +22,7 @@ void launch_fast_fill_wide(const FastPlan& plan, hipStream_t st, const ChunkDesc
                            const uint32_t* cendoff, const uint32_t* crank) {
     const int NW = 8;
     const int grid = std::min((n_chunks + NW - 1) / NW, n_cu);  // persistent: one workgroup per CU (LDS)
-    const size_t lds = (size_t)5 * (plan.P / 16) * 512 * sizeof(uint32_t);
+    const size_t lds = (size_t)5 * (plan.P / 16) * 512 * sizeof(uint32_t) + 128;   // + FairShare's words
     const bool ranked = cendoff != nullptr;
     if (!plan.full_floor &&
         launch_fast_fill_wide_fl(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt,

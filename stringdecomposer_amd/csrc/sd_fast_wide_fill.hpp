@@ -63,6 +63,8 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
         if constexpr (F16) return CO::add(u, cvt_bf8x2(tb, pair, 0x3f800000u));
         else return add_b8(u, tb, pair);
     };
+    FairShare fair;   // issue fairness among the waves of a SIMD at the end of the launch (sd_fast_dev.hpp)
+    fair.init(reinterpret_cast<int*>(lds + TBL), wave, nw, lane, queue, n_chunks);
     ChunkSched sched;
     sched.init(queue, order, n_chunks);
     for (int c = sched.next(); c >= 0; c = sched.next()) {
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
     load_group(0, 0, L[P - 1]);
     for (int i = 1; i < n; ++i) {
         if ((i & (FAST_R - 1)) == 0) {
+            fair.update(n - i);
             if ((i & (FAST_REBASE - 1)) == 0) {
                 const uint32_t d2 = CO::splat(Brel - tp * sc.ins);
                 base += Brel;
@@ -259,6 +262,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
         guard.finish(sc.guard_flag);
     }
     }  // chunk queue
+    fair.leave();
 }
 
 
