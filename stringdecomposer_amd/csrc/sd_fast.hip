@@ -653,11 +653,11 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
                       const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV,
                       uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order, int n_cu,
                       const uint32_t* cendoff, const uint32_t* crank, size_t min_lds) {
-    const int NW = SD_FILL_NW;
-    #ifndef SD_FILL_WPC
-#define SD_FILL_WPC 16   // resident fill waves per CU (4 per SIMD)
-#endif
-    int grid = std::min((n_chunks + NW - 1) / NW, (SD_FILL_WPC / NW) * n_cu);  // persistent
+    // 16 waves per CU either way (4 per SIMD): one workgroup of 16 when the launch fills the machine, else workgroups of 8
+    int nw = n_chunks >= SD_FILL_NW_MAX * n_cu ? SD_FILL_NW_MAX : 8;
+    if (const char* ev = getenv("SD_FILL_NW")) nw = atoi(ev) == 16 ? 16 : 8;   // developer knob
+    const int NW = nw;
+    int grid = std::min((n_chunks + NW - 1) / NW, (16 / NW) * n_cu);  // persistent
     if (const char* ev = getenv("SD_FILL_GRID")) grid = std::max(1, atoi(ev));   // developer knob
     // `queue` points at a zeroed work-queue head that no earlier launch has used (sd_engine hands out a fresh
     // one per run): no memset kernel sits between the launches of a stream
@@ -678,7 +678,7 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
     {                                                                                                \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, HF>),          \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-        hipLaunchKernelGGL((sd_fast_fill<PP, RK, HF>), dim3(grid), dim3(NW * 64), lds, st, chunks,    \
+        hipLaunchKernelGGL((sd_fast_fill<PP, RK, HF>), dim3(grid), dim3(nw * 64), lds, st, chunks,    \
                            n_chunks, bases2, nmask, table, lane_consts, sc, plan.H, B, argV, ckpt,   \
                            ckbase, queue, order, cendoff, crank);                                    \
     }
@@ -693,9 +693,9 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
     // fp16 cells, 150-200 bp monomers: the variants that skip the dominated start-term maxima (sd_fast_fl.hip);
     // FastPlan::full_floor (SD_FLAG_FULL_FLOOR) keeps the full kernel (developer A/B and the parity test of the two)
     if (!plan.full_floor &&
-        (plan.f16 ? launch_fast_fill_fl(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
+        (plan.f16 ? launch_fast_fill_fl(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
                                         argV, ckpt, ckbase, queue, order, cendoff, crank)
-                  : launch_fast_fill_fl_i16(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc,
+                  : launch_fast_fill_fl_i16(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc,
                                             B, argV, ckpt, ckbase, queue, order, cendoff, crank)))
         return;
     switch (plan.P) {

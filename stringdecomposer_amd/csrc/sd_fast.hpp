@@ -97,18 +97,18 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
                       const uint32_t* cendoff, const uint32_t* crank, size_t min_lds = 0);
 
 // variants with the start-term maximum in the first slots of a lane only (sd_fast_fl.hip); false = not covered
-bool launch_fast_fill_fl(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks,
+bool launch_fast_fill_fl(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
                          int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                          const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
                          int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
                          const uint32_t* crank);
 
-bool launch_fast_fill_fl_i16(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks,
+bool launch_fast_fill_fl_i16(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
                              int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                              const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
                              int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
                              const uint32_t* crank);
-bool launch_fast_fill_fl_long(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks,
+bool launch_fast_fill_fl_long(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
                               int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                               const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
                               int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,

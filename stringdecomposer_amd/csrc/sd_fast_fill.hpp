@@ -22,9 +22,10 @@ namespace sd {
 // rebase), so that the insertion move costs nothing:
 //   S_new[x] = max( max(S[x-1], B_i + del - tp*ins) + (mm - del - ins),  S[x],  S_new[x-1] )
 // i.e. 4 packed ops per cell pair: u = max(pd, KB); v = u + tbl; cand = max(v, old); run = max(run, cand).
-#ifndef SD_FILL_NW
-#define SD_FILL_NW 8   // waves (= chunks) per workgroup; two workgroups per CU
-#endif
+// waves (= chunks) per workgroup: 16 -- one workgroup per CU, so that FairShare sees all four waves of a SIMD -- when
+// the launch fills the machine, 8 -- two workgroups per CU, 2 waves per SIMD each -- for smaller launches, which then
+// spread over twice as many CUs (fill_block_waves)
+#define SD_FILL_NW_MAX 16
 //
 // F16 variant: the same recurrence on packed fp16 (every value is an integer of magnitude < 2048,
 // hence exact; -inf is the padding / "no predecessor" value).  gfx950 has v_pk_maximum3_f16, which
@@ -32,7 +33,7 @@ namespace sd {
 // -- 3 packed ops per cell pair instead of 4.  fast_plan_build() enables it when the score range
 // fits (FastPlan::f16); the checkpoints then hold fp16 pairs (the traceback converts them).
 template <int P, bool RANKED, bool F16, int FL = P>
-__global__ __launch_bounds__(SD_FILL_NW * 64, 4) void sd_fast_fill(
+__global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
     const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int H, int32_t* __restrict__ Bout,

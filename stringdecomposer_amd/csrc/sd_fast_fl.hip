@@ -16,14 +16,14 @@
 
 namespace sd {
 
-bool launch_fast_fill_fl(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks,
+bool launch_fast_fill_fl(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
                          int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                          const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
                          int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
                          const uint32_t* crank) {
     if (!plan.f16 || plan.wide || plan.P < 30 || plan.floor_slots < 1) return false;
     if (plan.P > 40)
-        return launch_fast_fill_fl_long(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
+        return launch_fast_fill_fl_long(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
                                         argV, ckpt, ckbase, queue, order, cendoff, crank);
     int fl = 0;
     for (int c : {12, 16, 20, 24, 28})
@@ -34,7 +34,7 @@ bool launch_fast_fill_fl(const FastPlan& plan, hipStream_t st, int grid, size_t 
     {                                                                                                \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, true, FF>),     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-        hipLaunchKernelGGL((sd_fast_fill<PP, RK, true, FF>), dim3(grid), dim3(SD_FILL_NW * 64), lds,  \
+        hipLaunchKernelGGL((sd_fast_fill<PP, RK, true, FF>), dim3(grid), dim3(nw * 64), lds,  \
                            st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, plan.H, B,   \
                            argV, ckpt, ckbase, queue, order, cendoff, crank);                        \
         return true;                                                                                 \

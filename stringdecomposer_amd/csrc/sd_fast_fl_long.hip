@@ -4,7 +4,7 @@
 
 namespace sd {
 
-bool launch_fast_fill_fl_long(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks,
+bool launch_fast_fill_fl_long(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
                               int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                               const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
                               int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
@@ -17,7 +17,7 @@ bool launch_fast_fill_fl_long(const FastPlan& plan, hipStream_t st, int grid, si
     {                                                                                                \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, true, FF>),     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-        hipLaunchKernelGGL((sd_fast_fill<PP, RK, true, FF>), dim3(grid), dim3(SD_FILL_NW * 64), lds,  \
+        hipLaunchKernelGGL((sd_fast_fill<PP, RK, true, FF>), dim3(grid), dim3(nw * 64), lds,  \
                            st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, plan.H, B,   \
                            argV, ckpt, ckbase, queue, order, cendoff, crank);                        \
         return true;                                                                                 \
