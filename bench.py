@@ -43,6 +43,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_CYC_PER_WAVE_INST = 4.1
 SHADER_CLOCK_HZ = 2.4e9
 N_SIMDS = 1024
+VALU_WALL_NS_PER_INST = 1.806   # measured wall time per wave-instruction per SIMD (cell mix, 4 waves per SIMD)
 VALU_PEAK_GINST = N_SIMDS * SHADER_CLOCK_HZ / VALU_CYC_PER_WAVE_INST / 1e9
 
 
@@ -532,6 +533,11 @@ def main():
         roofline = {"bound": "valu", "achieved": v_ach, "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s",
                     "frac": v_ach / VALU_PEAK_GINST,
                     "isolated_frac": None if v_iso is None else v_iso / VALU_PEAK_GINST}
+        # `peak` prices the 4.1 cycles at the 2.4-GHz peak clock; under this load the chip holds 2.27-2.33 GHz (the
+        # micro-benchmark's wall time per instruction, profiles/r03_ubench_issue.txt: 1.806 ns per SIMD for the fill's
+        # instruction mix at 4 waves per SIMD): what the machine delivered there, for reference
+        valu["wall_ceiling_ginst"] = N_SIMDS / VALU_WALL_NS_PER_INST
+        valu["isolated_frac_of_wall_ceiling"] = None if v_iso is None else v_iso / valu["wall_ceiling_ginst"]
     else:   # no instruction count for this workload / binary: only the notional figure
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
