@@ -207,7 +207,7 @@ def bench_c4_second_best(args):
                "host_ms_per_step": {k: acc[k] / K for k in ("pack_ms", "wait_ms", "raw_text_ms", "post_ms", "io_ms",
                                                             "text_identity_ms", "final_text_ms", "total_ms", "setup_ms", "assemble_ms")},
                "cpu_baseline": cpu}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_claimed_stdout(), flush=True)
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -293,9 +293,23 @@ def bench_strong(args):
            "note": "strong-scaling companion of the headline line (which is weak scaling on C2, roofline and cpu_baseline "
                    "there); time = MAX over ranks of the K steps"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_claimed_stdout(), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+_REAL_STDOUT = None
+
+
+def _claimed_stdout():
+    """The process's original stdout; everything else that writes to fd 1 (gloo / RCCL / runtime chatter) goes to stderr,
+    so that rank 0 prints exactly ONE line there."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _REAL_STDOUT
 
 
 def main():
@@ -349,6 +363,7 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+    _claimed_stdout()   # from here on only the result line goes to stdout
 
     if args.config == "c4-second-best":
         return bench_c4_second_best(args)
@@ -603,7 +618,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_claimed_stdout(), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
