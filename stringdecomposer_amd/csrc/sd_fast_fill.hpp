@@ -41,7 +41,7 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     int* __restrict__ queue, const int* __restrict__ order, const uint32_t* __restrict__ cendoff,
     const uint32_t* __restrict__ crank) {
     constexpr int P4 = (P + 3) & ~3;
-    extern __shared__ uint32_t lds[];  // [5][P4/4][64][4]
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [5][P4/4][64][4]
     constexpr int TBL = 5 * P4 * 64;
     using CO = CellOps<F16>;
     constexpr uint32_t NEGC = CO::NEG;
@@ -108,13 +108,18 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
 
     // `after` pins the LDS reads behind the value it names (the last slot of the row being
     // finished): hoisted above the slot loop they would need a second register set + 35 copies
+    // one LDS byte address per row (the lane's 16 bytes + the table of the read symbol): ONE VALU add; the slot groups
+    // are immediate offsets of ds_read_b128
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    using lds_u4 = __attribute__((address_space(3))) const u32x4_t;
+    const uint32_t lds_lane = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)lds + lane * 16;
     auto load_table = [&](int r, uint32_t& after) {
-        uint32_t off = (uint32_t)(r * (P4 * 64) + lane * 4);
-        asm volatile("" : "+v"(off), "+v"(after));
-        const uint32_t* t = lds + off;
+        uint32_t addr = lds_lane + (uint32_t)(r * (P4 * 256));
+        asm volatile("" : "+v"(addr), "+v"(after));
+        lds_u4* t = (lds_u4*)(uintptr_t)addr;
 #pragma unroll
         for (int c4 = 0; c4 < P4 / 4; ++c4) {
-            const uint4 q = *reinterpret_cast<const uint4*>(t + c4 * 256);
+            const u32x4_t q = t[c4 * 64];
             tb[4 * c4 + 0] = q.x; tb[4 * c4 + 1] = q.y; tb[4 * c4 + 2] = q.z; tb[4 * c4 + 3] = q.w;
         }
     };
