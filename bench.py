@@ -507,7 +507,8 @@ def main():
                 tj = json.load(f)
             # the C2 entry at the top level, further workloads (the 64-monomer wide kernel) under "other_workloads"
             for tj in [tj] + list(tj.get("other_workloads", [])):
-                same_kernel = (tj.get("kernel_family") == info["family"] and tj.get("cells", info["cells"]) == info["cells"] and
+                same_kernel = (tj.get("kernel_family") == info["family"] and
+                               tj.get("cells", info["cells"]).split("/")[0] == info["cells"].split("/")[0] and
                                tj.get("cells_per_lane", 35) == info["cells_per_lane"] and tj.get("sum_template_len", 4096) == sumL)
                 if same_kernel and tj.get("workload_rows") == rows and tj.get("hbm_bytes_per_launch"):
                     traffic = tj.get("hbm_bytes_per_launch")
