@@ -2388,8 +2388,8 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     if (second_best && rc == SD_OK) {
         const size_t nc = job.table.size();
         min_batches = nc >= 2048 ? 4 : nc >= 1024 ? 2 : 1;   // C4 shape, 2 560 chunks: 170 / 159 / 149 / 140 / 134+ ms for 1 / 2 / 3 / 4 / 5+
-        if (const char* ev = getenv("SD_MIN_BATCHES")) min_batches = std::max(1, atoi(ev));   // developer A/B
     }
+    if (const char* ev = getenv("SD_MIN_BATCHES")) min_batches = std::max(1, atoi(ev));   // developer A/B
     if (rc == SD_OK) plan_batches(job.table, 0, job.table.size(), pipe.row_budget(), min_batches, batches);
     lap("chunk table, engine");
     const double t_setup = now_s() - t_begin;
