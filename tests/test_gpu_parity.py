@@ -881,6 +881,29 @@ def test_in_stream_identities_equal_the_text_based_path_across_batches(tmp_path,
 
 
 @pytest.mark.gpu
+def test_second_best_job_is_cut_into_device_batches_with_the_same_files(tmp_path, monkeypatch):
+    """A --second-best job that fits one device batch is cut in up to four, so that the text of a part is written while
+    the next part is on the device (run_files_impl); the three files do not depend on the cut."""
+    mn, ms = synth.make_monomers(12, seed=3)
+    rn, rs = synth.make_reads(ms, 230, read_len=50000, seed=4)
+    rs[5] = rs[5][:20000] + b"N" * 30 + rs[5][20030:]
+    rfa, mfa = str(tmp_path / "r.fa"), str(tmp_path / "m.fa")
+    synth.write_fasta(rfa, rn, rs, width=80)
+    synth.write_fasta(mfa, mn, ms)
+    outs = {}
+    for tag, mb in (("default", None), ("one", "1"), ("seven", "7")):
+        if mb is None:
+            monkeypatch.delenv("SD_MIN_BATCHES", raising=False)
+        else:
+            monkeypatch.setenv("SD_MIN_BATCHES", mb)
+        o = [str(tmp_path / ("%s_%s.tsv" % (tag, x))) for x in ("raw", "final", "alt")]
+        lib.run_files(rfa, mfa, o[0], o[1], o[2], second_best=True, threads=8)
+        assert lib.last_run_stats()["batches"] == {"default": 4, "one": 1, "seven": 7}[tag]
+        outs[tag] = [hashlib.sha256(open(x, "rb").read()).hexdigest() for x in o]
+    assert outs["default"] == outs["one"] == outs["seven"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mlen", [20, 3])
 def test_in_stream_identities_fall_back_when_a_batch_has_too_many_records(tmp_path, mlen):
     """A batch with more records than the identity outputs have room for (one per 48 rows: 20-bp monomers give one per
