@@ -32,6 +32,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import stringdecomposer_amd  # noqa: E402
+
+# this process is the benchmark's own: the runtime's queue-thread mode (see the function), chosen before any HIP call;
+# the effective value is part of the result line ("amd_direct_dispatch")
+AMD_DIRECT_DISPATCH = stringdecomposer_amd.prefer_queue_thread_dispatch()
+
 from stringdecomposer_amd import lib, shard, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -333,6 +339,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--kernel", choices=["auto", "generic", "fast"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-port-baseline", action="store_true",
+                    help="accept the C restatement (kind \"port\") as cpu_baseline when oracle/_ref/dp is absent; by default "
+                         "the run then exits 3 after printing its line")
     ap.add_argument("--cpu-sample-reads", type=int, default=200,
                     help="reads of the benchmark set the reference CPU path is timed on and compared with (200 x 50 kb = 10 Mbp: "
                          "~25 s of `dp -t 8`)")
@@ -489,6 +498,28 @@ def main():
     einfo = eng.info()
     eng.close()
 
+    # ---- the same launch with INTEGER cells (SD_FLAG_NO_F16): the figure at the reading "no narrower than the
+    # reference's arithmetic wants int16" beside the headline's exact-integer fp16 cells (roofline.int16_cells) ----
+    int16_leg = None
+    if ws == 1 and not args.timed_only and info["cells"].split("/")[0] == "f16" and args.ed_thr < 0:
+        e16 = lib.Engine(ms, device=local_rank, kernel=kernel, threads=threads, flags=lib.FLAG_NO_F16)
+        e16.load_reads(rs)
+        i16 = e16.info()
+        n16 = max(2, min(res_steps, 5))
+        e16.run(tstream)
+        rows16 = e16.total_rows()
+        f16ms = t16ms = 0.0
+        for _ in range(n16):
+            e16.run(tstream)
+            e16.total_rows()
+            tm = e16.timings()
+            f16ms += tm["fill_ms"]
+            t16ms += tm["trace_ms"]
+        torch.cuda.synchronize()
+        int16_leg = {"cells": i16["cells"], "fill_ms": f16ms / n16, "traceback_ms": t16ms / n16, "steps": n16,
+                     "rows_out": rows16, "launched": "alone, batch resident in HBM (as isolated_*)"}
+        e16.close()
+
     # ---- roofline of the dominant kernel (fill) over the timed region, rank 0 ---------------------
     sumL, rows = info["sum_template_len"], einfo["rows"]
     alg_bytes = rows * (sumL / 4.0 + 6.25) + 24.0 * rows_out       # SURVEY.md 8(d), per step
@@ -570,6 +601,11 @@ def main():
                             "SIMD on gfx950 (measured), the fill is %s of them per row" % (
                                 "%.0f" % valu["insts_per_row"] if valu else "116 (C2) / 584 (128 templates)"),
         "cells_per_s": rows * sumL * K / launches / fill_s if fill_s > 0 else 0.0})
+    if int16_leg is not None:
+        # same algorithmic bytes per launch, the integer-cell kernel's duration launched alone
+        int16_leg["hbm_notional_frac"] = alg_bytes / max(einfo["fill_launches"], 1) / (int16_leg["fill_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS
+        int16_leg["same_rows_as_headline"] = bool(int16_leg.pop("rows_out") == rows_out)
+        roofline["int16_cells"] = int16_leg
 
     out = {
         "metric": "decomposed read-bp/sec (whole node) at 12 monomers x 50kb reads",
@@ -605,6 +641,9 @@ def main():
                              "note": "wall ms of the host stages of one step; process_cpu_ms = CPU time of all host "
                                      "threads of this rank per step (user + system)"},
         "other_pipe_mode": other,
+        "amd_direct_dispatch": AMD_DIRECT_DISPATCH,
+        # batches repeated with integer cells because the fp16 range guard tripped: must be 0 (checked below)
+        "f16_guard_trips": lib.guard_trips(),
         "rows_out_per_gpu": rows_out, "hbm_workspace_bytes": einfo["workspace_bytes"],
         # kernels only, batch packed and resident in HBM before the clock starts, one launch per kernel
         "device_resident": None if not res_steps else {
@@ -618,10 +657,31 @@ def main():
         out["cpu_baseline"] = cpu_baseline(mn, ms, rn[:k], rs[:k], txt)
     elif rank == 0:
         out["cpu_baseline"] = None
+    # The line is only a result if the fp16 guard never tripped, and -- where a CPU baseline was asked for -- if that
+    # baseline is the REAL reference binary and its rows equal the HIP path's on the sample: otherwise the line is
+    # still printed (with "invalid") and the process exits non-zero.
+    problems = []
+    if out["f16_guard_trips"] != 0:
+        problems.append("fp16 range guard tripped %d time(s)" % out["f16_guard_trips"])
+    cb = out.get("cpu_baseline")
+    if cb is not None and not args.allow_port_baseline:
+        if cb["kind"] != "reference":
+            problems.append("cpu_baseline.kind is %r (oracle/_ref/dp missing): not the reference binary" % cb["kind"])
+        if not cb["parity_on_sample"]:
+            problems.append("rows of the HIP path differ from the CPU baseline's on the sample")
+    elif cb is not None and not cb["parity_on_sample"]:
+        problems.append("rows of the HIP path differ from the CPU baseline's on the sample")
+    if int16_leg is not None and not int16_leg["same_rows_as_headline"]:
+        problems.append("integer-cell run produced a different number of rows")
+    if problems:
+        out["invalid"] = problems
     if rank == 0:
         print(json.dumps(out), file=_claimed_stdout(), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if problems:
+        print("bench.py: INVALID RESULT: " + "; ".join(problems), file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -261,6 +261,12 @@ int sd_format_rows(const char* read_name, const char* const* tmpl_names, const s
  * = 0..3, N = 0 + a set bit in the optional 1-bit mask); returns 1 if the chunk holds an N, -1 on bad
  * arguments.  words: (n+15)/16 dwords, nmask (may be NULL): (n+31)/32 dwords. */
 int32_t sd_pack_bases(const char* seq, int64_t n, uint32_t* words, uint32_t* nmask);
+/* Self-test of the file writer behind sd_run_files (no device): n_parts parts of part_bytes bytes appended to
+ * `path` in two calls, read back and compared.  fail_reserve != 0 makes the page reservation of the mapped
+ * (tmpfs) path fail, as on a full /dev/shm -- the text must then arrive through the pwritev loop, which reports
+ * ENOSPC as SD_ERR_IO instead of dying of SIGBUS.  out (may be NULL): [0] bytes written, [1] 1 on tmpfs / ramfs. */
+int sd_write_parts_selftest(const char* path, int32_t n_parts, int64_t part_bytes, int32_t threads,
+                            int32_t fail_reserve, int64_t out[2]);
 /* Rates of the host stages alone (no device): out[0] = chunk table + 2-bit packing, bp/s; out[1] = per-read
  * assembly (chunk offsets, seam merge) + raw TSV text of one synthetic record per 171 bases, bp/s; out[2] =
  * TSV rows/s; out[3] = bytes of text per pass.  p->threads host threads, `iters` passes over the reads. */

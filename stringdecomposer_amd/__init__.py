@@ -1,11 +1,27 @@
 """stringdecomposer_amd -- MI355X-native StringDecomposer read x monomer DP hot path."""
 import os as _os
-
-# The HIP runtime's "direct dispatch" mode runs a helper thread per process that stays busy while kernels are in
-# flight: 12.5 ms of CPU per 16.4-ms pipelined C2 step, measured (tools/helper_thread_ab.sh, profiles/r03_helper_thread.txt)
-# -- two thirds of everything a rank asks of the host.  With the runtime's queue-thread mode the same step costs 12 ms of
-# CPU instead of 17 at the same step time, which is what lets 8 ranks fit the 16-CPU quota of a GPU box.  The runtime
-# reads the variable when it initialises, so it is set here, at import, and only if the caller has not chosen.
-_os.environ.setdefault("AMD_DIRECT_DISPATCH", "0")
+import sys as _sys
 
 __version__ = "0.1.0"
+
+
+def prefer_queue_thread_dispatch():
+    """Opt-in process setting for the entry points that OWN their process (bin/stringdecomposer, bench.py, tools/):
+    AMD_DIRECT_DISPATCH=0 unless the caller has chosen.
+
+    The HIP runtime's "direct dispatch" mode runs a helper thread per process that stays busy while kernels are in
+    flight: 12.5 ms of CPU per 16.4-ms pipelined C2 step, measured (tools/helper_thread_ab.sh,
+    profiles/r03_helper_thread.txt) -- two thirds of everything a rank asks of the host.  With the runtime's
+    queue-thread mode the same step costs 12 ms of CPU instead of 17 at the same step time, which is what lets 8 ranks
+    fit the 16-CPU quota of a GPU box.  The runtime reads the variable when it initialises, so this must run before
+    the first HIP call of the process; importing the package does NOT change the environment (a library must not
+    reconfigure the runtime of torch / RCCL users that merely import it).  Returns the effective value; warns when a
+    HIP runtime is already loaded and the variable was not set (then it may be too late)."""
+    if "AMD_DIRECT_DISPATCH" not in _os.environ:
+        late = any(m in _sys.modules for m in ("torch",)) and getattr(_sys.modules.get("torch"), "cuda", None) is not None \
+            and _sys.modules["torch"].cuda.is_initialized()
+        if late:
+            import warnings
+            warnings.warn("AMD_DIRECT_DISPATCH chosen after the HIP runtime initialised: it may have no effect")
+        _os.environ["AMD_DIRECT_DISPATCH"] = "0"
+    return _os.environ["AMD_DIRECT_DISPATCH"]

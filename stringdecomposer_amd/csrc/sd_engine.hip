@@ -797,8 +797,9 @@ static void engine_alloc_batch(sd_engine* e, int64_t nck) {
             e->d_dist.alloc(C * (size_t)e->T);
             e->d_cendoff.alloc(C * 64 * (size_t)e->fplan.waves);
             e->d_crank.alloc(C * 64 * (size_t)e->fplan.waves);
-            const char* ck = getenv("SD_EDTHR_COMPACT");   // "0": every chunk on the W-wave ranked kernel (A/B, tests)
-            e->compact_edthr = e->fplan.wide && e->fplan.waves > 1 && !(ck && ck[0] == '0');
+            // SD_FLAG_NO_EDTHR_COMPACT (SD_EDTHR_COMPACT=0 arrives as that flag through apply_env_overrides):
+            // every chunk on the W-wave ranked kernel (A/B, tests)
+            e->compact_edthr = e->fplan.wide && e->fplan.waves > 1 && !(e->p.reserved[1] & SD_FLAG_NO_EDTHR_COMPACT);
             if (e->compact_edthr) {
                 e->d_klist.alloc(C * (size_t)e->T + 2);
                 e->d_kpos.alloc(C * (size_t)e->T);
@@ -1123,6 +1124,7 @@ static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errle
                 if (e->h_ident_bytes < nb) {
                     g_pinpool.give(e->h_ident, e->h_ident_bytes);
                     e->h_ident = nullptr;
+                    e->h_ident_bytes = 0;   // take() may throw: no stale size beside a null pointer
                     e->h_ident = static_cast<uint32_t*>(g_pinpool.take(nb, e->h_ident_bytes));
                 }
                 SD_HIP(hipMemcpyAsync(e->h_ident, e->d_ident.p, nb, hipMemcpyDeviceToHost, cs));
@@ -1130,6 +1132,7 @@ static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errle
                     if (e->h_identh_bytes < nb) {
                         g_pinpool.give(e->h_identh, e->h_identh_bytes);
                         e->h_identh = nullptr;
+                        e->h_identh_bytes = 0;
                         e->h_identh = static_cast<uint32_t*>(g_pinpool.take(nb, e->h_identh_bytes));
                     }
                     SD_HIP(hipMemcpyAsync(e->h_identh, e->d_identh.p, nb, hipMemcpyDeviceToHost, cs));
@@ -2242,6 +2245,41 @@ int32_t sd_pack_bases(const char* seq, int64_t n, uint32_t* words, uint32_t* nma
             if (seq[i] == 'N') nmask[i >> 5] |= 1u << (i & 31);
     }
     return hn ? 1 : 0;
+}
+
+// sd::write_parts alone (how sd_run_files puts a batch's text into its files): `n_parts` parts of `part_bytes`
+// bytes appended to `path` twice (two calls, the second at the first's end offset), then read back and compared.
+// fail_reserve != 0 makes the page reservation of the mapped (tmpfs) path fail, as on a full /dev/shm: the text
+// must then arrive through the pwritev loop.  out (may be null): [0] bytes written, [1] 1 if the file system is tmpfs / ramfs.
+int sd_write_parts_selftest(const char* path, int32_t n_parts, int64_t part_bytes, int32_t threads, int32_t fail_reserve,
+                            int64_t out[2]) {
+    if (!path || n_parts < 1 || part_bytes < 0 || threads < 1) return SD_ERR_PARAM;
+    std::vector<std::string> parts((size_t)n_parts);
+    for (int32_t i = 0; i < n_parts; ++i) {
+        parts[(size_t)i].resize((size_t)part_bytes);
+        for (int64_t b = 0; b < part_bytes; ++b) parts[(size_t)i][(size_t)b] = (char)('a' + (i * 7 + b * 13) % 26);
+    }
+    const int fd = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return SD_ERR_IO;
+    sd::write_parts_hook().store(fail_reserve ? 1 : 0);
+    int64_t off = 0;
+    bool ok = sd::write_parts(fd, off, parts, threads) && sd::write_parts(fd, off, parts, threads);
+    sd::write_parts_hook().store(0);
+    struct statfs fs;
+    const bool ram = ::fstatfs(fd, &fs) == 0 && ((unsigned long)fs.f_type == 0x01021994ul || (unsigned long)fs.f_type == 0x858458f6ul);
+    struct stat st;
+    ok = ok && ::fstat(fd, &st) == 0 && (int64_t)st.st_size == off && off == 2 * (int64_t)n_parts * part_bytes;
+    if (ok) {
+        std::string back((size_t)part_bytes, '\0');
+        for (int rep = 0; rep < 2 && ok; ++rep)
+            for (int32_t i = 0; i < n_parts && ok; ++i) {
+                const int64_t at = ((int64_t)rep * n_parts + i) * part_bytes;
+                ok = ::pread(fd, &back[0], (size_t)part_bytes, (off_t)at) == (ssize_t)part_bytes && back == parts[(size_t)i];
+            }
+    }
+    ::close(fd);
+    if (out) { out[0] = off; out[1] = ram ? 1 : 0; }
+    return ok ? SD_OK : SD_ERR_IO;
 }
 
 // -------------------------------------------------------------------------------------------

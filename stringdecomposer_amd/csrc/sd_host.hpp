@@ -360,6 +360,13 @@ inline void gather_text(const std::vector<Part>& parts, int threads, TextBuf& ou
     });
 }
 
+// test hook of write_parts: a non-zero value makes the page reservation of the mapped path "fail"
+inline std::atomic<int>& write_parts_hook() {
+    static std::atomic<int> h{0};
+    return h;
+}
+inline bool write_parts_fallocate_ok() { return write_parts_hook().load(std::memory_order_relaxed) == 0; }
+
 // parts -> the file `fd` at `off` (advanced by the total).  The cost of a TSV write is the copy into the page cache
 // (300 MB of _alt rows per --second-best batch).  On tmpfs, where write(2) serialises on the inode and a page fault is
 // cheap, large texts are copied by all threads through a shared mapping of the file's new range (65 instead of 88 ms per
@@ -374,10 +381,14 @@ inline bool write_parts(int fd, int64_t& off, const std::vector<Part>& parts, in
     struct statfs fs;
     const bool ram = ::fstatfs(fd, &fs) == 0 && ((unsigned long)fs.f_type == 0x01021994ul /* tmpfs */ ||
                                                  (unsigned long)fs.f_type == 0x858458f6ul /* ramfs */);
-    if (ram && total >= (4 << 20) && ::ftruncate(fd, (off_t)(off + total)) == 0) {
+    // The mapped copy is taken only when fallocate has really reserved the pages of the new range: a store into a
+    // sparse tmpfs mapping that the file system cannot back (full or small /dev/shm) raises SIGBUS and kills the
+    // process, where the pwritev loop below reports the same condition as a short write (-> SD_ERR_IO).
+    // sd_write_parts_test_hook() != 0 makes fallocate "fail" (CPU test of the fall-back).
+    if (ram && total >= (4 << 20) && write_parts_fallocate_ok() &&
+        ::fallocate(fd, 0, (off_t)off, (off_t)total) == 0) {
         // pages allocated in one call: the copies below then take minor faults only (300 MB on the GPU box: 52-63 ms
         // against 83-104 ms with every page allocated by the fault of a copying thread; tools/scratch/tmpfs_write.cpp)
-        (void)::fallocate(fd, 0, (off_t)off, (off_t)total);
         const long pg = ::sysconf(_SC_PAGESIZE);
         const int64_t m0 = off / pg * pg;
         void* mp = ::mmap(nullptr, (size_t)(off + total - m0), PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)m0);

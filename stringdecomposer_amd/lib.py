@@ -34,7 +34,7 @@ EXPORTS = [
     "sd_stream_create", "sd_stream_destroy", "sd_stream_submit", "sd_stream_collect", "sd_stream_stats",
     "sd_stream_info", "sd_pack_bases", "sd_identity_segments_dev", "sd_nw_release_cache", "sd_last_run_stats", "sd_guard_trips",
     "sd_run_files", "sd_convert_raw_tsv", "sd_decompose_files_range", "sd_assemble_files_tsv",
-    "sd_host_stage_rates", "sd_run_files_range", "sd_plan_info",
+    "sd_host_stage_rates", "sd_run_files_range", "sd_plan_info", "sd_write_parts_selftest",
 ]
 
 
@@ -498,6 +498,18 @@ def host_stage_rates(reads, iters=3, **kw):
     if rc != SD_OK:
         raise SdError(rc, "sd_host_stage_rates")
     return {"pack_bp_per_s": out[0], "assemble_format_bp_per_s": out[1], "rows_per_s": out[2], "text_bytes": out[3]}
+
+
+def write_parts_selftest(path, n_parts, part_bytes, threads=4, fail_reserve=False):
+    """sd::write_parts alone (the file writer of sd_run_files); returns (bytes written, on tmpfs)."""
+    L = load()
+    L.sd_write_parts_selftest.restype = C.c_int
+    L.sd_write_parts_selftest.argtypes = [C.c_char_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
+    out = (C.c_int64 * 2)()
+    rc = L.sd_write_parts_selftest(_b(path), n_parts, part_bytes, threads, 1 if fail_reserve else 0, out)
+    if rc != SD_OK:
+        raise SdError(rc, "sd_write_parts_selftest")
+    return int(out[0]), bool(out[1])
 
 
 def pack_bases(seq):

@@ -183,7 +183,7 @@ def decompose_files_sharded(reads_fa, monomers_fa, raw_tsv_out, dist, range_fn=N
     failure, res = None, None
     try:
         res = fn(reads_fa, monomers_fa, rank, ws, **params)
-    except BaseException as e:   # ANY failure is exchanged: a rank that left the collective sequence would hang the others
+    except Exception as e:   # ANY failure is exchanged: a rank that left the collective sequence would hang the others
         failure = _status_of(e)
     _raise_first(dist, ws, failure)
     recs, off, lo, hi, n_chunks = res
@@ -202,7 +202,7 @@ def decompose_files_sharded(reads_fa, monomers_fa, raw_tsv_out, dist, range_fn=N
             assert len(all_off) == n_chunks + 1
             keep = {k: v for k, v in params.items() if k in ("scoring", "part_size", "overlap", "threads")}
             lib.assemble_files_tsv(reads_fa, monomers_fa, all_recs, all_off, raw_tsv_out, **keep)
-        except BaseException as e:
+        except Exception as e:
             failure = _status_of(e)
     _raise_first(dist, ws, failure)   # rank 0's assembly failing is everybody's failure too
     return True if rank == 0 else None
@@ -272,7 +272,7 @@ def run_files_sharded(reads_fa, monomers_fa, raw_out, final_out, alt_out, dist, 
     try:
         try:
             fn(reads_fa, monomers_fa, rank, ws, *parts, **params)
-        except BaseException as e:   # not only SdError: a rank that raised past the exchange would leave the others waiting
+        except Exception as e:   # not only SdError: a rank that raised past the exchange would leave the others waiting
             failure = _status_of(e)
         status = [None] * ws
         dist.all_gather_object(status, failure)
@@ -285,7 +285,7 @@ def run_files_sharded(reads_fa, monomers_fa, raw_out, final_out, alt_out, dist, 
         sizes, failure = [None] * ws, None
         try:
             mine = [os.path.getsize(p) for p in parts]
-        except BaseException as e:
+        except Exception as e:
             mine, failure = None, _status_of(e)
         dist.all_gather_object(sizes, mine)
         if failure is None and rank == 0 and all(sz is not None for sz in sizes):
@@ -293,13 +293,13 @@ def run_files_sharded(reads_fa, monomers_fa, raw_out, final_out, alt_out, dist, 
                 for k, p in enumerate(outs):
                     with open(p, "wb") as f:
                         f.truncate(sum(sz[k] for sz in sizes))
-            except BaseException as e:
+            except Exception as e:
                 failure = _status_of(e)
         _raise_first(dist, ws, failure)     # also the barrier in front of the copies
         try:
             for k, p in enumerate(outs):
                 _copy_into(parts[k], p, sum(sz[k] for sz in sizes[:rank]))
-        except BaseException as e:
+        except Exception as e:
             failure = _status_of(e)
         _raise_first(dist, ws, failure)
         return True

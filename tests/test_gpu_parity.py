@@ -734,11 +734,7 @@ def test_ed_thr_compacts_large_template_sets(oracle, thr, nm):
     kw = dict(part_size=700, overlap=100, ed_thr=thr)
     exp = oracle.decompose(rn, rs, mn, ms, threads=8, part=700, overlap=100, ed_thr=thr)
     got = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, **kw)
-    os.environ["SD_EDTHR_COMPACT"] = "0"
-    try:
-        full = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, **kw)
-    finally:
-        del os.environ["SD_EDTHR_COMPACT"]
+    full = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, flags=lib.FLAG_NO_EDTHR_COMPACT, **kw)
     assert full == exp
     assert got == exp
 

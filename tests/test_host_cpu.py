@@ -671,3 +671,32 @@ def test_plan_range_bound_covers_the_recurrence(sc):
                  synth._to_ascii(st.below(300, 4)), (ms[0][: len(ms[0]) // 2] * 60)[:300]]
         for rd in reads:
             assert _stored_extrema(tm, rd, sc) <= info["range_bound"], (sc, trial, info)
+
+
+@pytest.mark.parametrize("fail_reserve", [False, True])
+def test_file_writer_on_tmpfs_with_and_without_page_reservation(fail_reserve, tmp_path):
+    """sd::write_parts (the TSV writer of sd_run_files): on tmpfs large texts go through a shared mapping, but only
+    after fallocate has reserved the pages -- when that fails (a full /dev/shm) the text must take the pwritev
+    loop (which reports ENOSPC as SD_ERR_IO) instead of a store into a sparse mapping (SIGBUS).  Both ways give
+    the same bytes; a disk directory always takes pwritev."""
+    shm = "/dev/shm"
+    dirs = [str(tmp_path)]
+    if os.path.isdir(shm) and os.access(shm, os.W_OK):
+        free = os.statvfs(shm).f_bavail * os.statvfs(shm).f_frsize
+        if free > (64 << 20):
+            dirs.append(shm)
+    for d in dirs:
+        path = os.path.join(d, "sd_wp_selftest_%d_%d.bin" % (os.getpid(), int(fail_reserve)))
+        try:
+            # 2 x 12 parts x 512 KiB = 12 MiB: above the 4-MiB threshold of the mapped path
+            n, ram = lib.write_parts_selftest(path, 12, 512 << 10, threads=4, fail_reserve=fail_reserve)
+            assert n == 2 * 12 * (512 << 10)
+            assert os.path.getsize(path) == n
+            if d == shm:
+                assert ram
+            # small texts (below the threshold) and empty parts
+            n2, _ = lib.write_parts_selftest(path, 3, 0, threads=2, fail_reserve=fail_reserve)
+            assert n2 == 0 and os.path.getsize(path) == 0
+        finally:
+            if os.path.exists(path):
+                os.unlink(path)

@@ -1,6 +1,7 @@
 import os, sys, time
 sys.path.insert(0, os.getcwd())
-import stringdecomposer_amd  # sets AMD_DIRECT_DISPATCH=0 unless chosen
+import stringdecomposer_amd
+stringdecomposer_amd.prefer_queue_thread_dispatch()  # AMD_DIRECT_DISPATCH=0 unless chosen
 print("AMD_DIRECT_DISPATCH =", os.environ.get("AMD_DIRECT_DISPATCH"))
 os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
 import torch, torch.distributed as dist
