@@ -496,6 +496,7 @@ def main():
     torch.cuda.synchronize()
     dtr = time.perf_counter() - tr0
     einfo = eng.info()
+    res_recs = eng.total_rows() if res_steps else None   # records of the resident batch (before the per-read seam merge)
     eng.close()
 
     # ---- the same launch with INTEGER cells (SD_FLAG_NO_F16): the figure at the reading "no narrower than the
@@ -604,7 +605,7 @@ def main():
     if int16_leg is not None:
         # same algorithmic bytes per launch, the integer-cell kernel's duration launched alone
         int16_leg["hbm_notional_frac"] = alg_bytes / max(einfo["fill_launches"], 1) / (int16_leg["fill_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS
-        int16_leg["same_rows_as_headline"] = bool(int16_leg.pop("rows_out") == rows_out)
+        int16_leg["same_rows_as_headline"] = bool(int16_leg.pop("rows_out") == res_recs)   # records of the same resident batch
         roofline["int16_cells"] = int16_leg
 
     out = {

@@ -58,6 +58,7 @@ typedef struct sd_params {
 #define SD_FLAG_NO_EDTHR_COMPACT 4 /* --ed_thr with > 128 templates: every chunk on the W-wave ranked kernel        */
 #define SD_FLAG_FILTER_GENERAL 8   /* --ed_thr: the general prefilter kernel instead of the uniform one             */
 #define SD_FLAG_NO_STREAM_IDENT 16 /* sd_run_files: identities from the read text in the post-processing (round 2)  */
+#define SD_FLAG_TRACE_V1 64        /* the one-block int32 traceback (sd_fast_trace) where the packed two-block form would run */
 #define SD_FLAG_PROGRESS 32        /* sd_run_files: the reference binary's progress lines on stderr ("Scores: ...",
                                       "Prepared reads", "<p>%: Aligned <read>", main.cpp:82,115,393); the command line sets it */
 
@@ -206,7 +207,9 @@ int sd_engine_timings(sd_engine* e, float ms[4]);
  *      4 wide: fp16 cells / bf8 table, 5 multi-wave wide: fp16 cells / template codes in LDS, > 128 templates)
  * [5] generic: cells-per-thread parameter Q; fast: slots per lane P in bits 0..15, bits 16..: the last slot
  *     of a lane whose diagonal input needs the maximum with the start term (0 = every slot takes it)
- * [6] bytes of HBM workspace allocated [7] number of fill launches per run */
+ * [6] bytes of HBM workspace allocated [7] bits 0..15: number of fill launches per run; bits 16..: traceback of the
+ *     fast family: 1 = one block per step, int32 cells (sd_fast_trace), 2 = two blocks per step, packed 16-bit cells
+ *     (sd_fast_trace_pk; narrow layouts with templates <= 248 bp unless SD_FLAG_TRACE_V1) */
 int sd_engine_info(sd_engine* e, int64_t info[8]);
 
 /* Host only (no device needed): the layout sd_engine_create would choose for this monomer set and scoring.

@@ -244,6 +244,7 @@ struct sd_engine {
     DevBuf<uint32_t> d_flane;        // per-lane constants
     DevBuf<uint32_t> d_fslot;        // (wave, slot, virtual lane) of template cell (j,k) in the lane layout
     DevBuf<uint8_t> d_ftcodes;       // base code of template cell (j,k)
+    DevBuf<uint32_t> d_ftr2;         // tables of the packed two-block traceback (FastPlan::tr2_tab)
     DevBuf<uint32_t> d_fckpt;        // checkpoints
     DevBuf<int32_t> d_fckbase;       // per-checkpoint rebase values
     // --ed_thr prefilter (fast family only)
@@ -354,7 +355,7 @@ void ensure_events(std::vector<hipEvent_t>& v, size_t pairs) {
 
 // Developer overrides of sd_params.reserved[] from the environment, read HERE and nowhere else (the switches are part
 // of the parameters; the variables exist so that a test or an A/B run can flip one without touching the caller):
-// SD_PIPE_MODE=0|1|2, SD_FILL_CELLS=i16, SD_FILL_FULLFLOOR=1, SD_EDTHR_COMPACT=0, SD_FILTER_GENERAL=1, SD_IDENT_STREAM=0,
+// SD_PIPE_MODE=0|1|2, SD_FILL_CELLS=i16, SD_FILL_FULLFLOOR=1, SD_EDTHR_COMPACT=0, SD_FILTER_GENERAL=1, SD_IDENT_STREAM=0, SD_TRACE=1,
 // SD_F16_GUARD=<limit>.
 void apply_env_overrides(sd_params& p) {
     if (p.reserved[0] == 0)
@@ -365,6 +366,7 @@ void apply_env_overrides(sd_params& p) {
     if (on("SD_EDTHR_COMPACT", '0')) p.reserved[1] |= SD_FLAG_NO_EDTHR_COMPACT;
     if (getenv("SD_FILTER_GENERAL")) p.reserved[1] |= SD_FLAG_FILTER_GENERAL;
     if (on("SD_IDENT_STREAM", '0')) p.reserved[1] |= SD_FLAG_NO_STREAM_IDENT;
+    if (on("SD_TRACE", '1')) p.reserved[1] |= SD_FLAG_TRACE_V1;
     if (p.reserved[2] == 0)
         if (const char* ev = getenv("SD_F16_GUARD")) p.reserved[2] = std::max(0, atoi(ev));
 }
@@ -432,7 +434,9 @@ static int engine_pick_family(sd_engine* e, bool allow_f16, std::string& err) {
     int family = p->kernel;
     std::string why;
     const bool no_f16 = !allow_f16 || (p->reserved[1] & SD_FLAG_NO_F16);
-    const bool fast_ok = sd::fast_plan_build(e->tseq, e->sc, p->part_size + p->overlap, e->fplan, why, !no_f16);
+    // the packed two-block traceback unless switched off, and not after a range guard tripped (its own check raises the same flag)
+    const bool tr2 = allow_f16 && !(p->reserved[1] & SD_FLAG_TRACE_V1);
+    const bool fast_ok = sd::fast_plan_build(e->tseq, e->sc, p->part_size + p->overlap, e->fplan, why, !no_f16, tr2);
     e->fplan.full_floor = (p->reserved[1] & SD_FLAG_FULL_FLOOR) != 0;
     if (family == 0) family = fast_ok ? 2 : 1;
     if (family == 2 && !fast_ok) { err = "fast kernel family not applicable: " + why; return SD_ERR_UNSUPPORTED; }
@@ -450,6 +454,7 @@ static int engine_pick_family(sd_engine* e, bool allow_f16, std::string& err) {
         e->d_flane.upload(e->fplan.lane_consts);
         e->d_fslot.upload(e->fplan.slot_of);
         e->d_ftcodes.upload(e->fplan.tcodes);
+        if (e->fplan.tr2_ok) e->d_ftr2.upload(e->fplan.tr2_tab);
         if (p->ed_thr > -1) {
             e->d_endvl.upload(e->fplan.end_vlane);
             e->d_endoff.upload(e->fplan.end_off);
@@ -1025,7 +1030,7 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                                       e->d_tlen.p, e->sc, e->d_B.p, e->d_argB.p, e->d_fckpt.p,
                                       e->d_fckbase.p, e->d_recs.p, e->d_cnt.p, qtrace, e->dp_order,
                                       e->n_cu, compact ? e->d_klist.p : nullptr, compact ? e->d_kpos.p : nullptr,
-                                      compact ? e->d_nkept.p : nullptr);
+                                      compact ? e->d_nkept.p : nullptr, e->fplan.tr2_ok ? e->d_ftr2.p : nullptr);
                 SD_HIP(hipEventRecord(e->ev_trace[1], ts));
                 e->fill_launches = 1;
             }
@@ -1226,7 +1231,8 @@ int sd_engine_info(sd_engine* e, int64_t info[8]) {
     info[4] = e->family | ((e->family == 1 ? 0 : e->fplan.waves > 1 ? 5 : e->fplan.wide ? (e->fplan.f16 ? 4 : 3) : e->fplan.f16 ? 2 : 1) << 8);
     info[5] = e->family == 1 ? e->Q : (e->fplan.P | ((int64_t)e->fplan.floor_slots << 16));
     info[6] = (int64_t)e->workspace_bytes();
-    info[7] = e->family == 1 ? (int64_t)e->subs.size() : 1;
+    info[7] = (e->family == 1 ? (int64_t)e->subs.size() : 1) |
+              ((int64_t)(e->family == 1 ? 0 : (e->fplan.tr2_ok && !e->compact_edthr) ? 2 : 1) << 16);
     return SD_OK;
 }
 

@@ -300,7 +300,7 @@ static int code_of(char ch) {
 }
 
 bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max_rows,
-                     FastPlan& plan, std::string& why, bool allow_f16) {
+                     FastPlan& plan, std::string& why, bool allow_f16, bool allow_tr2) {
     (void)max_rows;
     plan = FastPlan();
     const int T = (int)tseq.size();
@@ -531,6 +531,22 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         put(lc[FLC_CONT2], plane, (j >= 0 && uidx[(size_t)v] >= 2) ? 0xffff : 0);
         put(lc[FLC_ENDALL], plane, j >= 0 ? ((int)tseq[(size_t)j].size() - 1) * sc.del : NEG16);
     }
+    // The carry scan of the narrow fills can take its shifted operands from ds_bpermute (no VALU work, and a start lane
+    // simply reads an idle lane's -inf instead of being masked) when both planes have the same segment structure --
+    // every lane starts / continues a template in both planes alike -- and some lane is idle in both: Hx = H | 1 << 8 |
+    // idle lane << 16 (C2: 24 templates of five lanes, 12 per plane).
+    plan.Hx = plan.H;
+    if (!wide && W == 1 && plan.H >= 1 && plan.H <= 4 && !getenv("SD_FILL_DPP_SCAN")) {
+        bool same = true;
+        int idle = -1;
+        for (int l = 0; l < 64; ++l) {
+            const uint32_t c1 = plan.lane_consts[(size_t)l * FAST_LANE_WORDS + FLC_CONTMASK];
+            const uint32_t c2 = plan.lane_consts[(size_t)l * FAST_LANE_WORDS + FLC_CONT2];
+            if ((c1 & 0xffffu) != (c1 >> 16) || (c2 & 0xffffu) != (c2 >> 16)) same = false;
+            if (owner[(size_t)l] < 0 && owner[(size_t)64 + l] < 0) idle = l;
+        }
+        if (same && idle >= 0) plan.Hx = plan.H | (1 << 8) | (idle << 16);
+    }
     if (wide) {
         // int8 table [5][G][2 halves][64 lanes][4 dwords]; dword d of half h of group g holds slots
         // 16g+8h+2d, +1 as bytes {lo plane, hi plane, lo plane, hi plane}; -128 = transparent padding
@@ -631,6 +647,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
             }
         }
     }
+    if (allow_tr2) fast_plan_trace2(tseq, sc, plan);
     plan.ok = true;
     return true;
 }
@@ -679,7 +696,7 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, HF>),          \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
         hipLaunchKernelGGL((sd_fast_fill<PP, RK, HF>), dim3(grid), dim3(nw * 64), lds, st, chunks,    \
-                           n_chunks, bases2, nmask, table, lane_consts, sc, plan.H, B, argV, ckpt,   \
+                           n_chunks, bases2, nmask, table, lane_consts, sc, plan.Hx, B, argV, ckpt,  \
                            ckbase, queue, order, cendoff, crank);                                    \
     }
 #define SD_FILL(PP)                                                                                  \
@@ -715,7 +732,11 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
                        const int32_t* tlen, ScoreArgs sc, const int32_t* B, const int32_t* argV,
                        const uint32_t* ckpt, const int32_t* ckbase, DevRec* recs,
                        int32_t* rec_cnt, int* queue, const int* order, int n_cu, const uint16_t* klist,
-                       const uint16_t* kpos, const int32_t* nkept) {
+                       const uint16_t* kpos, const int32_t* nkept, const uint32_t* tr2_tab) {
+    // the packed two-block form where the plan has it (narrow layout, templates <= 248 bp, 16-bit tagged range)
+    if (klist == nullptr && launch_fast_trace2(plan, st, chunks, n_chunks, bases2, nmask, lane_consts, tcodes, toff, tlen, sc,
+                                               B, ckpt, ckbase, tr2_tab, recs, rec_cnt, queue, order, n_cu))
+        return;
     int bpc = 8;
     if (const char* ev = getenv("SD_TRACE_BPC")) bpc = std::max(1, atoi(ev));  // developer knob
     int grid = std::min((n_chunks + 3) / 4, bpc * n_cu);  // persistent: 8 workgroups of 4 waves per CU

@@ -41,6 +41,7 @@ struct FastPlan {
     int P = 0;            // slots per virtual lane
     int P4 = 0;           // P rounded up to a multiple of 4 (LDS table row)
     int H = 0;            // carry hops of the cross-lane chain: Vmax-1
+    int Hx = 0;           // what the narrow fills get: H | (carry scan through ds_bpermute) << 8 | idle lane << 16
     int T = 0;
     int split = 0;        // templates [0,split) in the lo plane
     int Lmax = 0;
@@ -59,7 +60,19 @@ struct FastPlan {
     std::vector<uint8_t> tcodes;         // per template cell: base code
     std::vector<int32_t> end_vlane;      // virtual lane holding the end of template j
     std::vector<int32_t> end_off;        // (L_j - 1) * del
+    // traceback, second form (sd_fast_trace2.hip): packed 16-bit recomputation, two blocks per wave
+    bool tr2_ok = false;                 // the narrow layout, templates <= 248 bp, scores inside the 16-bit tagged range
+    int tr2_qm = 0;                      // ceil(Lmax / 62): registers per lane at the widest level
+    int tr2_xlim = 0;                    // |E' - base| a checkpoint cell may have (run-time check of the range proof)
+    std::vector<uint32_t> tr2_tab;       // per template and level: table [5][QQ][32] + checkpoint map [QQ][2][32]
 };
+
+// the tables of sd_fast_trace_pk for a built narrow plan (tr2_ok = false when it does not apply)
+void fast_plan_trace2(const std::vector<std::string>& tseq, ScoreArgs sc, FastPlan& plan);
+bool launch_fast_trace2(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks, const uint32_t* bases2,
+                        const uint32_t* nmask, const uint32_t* lane_consts, const uint8_t* tcodes, const int32_t* toff,
+                        const int32_t* tlen, ScoreArgs sc, const int32_t* B, const uint32_t* ckpt, const int32_t* ckbase,
+                        const uint32_t* tr2_tab, DevRec* recs, int32_t* rec_cnt, int* queue, const int* order, int n_cu);
 
 // slots-per-virtual-lane values the fill kernels are instantiated for
 static const int FAST_P_LIST[] = {4, 8, 12, 16, 20, 24, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39,
@@ -69,7 +82,7 @@ static const int FAST_WIDE_P_LIST[] = {80, 96, 112, 128, 144, 160, 176, 192, 208
 // Builds the plan; returns false (with the reason) when the fast family cannot represent the
 // input exactly (then the generic family is used).
 bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max_rows,
-                     FastPlan& plan, std::string& why, bool allow_f16 = true);
+                     FastPlan& plan, std::string& why, bool allow_f16 = true, bool allow_tr2 = true);
 
 // --ed_thr prefilter on the device (sd_filter.hip): infix edit distances, kept set and ranks per
 // chunk -> per-chunk lane constants of the fast family (cendoff, crank: [chunk][64] packed {lo,hi}
@@ -151,6 +164,7 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
                        const int32_t* tlen, ScoreArgs sc, const int32_t* B, const int32_t* argV,
                        const uint32_t* ckpt, const int32_t* ckbase, DevRec* recs,
                        int32_t* rec_cnt, int* queue, const int* order, int n_cu,
-                       const uint16_t* klist = nullptr, const uint16_t* kpos = nullptr, const int32_t* nkept = nullptr);
+                       const uint16_t* klist = nullptr, const uint16_t* kpos = nullptr, const int32_t* nkept = nullptr,
+                       const uint32_t* tr2_tab = nullptr);   // device copy of FastPlan::tr2_tab: the second form where it applies
 
 }  // namespace sd

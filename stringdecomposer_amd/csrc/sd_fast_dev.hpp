@@ -11,6 +11,9 @@
 #ifndef SD_USE_DPP
 #define SD_USE_DPP 1
 #endif
+#ifndef SD_ACC_WRITELANE
+#define SD_ACC_WRITELANE 1
+#endif
 
 namespace sd {
 
@@ -201,9 +204,15 @@ struct F16Guard {
 // acc[lane == slot] = value (wave-uniform value and slot): one v_mov + one v_cndmask with a
 // scalar one-hot mask instead of v_mov + v_cmp + v_cndmask
 __device__ __forceinline__ void acc_put(int& acc, int value, int slot) {
+#if SD_ACC_WRITELANE
+    // scalar value into the lane `slot`; the lane select goes through m0 (two SGPR operands would exceed the one
+    // constant-bus read a gfx9 VALU instruction may make; SGPR + m0 is the form v_writelane allows)
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(acc) : "s"(value), "s"(slot) : "m0");
+#else
     const unsigned long long m = 1ull << slot;
     int v = value;
     asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(acc) : "v"(v), "s"(m));
+#endif
 }
 
 // Persistent waves: every wave pulls the next chunk from an atomic queue when it is done with its
@@ -257,12 +266,18 @@ struct ChunkSched {
     __device__ __forceinline__ void init(int* q, const int* o, int n) {
         queue = q; order = o; n_chunks = n;
     }
+    int pos = 0;   // queue position of the chunk last handed out
     // wave-uniform next chunk index, -1 when the queue is empty
     __device__ __forceinline__ int next() {
         int q = 0;
         if ((threadIdx.x & 63) == 0) q = atomicAdd(queue, 1);
         q = __builtin_amdgcn_readfirstlane(q);
+        pos = q;
         return q < n_chunks ? order[q] : -1;
+    }
+    // true when no wave will find another chunk after this one: the launch's last round, in which the SIMDs empty out
+    __device__ __forceinline__ bool last_round() const {
+        return pos + (int)(gridDim.x * (blockDim.x >> 6)) >= n_chunks;
     }
 };
 

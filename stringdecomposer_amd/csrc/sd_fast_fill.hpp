@@ -36,7 +36,7 @@ template <int P, bool RANKED, bool F16, int FL = P>
 __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
-    const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int H, int32_t* __restrict__ Bout,
+    const uint32_t* __restrict__ lane_consts, ScoreArgs sc, int Hx, int32_t* __restrict__ Bout,
     int32_t* __restrict__ argV, uint32_t* __restrict__ ckpt, int32_t* __restrict__ ckbase,
     int* __restrict__ queue, const int* __restrict__ order, const uint32_t* __restrict__ cendoff,
     const uint32_t* __restrict__ crank) {
@@ -59,6 +59,8 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     const int nw = (int)(blockDim.x >> 6);
     const int lane = threadIdx.x & 63;
     (void)wave; (void)nw;
+    const int H = Hx & 0xff;                    // carry hops (FastPlan::Hx)
+    const bool bperm_ok = (Hx >> 8) & 1;        // both planes segment alike and lane Hx >> 16 is idle in both
     // Issue fairness among the waves of a SIMD (FairShare, sd_fast_dev.hpp): the rows a wave still has to fill, one
     // word per wave behind the table
     FairShare fair;
@@ -70,6 +72,10 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     const int n = cd.n;
     ReadStream rs;
     rs.init(bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr, n);
+    // The carry scan through ds_bpermute trades seven VALU instructions per row for three crossbar round trips: a gain
+    // while four waves keep a SIMD's issue slots busy, a loss in the launch's last round, when the SIMDs empty out and
+    // a wave's own latency is what is left (there the DPP form stays)
+    const bool bperm_scan = bperm_ok && !sched.last_round();
 
     const uint32_t* lc = lane_consts + lane * FAST_LANE_WORDS;
     const uint32_t startMask = lc[FLC_STARTMASK];
@@ -125,8 +131,21 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     };
     // exclusive, template-segmented prefix maximum over the virtual lanes (both planes at once):
     // H = Vmax-1 carry hops of one lane each (DPP wave_shr:1)
+    // ds_bpermute byte addresses of the lanes one and two below, or of the idle lane (whose cells are -inf in both
+    // planes) where that lane belongs to another template: the shifted operands of the scan then cost no VALU
+    // instruction and need no mask (the LDS crossbar is otherwise idle in this kernel; the scan's latency hides
+    // under the B reduction, which depends on the same lane totals only)
+    const int idle4 = (Hx >> 16) << 2;
+    int bp1 = (contMask & 0xffffu) ? (lane - 1) << 2 : idle4;
+    int bp2 = (cont2Mask & 0xffffu) ? (lane - 2) << 2 : idle4;
+    asm volatile("" : "+v"(bp1), "+v"(bp2));
     auto excl_scan = [&](uint32_t a) {
         uint32_t inc = a;
+        if (bperm_scan) {   // wave-uniform
+            inc = CO::mx(inc, (uint32_t)__builtin_amdgcn_ds_bpermute(bp1, (int)inc));
+            inc = CO::mx(inc, (uint32_t)__builtin_amdgcn_ds_bpermute(bp2, (int)inc));
+            return (uint32_t)__builtin_amdgcn_ds_bpermute(bp1, (int)inc);
+        }
         if (H <= 4) {  // doubling: window of 4 previous lanes (the masks keep it inside the template;
                        // with H = 0 they are all zero and the result is -inf everywhere)
             inc = CO::mx(inc, bfi(contMask, lane_up(inc, 1), NEGC));
@@ -176,6 +195,7 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
             acc_put(accBV, (int)((b16 << 7) | (uint32_t)v), slot);
             if (slot == 63 || row == n) {
                 // 64 rows at once: fp16 -> int, B = base + (b + del) - del + tp_row * ins
+                asm volatile("");   // keeps this a scalar branch: the lane test below is not evaluated on every row
                 const uint32_t w = (uint32_t)accBV;
                 const int bi = (int)(float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 7));
                 const int tpl = tp - (slot - lane);
@@ -333,8 +353,17 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
         const uint32_t a = F16 ? L[P - 1] : CO::mx(L[P - 1], K);  // fp16: K already joined the chain
         ++tp;
         if constexpr (HRED) {
-            reduce_ends(a, i + 1);
-            K = excl_scan(a);
+            if (bperm_scan) {
+                // the scan's three crossbar trips run under the DPP chain of the B reduction (both need only `a`)
+                const uint32_t t1 = (uint32_t)__builtin_amdgcn_ds_bpermute(bp1, (int)a);
+                reduce_ends(a, i + 1);
+                const uint32_t i1 = CO::mx(a, t1);
+                const uint32_t i2 = CO::mx(i1, (uint32_t)__builtin_amdgcn_ds_bpermute(bp2, (int)i1));
+                K = (uint32_t)__builtin_amdgcn_ds_bpermute(bp1, (int)i2);
+            } else {
+                reduce_ends(a, i + 1);
+                K = excl_scan(a);
+            }
         } else {
             K = excl_scan(a);           // totals never decrease: the new carry replaces the old one
             Eend = CO::mx(a, K);

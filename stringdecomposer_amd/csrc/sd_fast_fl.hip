@@ -35,7 +35,7 @@ bool launch_fast_fill_fl(const FastPlan& plan, hipStream_t st, int grid, int nw,
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, true, FF>),     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
         hipLaunchKernelGGL((sd_fast_fill<PP, RK, true, FF>), dim3(grid), dim3(nw * 64), lds,  \
-                           st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, plan.H, B,   \
+                           st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, plan.Hx, B,   \
                            argV, ckpt, ckbase, queue, order, cendoff, crank);                        \
         return true;                                                                                 \
     }

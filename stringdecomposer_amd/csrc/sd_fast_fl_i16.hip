@@ -20,7 +20,7 @@ bool launch_fast_fill_fl_i16(const FastPlan& plan, hipStream_t st, int grid, int
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, false, FF>),    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
         hipLaunchKernelGGL((sd_fast_fill<PP, RK, false, FF>), dim3(grid), dim3(nw * 64), lds, \
-                           st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, plan.H, B,   \
+                           st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, plan.Hx, B,   \
                            argV, ckpt, ckbase, queue, order, cendoff, crank);                        \
         return true;                                                                                 \
     }

@@ -160,6 +160,7 @@ def _strs(seq):
 
 
 FLAG_NO_F16, FLAG_FULL_FLOOR, FLAG_NO_EDTHR_COMPACT, FLAG_FILTER_GENERAL, FLAG_NO_STREAM_IDENT, FLAG_PROGRESS = 1, 2, 4, 8, 16, 32
+FLAG_TRACE_V1 = 64
 
 
 def make_params(scoring=(-1, -1, -1, 1), part_size=5000, overlap=500, ed_thr=-1, threads=1,
@@ -404,7 +405,8 @@ def _info_dict(v):
                       5: "f16/bf8-codes x waves"}.get(v[4] >> 8, "?"),
             "cells_per_lane": v[5] if (v[4] & 0xff) == 1 else v[5] & 0xffff,
             "floor_slots": 0 if (v[4] & 0xff) == 1 else v[5] >> 16,
-            "workspace_bytes": v[6], "fill_launches": v[7]}
+            "workspace_bytes": v[6], "fill_launches": v[7] & 0xffff,
+            "trace": {0: "generic", 1: "one-block int32", 2: "two-block packed16"}.get(v[7] >> 16, "?")}
 
 
 class ReadSet:

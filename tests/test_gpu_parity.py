@@ -960,3 +960,48 @@ def test_ed_thr_with_monomers_longer_than_512_bp(oracle, lo, hi):
         assert gen == exp, (lo, hi, ed, "generic")
     exp = oracle.decompose(rn, reads, mn, ms, threads=8, sc=(-2, -3, -4, 2))
     assert lib.decompose(rn, reads, mn, ms, scoring=(-2, -3, -4, 2)) == exp
+
+
+TR_SHAPES = [
+    # (monomers, Lmin, Lmax, scoring, part, overlap, N in reads) -- the packed two-block traceback (sd_fast_trace2.hip)
+    (12, 165, 178, (-1, -1, -1, 1), 5000, 500, False),    # C2's shape: three levels (QQ = 3, 2, 1)
+    (12, 165, 178, (-2, -3, -4, 2), 1500, 200, True),     # BASELINE config 5's scoring
+    (5, 20, 61, (-1, -1, -1, 1), 333, 77, True),          # one level, blocks shorter than a checkpoint interval apart
+    (4, 62, 63, (-1, -2, -1, 1), 700, 100, False),        # the 62-cell level boundary
+    (6, 187, 248, (-1, -1, -2, 2), 2000, 300, True),      # four registers per lane
+    (3, 2, 9, (0, -1, -1, 1), 97, 13, True),              # tiny templates: an instance is a fraction of a block
+    (8, 120, 130, (-3, -1, -2, 3), 640, 64, False),       # a chunk that ends exactly on a checkpoint row
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", TR_SHAPES, ids=["%dx%d-%d_%s" % (s[0], s[1], s[2], "_".join(map(str, s[3]))) for s in TR_SHAPES])
+def test_packed_two_block_traceback_vs_one_block_form_and_oracle(oracle, shape):
+    """sd_fast_trace_pk (two 32-row blocks per wave, packed 16-bit tagged cells, main.cpp:217-269) against the oracle and
+    against sd_fast_trace (SD_FLAG_TRACE_V1) on the same fills: every level of cells per lane, both block pairings
+    (chunks shorter than 64 rows never pair), row-0 blocks, N, scorings whose words sit elsewhere in the 16-bit range."""
+    nm, lo, hi, sc, part, ov, with_n = shape
+    st = synth.Stream(1000 + nm * 7 + hi, 3)
+    ms = []
+    for j in range(nm):
+        L = lo + int(st.below(1, hi - lo + 1)[0])
+        ms.append(synth._ACGT[st.below(L, 4)].tobytes())
+    mn = ["m%d" % j for j in range(nm)]
+    rn, rs = synth.make_reads(ms, 6, read_len=max(4 * part, 900), seed=hi)
+    rs = list(rs)
+    # short reads around the pairing limits: 1, 31, 32, 33, 63, 64, 65, 96, 97 rows
+    for L in (1, 2, 31, 32, 33, 63, 64, 65, 96, 97, 129):
+        rs.append((b"".join(ms) * 3)[7:7 + L])
+    if with_n:
+        b = bytearray(rs[0]); b[50:53] = b"NNN"; b[700] = ord("N"); rs[0] = bytes(b)
+        rs.append(b"N" * 70 + ms[0] * 2)
+    rn = ["r%d" % i for i in range(len(rs))]
+    kw = dict(part_size=part, overlap=ov, scoring=sc)
+    e = lib.Engine(ms, kernel=lib.KERNEL_FAST, scoring=sc, part_size=part, overlap=ov)
+    assert e.info()["trace"] == "two-block packed16"
+    e.close()
+    exp = oracle.decompose(rn, rs, mn, ms, threads=8, sc=sc, part=part, overlap=ov)
+    got = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, **kw)
+    v1 = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, flags=lib.FLAG_TRACE_V1, **kw)
+    assert v1 == exp
+    assert got == exp
