@@ -245,6 +245,8 @@ struct sd_engine {
     DevBuf<uint32_t> d_fslot;        // (wave, slot, virtual lane) of template cell (j,k) in the lane layout
     DevBuf<uint8_t> d_ftcodes;       // base code of template cell (j,k)
     DevBuf<uint32_t> d_ftr2;         // tables of the packed two-block traceback (FastPlan::tr2_tab)
+    DevBuf<long long> d_scanws;      // sd_scan_compact: per-range counts and launch stamps (persist between launches)
+    long long scan_epoch = 0;
     DevBuf<uint32_t> d_fckpt;        // checkpoints
     DevBuf<int32_t> d_fckbase;       // per-checkpoint rebase values
     // --ed_thr prefilter (fast family only)
@@ -1035,8 +1037,13 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                 e->fill_launches = 1;
             }
             SD_HIP(hipEventRecord(e->ev_cmp0, ts));
+            if (!e->d_scanws.p) {
+                e->d_scanws.alloc(512);
+                SD_HIP(hipMemsetAsync(e->d_scanws.p, 0, 512 * sizeof(long long), ts));
+            }
             sd::launch_compact(ts, e->dp_chunks, C, e->d_cnt.p, e->d_roff.p, e->d_recs.p,
-                               e->d_dense.p, e->dense_cap, true, e->ident_mode ? e->d_recchunk.p : nullptr);
+                               e->d_dense.p, e->dense_cap, true, e->ident_mode ? e->d_recchunk.p : nullptr,
+                               e->d_scanws.p, ++e->scan_epoch);
             SD_HIP(hipEventRecord(e->ev_cmp1, ts));
             if (e->ident_mode) {   // identities of the final TSV on the batch's compact records (sd_ident.hip)
                 SD_HIP(hipEventRecord(e->ev_id0, ts));
@@ -1387,8 +1394,16 @@ struct Pipeline {
     }
     int push(const std::vector<const char*>& cptr, const std::vector<int32_t>& clen, RecSink sink) {
         int rc = SD_OK;
-        if (inflight() == NS) rc = pop();
+        // All slots busy: the oldest batch has to leave its engine first.  Only its device work and the copy of its
+        // records are waited for here; its sink (per-read assembly, text) runs AFTER the new batch is packed and
+        // enqueued -- the records sit in the engine's pinned buffers, which the new batch does not touch before its own
+        // fetch -- so that the device gets its next fill as early as possible (with few host threads the assembly +
+        // packing of 5 ms used to end after the running fill's last round had begun: 17.0 instead of 14.6 ms per C2
+        // step at two host threads).
+        bool deferred = false;
+        if (inflight() == NS) { rc = pop_fetch(); deferred = rc == SD_OK; }
         if (rc) return rc;
+        struct RunSink { Pipeline* p; bool on; ~RunSink() { if (on) p->pop_sink(); } } run_sink{this, deferred};
         const int k = (int)(pushed % NS);
         if (!eng[k]) {
             rc = sd_engine_create(&eng[k], &p, mseq.data(), mlen.data(), (int32_t)mseq.size(), eb, sizeof eb);
@@ -1409,6 +1424,17 @@ struct Pipeline {
         return SD_OK;
     }
     int pop() {
+        const int rc = pop_fetch();
+        if (rc == SD_OK) pop_sink();
+        return rc;
+    }
+    int sink_slot = -1;          // slot whose records are fetched and whose sink has not run yet
+    RecSink sink_fn;             // ... its sink, its record offsets (a copy: the engine's pinned array is the target of the
+    std::vector<int64_t> sink_roff;   // next run's copy) and its chunk count
+    size_t sink_chunks = 0;
+    // first half of pop(): wait for the oldest batch, copy its records to the host, book its times
+    int pop_fetch() {
+        if (sink_slot >= 0) pop_sink();
         if (inflight() == 0) return SD_OK;
         const int k = (int)(popped % NS);
         int64_t total = 0;
@@ -1416,7 +1442,7 @@ struct Pipeline {
         int rc = fetch_pinned(eng[k], total, eb, sizeof eb);
         wait_s += now_s() - t0;
         ++popped;
-        if (rc) return rc;
+        if (rc) { sinks[k] = nullptr; return rc; }
         float ms[4];
         if (sd_engine_timings(eng[k], ms) == SD_OK) { fill_ms += ms[0]; trace_ms += ms[1]; compact_ms += ms[2]; run_ms += ms[3]; }
         if (eng[k]->ident_mode && !eng[k]->chunks.empty()) {
@@ -1427,19 +1453,30 @@ struct Pipeline {
         launches += eng[k]->fill_launches;
         ++batches;
         rows += eng[k]->rows;
-        t0 = now_s();
+        sink_slot = k;
+        sink_fn = std::move(sinks[k]);
+        sinks[k] = nullptr;
+        sink_chunks = eng[k]->chunks.size();
+        sink_roff.assign(eng[k]->h_roff.p, eng[k]->h_roff.p + sink_chunks + 1);
+        return SD_OK;
+    }
+    // second half: hand the fetched records to the batch's sink
+    void pop_sink() {
+        if (sink_slot < 0) return;
+        const int k = sink_slot;
+        sink_slot = -1;
+        const double t0 = now_s();
         cur_ident = IdentOut{};
         cur_engine = eng[k];
         if (eng[k]->ident_valid)
             cur_ident = IdentOut{eng[k]->h_ident, eng[k]->ident_mode == 2 ? eng[k]->h_identh : nullptr,
                                  eng[k]->ident_mode == 2 ? eng[k]->iT : 1, eng[k]->h_ident_bytes,
                                  eng[k]->ident_mode == 2 ? eng[k]->h_identh_bytes : 0};
-        if (sinks[k]) sinks[k](eng[k]->h_recs.p, eng[k]->h_roff.p, eng[k]->chunks.size());
-        sinks[k] = nullptr;
+        if (sink_fn) sink_fn(eng[k]->h_recs.p, sink_roff.data(), sink_chunks);
+        sink_fn = nullptr;
         cur_ident = IdentOut{};
         cur_engine = nullptr;
         sink_s += now_s() - t0;
-        return SD_OK;
     }
     int drain() {
         int rc = SD_OK;

@@ -239,12 +239,23 @@ __global__ __launch_bounds__(64 * trace_waves_per_group(QK), (QK <= 4 ? SD_TRACE
                     pt[r_i - a][lane] = (pt_t)((unsigned long long)bits | ((unsigned long long)(bitsHi >> (64 - 2 * QQ)) << 32));
                 }
             }
-            // walk inside the block (wave-uniform)
+            // walk inside the block (wave-uniform).  Lane l looks at the cell l diagonal moves ahead, (i - l, k - l): the
+            // run of DIAG tags from lane 0 on is taken in one LDS round trip (reads of ~90 % identity are mostly diagonal
+            // runs), then the move that ends it.
             while (i >= a) {
-                const int tg = __builtin_amdgcn_readfirstlane((pt[i - a][k / QQ] >> (2 * (k % QQ))) & 3);
-                if (tg == 3) { --k; }
-                else if (tg == 2) { --i; }
-                else if (tg == 1) { --i; --k; }
+                const int il = i - lane, kl = k - lane;
+                const bool ok = il >= a && kl >= 0;
+                int tg = 0;
+                if (ok) tg = (int)((pt[il - a][kl / QQ] >> (2 * (kl % QQ))) & 3);
+                const unsigned long long dg = __ballot(ok && tg == 1);
+                const int run = dg == ~0ull ? 64 : __builtin_ctzll(~dg);
+                i -= run;
+                k -= run;
+                if (run == 64 || i < a) continue;
+                // (k >= 0 here: the k = 0 cell has no diagonal candidate, its tag is never DIAG)
+                const int te = __builtin_amdgcn_readlane(tg, run);
+                if (te == 3) { --k; }
+                else if (te == 2) { --i; }
                 else { return Pos{i, k, true}; }
             }
             return Pos{i, k, false};
@@ -545,7 +556,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
             if ((c1 & 0xffffu) != (c1 >> 16) || (c2 & 0xffffu) != (c2 >> 16)) same = false;
             if (owner[(size_t)l] < 0 && owner[(size_t)64 + l] < 0) idle = l;
         }
-        if (same && idle >= 0) plan.Hx = plan.H | (1 << 8) | (idle << 16);
+        if (same && idle >= 0) plan.Hx = plan.H | (1 << 8) | (idle << 16) | (getenv("SD_FILL_BPERM_TAIL") ? 1 << 9 : 0);   // bit 9 (developer A/B): in the last round too
     }
     if (wide) {
         // int8 table [5][G][2 halves][64 lanes][4 dwords]; dword d of half h of group g holds slots
@@ -619,6 +630,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
                 for (int b = 0; b < 5; ++b) putb(b * G + k / 16, v, k & 15, cd == b ? md : xd);
             }
         }
+        if (allow_tr2) fast_plan_trace2(tseq, sc, plan);   // (one wave per chunk: the same checkpoint layout as the narrow fills)
         plan.ok = true;
         return true;
     }

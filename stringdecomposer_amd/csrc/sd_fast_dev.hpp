@@ -207,7 +207,12 @@ __device__ __forceinline__ void acc_put(int& acc, int value, int slot) {
 #if SD_ACC_WRITELANE
     // scalar value into the lane `slot`; the lane select goes through m0 (two SGPR operands would exceed the one
     // constant-bus read a gfx9 VALU instruction may make; SGPR + m0 is the form v_writelane allows)
+    // (m0 is a reserved register the compiler never allocates; nothing else in these kernels uses it -- gfx9 LDS
+    // instructions do not -- so the clobber only documents the write)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
     asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(acc) : "s"(value), "s"(slot) : "m0");
+#pragma clang diagnostic pop
 #else
     const unsigned long long m = 1ull << slot;
     int v = value;

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     // The carry scan through ds_bpermute trades seven VALU instructions per row for three crossbar round trips: a gain
     // while four waves keep a SIMD's issue slots busy, a loss in the launch's last round, when the SIMDs empty out and
     // a wave's own latency is what is left (there the DPP form stays)
-    const bool bperm_scan = bperm_ok && !sched.last_round();
+    const bool bperm_scan = bperm_ok && (!sched.last_round() || ((Hx >> 9) & 1));
 
     const uint32_t* lc = lane_consts + lane * FAST_LANE_WORDS;
     const uint32_t startMask = lc[FLC_STARTMASK];

@@ -12,7 +12,7 @@
 //    A) the step runs A alone over A's rows only.
 //  * TWO cells per lane-operation.  Cells are 16-bit words  U = 4*(E' - base) + tag + 0x4000  packed two to a VGPR
 //    (low half / high half = two "planes": lane l of a half-wave owns the virtual lanes 2l and 2l+1, each QQ consecutive
-//    template cells, 62 virtual lanes per half-wave; lane 31 idles).  E' = E - i*ins is the fill's row-shifted domain
+//    template cells, 64 virtual lanes per half-wave).  E' = E - i*ins is the fill's row-shifted domain
 //    (the insertion move is "keep"), base = the block's first start term, and the two low bits carry the reference's
 //    traceback priority DEL 3 > INS 2 > DIAG 1 > START 0 (main.cpp:242-253) so that ONE maximum yields the value and,
 //    among equal values, the move the reference's equality tests pick first (as in sd_fast_trace).  Every word stays
@@ -26,8 +26,8 @@
 //    mt[5][QQ][32]     4*(mm - del - ins) - 1 of the lane's two cells of register q for the five read symbols, as a
 //                      signed pair (hi * 65536 + lo); 0 on padding cells
 //    ck[QQ][2][32]     where the cell sits in a checkpoint of the fill: slot * 64 + lane | plane << 31; ~0 = padding
-// Applies to the narrow layout (one wave per chunk in the fill) with templates of up to 62 * 4 = 248 bp; everything else
-// keeps sd_fast_trace.
+// Applies to the layouts with one wave per chunk in the fill (narrow, and wide up to 128 templates) and templates of up to
+// 64 * 4 = 256 bp; everything else keeps sd_fast_trace.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -103,7 +103,8 @@ __global__ __launch_bounds__(64 * TR2_NWV, 7) void sd_fast_trace_pk(
     // cell is k = 0, which has no insertion move in the fill (main.cpp:193-203)
     uint32_t pdmask = ll == 0 ? 0u : 0xffffffffu;
     uint32_t insmask = ll == 0 ? 0xffff0000u : 0xffffffffu;
-    asm volatile("" : "+v"(pdmask), "+v"(insmask));   // plain AND masks in registers (not selects on the lane test)
+    uint32_t two2 = 0x00020002u;
+    asm volatile("" : "+v"(pdmask), "+v"(insmask), "+v"(two2));   // plain AND masks in registers (not selects on the lane test)
     constexpr int STRIDE = 224 * QM * (QM + 1) / 2;
 
     ChunkSched sched;
@@ -153,12 +154,15 @@ __global__ __launch_bounds__(64 * TR2_NWV, 7) void sd_fast_trace_pk(
             const int mybase = hh ? baseB : baseA;
             const bool act = hh == 0 || hasB;
             // row info, one row per lane (lane ll of a half holds row ab + ll)
+            bool badrow = false;
             {
                 const int rl = ab + ll;
                 const bool rvalid = act && rl >= 1 && rl <= (hh ? a0 - 1 : i);
                 uint32_t w = 0;
                 if (rvalid) {
-                    const int bd = 4 * (Bof(rl) + del - (rl - 1) * ins - mybase) + 1 + TR2_BIAS;
+                    const int bx = Bof(rl) + del - (rl - 1) * ins - mybase;   // the row's start term relative to the block's first
+                    badrow = bx > xlim || bx < -xlim;
+                    const int bd = 4 * bx + 1 + TR2_BIAS;
                     w = ((uint32_t)bd & 0xffffu) | ((uint32_t)(rc.code(rl) * (QQ * 128)) << 16);
                 } else if (rl == 0 && act) {
                     // row 0 (main.cpp:171-182): E[0][k] = max(E[0][k-1], mm_k - del), E[0][0] = mm_0: the regular update with
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(64 * TR2_NWV, 7) void sd_fast_trace_pk(
             uint32_t T[QQ];
 #pragma unroll
             for (int q = 0; q < QQ; ++q) T[q] = 0;
-            bool bad = false;
+            bool bad = badrow;   // run-time check of the plan's range proof: a word outside the exact range raises the guard flag
             if (a0 != 0 && act) {
                 const int q0 = ab / FAST_R - 1;
                 const int32_t cb = ckbase[cd.pad + q0];
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(64 * TR2_NWV, 7) void sd_fast_trace_pk(
                 for (int q = 0; q < QQ; ++q) {
                     const uint32_t Ef = CellOps<true>::mx(loc[q], C);
                     acc = (acc << 2) | (Ef & TR2_TAGS);
-                    T[q] = (Ef & ~TR2_TAGS) | 0x00020002u;
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(T[q]) : "v"(Ef), "s"(~TR2_TAGS), "v"(two2));   // (Ef & ~tags) | INS tag
                 }
                 // byte 0 = the lo plane's moves, byte 2 = the hi plane's: one 16-bit store {virtual lane 2l, 2l + 1}
                 *reinterpret_cast<uint16_t*>(prow + t * 64) = (uint16_t)__builtin_amdgcn_perm(0u, acc, 0x0c0c0200u);
@@ -238,27 +242,28 @@ __global__ __launch_bounds__(64 * TR2_NWV, 7) void sd_fast_trace_pk(
             };
             const int nIter = hasB ? FAST_R : nA;
             int t = 0;
-            uint32_t w_cur = rip[0], w_nxt = rip[1];   // (ri has 32 words per half: row t + 1 <= 31 exists as a word)
-            uint32_t mm_cur[QQ], mm_nxt[QQ];
-            table_of(w_cur, mm_cur);
+            uint32_t w0 = rip[0];
+            uint32_t mm0[QQ], mm1[QQ];
+            table_of(w0, mm0);
             if (a0 == 0) {
-                table_of(w_nxt, mm_nxt);
-                row(std::true_type(), 0, w_cur, mm_cur);
-                w_cur = w_nxt;
-#pragma unroll
-                for (int q = 0; q < QQ; ++q) mm_cur[q] = mm_nxt[q];
-                w_nxt = rip[2];
+                row(std::true_type(), 0, w0, mm0);
+                w0 = rip[1];
+                table_of(w0, mm0);
                 t = 1;
             }
-            for (; t < nIter; ++t) {
-                table_of(w_nxt, mm_nxt);                              // row t + 1
-                const uint32_t w_n2 = rip[(t + 2) & (FAST_R - 1)];     // row t + 2 (wraps to a valid word at the end)
-                row(std::false_type(), t, w_cur, mm_cur);
-                w_cur = w_nxt;
-                w_nxt = w_n2;
-#pragma unroll
-                for (int q = 0; q < QQ; ++q) mm_cur[q] = mm_nxt[q];
+            uint32_t w1 = rip[(t + 1) & (FAST_R - 1)];   // (ri has 32 words per half: the index wraps to a valid word)
+            // two rows per trip, the table registers ping-pong: at the top w0 / mm0 belong to row t, w1 to row t + 1
+            for (; t + 1 < nIter; t += 2) {
+                table_of(w1, mm1);
+                const uint32_t w2 = rip[(t + 2) & (FAST_R - 1)];
+                row(std::false_type(), t, w0, mm0);
+                table_of(w2, mm0);
+                const uint32_t w3 = rip[(t + 3) & (FAST_R - 1)];
+                row(std::false_type(), t + 1, w1, mm1);
+                w0 = w2;
+                w1 = w3;
             }
+            if (t < nIter) row(std::false_type(), t, w0, mm0);
 
             // walk (wave-uniform)
             const int low = hasB ? aB : a0;
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(64 * TR2_NWV, 7) void sd_fast_trace_pk(
 
         int cur = 0;
         while (true) {
-            const int need = k / 62 + 1;
+            const int need = (k >> 6) + 1;
             Pos ps;
             auto go = [&](auto qq_c) {
                 constexpr int QQ = decltype(qq_c)::value;
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(64 * TR2_NWV, 7) void sd_fast_trace_pk(
 void fast_plan_trace2(const std::vector<std::string>& tseq, ScoreArgs sc, FastPlan& plan) {
     plan.tr2_ok = false;
     plan.tr2_tab.clear();
-    if (plan.wide || plan.waves != 1 || plan.Lmax > 62 * 4) return;
+    if (plan.waves != 1 || plan.Lmax > 64 * 4) return;
     auto ab = [](int v) { return v < 0 ? -v : v; };
     const int maxabs = std::max(std::max(ab(sc.ins), ab(sc.del)), std::max(ab(sc.mismatch), ab(sc.match)));
     // Range of X = E' - base inside a pair of blocks.  A cell is at most (Lmax - 1)*|del| above the next row's B (the rest
@@ -351,7 +356,7 @@ void fast_plan_trace2(const std::vector<std::string>& tseq, ScoreArgs sc, FastPl
     const int64_t R2 = (int64_t)(plan.Lmax + 1) * ab(sc.del) + 36 * (G + 2 * (int64_t)ab(sc.ins)) + 8 * (int64_t)maxabs + 16;
     if (4 * R2 + 16 > 15000) return;
     plan.tr2_xlim = (int)(15000 / 4 - 4);
-    const int QM = (plan.Lmax + 61) / 62;
+    const int QM = (plan.Lmax + 63) / 64;
     plan.tr2_qm = QM;
     const int stride = 224 * QM * (QM + 1) / 2;
     const int T = (int)tseq.size();
@@ -369,7 +374,7 @@ void fast_plan_trace2(const std::vector<std::string>& tseq, ScoreArgs sc, FastPl
                     int kk[2];
                     for (int pl = 0; pl < 2; ++pl) {
                         const int k = (2 * ll + pl) * QQ + q;
-                        kk[pl] = (ll < 31 && k < L) ? k : -1;
+                        kk[pl] = k < L ? k : -1;
                         uint32_t idx = 0xffffffffu;
                         if (kk[pl] >= 0) {
                             const uint32_t so = plan.slot_of[x0 + (size_t)k];   // (slot << 7) | virtual lane of the fill

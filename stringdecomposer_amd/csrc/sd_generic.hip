@@ -456,8 +456,90 @@ __global__ void sd_compact(const ChunkDesc* __restrict__ chunks, const int32_t* 
         for (int a = threadIdx.x; a < k; a += blockDim.x) out_chunk[roff[c] + a] = c;
 }
 
+// Offsets and compaction in ONE launch: workgroup b owns a contiguous range of chunks, publishes the record count of its
+// range, adds up the counts of the ranges before it as they appear (every workgroup's first step depends on nothing, and
+// workgroups are dispatched in order, so the wait is for work that is already running), scans its own chunks and copies
+// their records.  `ws`: 2 * SC_NB words that persist between launches -- [b] the count of range b, [SC_NB + b] the launch
+// (`epoch`) it belongs to -- so nothing has to be cleared.  Replaces the one-workgroup sd_scan_counts, which sat behind the
+// next batch's fill on the lower-priority stream for milliseconds before its 16 us of work (round 3: 4 ms on average).
+constexpr int SC_NB = 256, SC_T = 256;
+__global__ __launch_bounds__(SC_T) void sd_scan_compact(const ChunkDesc* __restrict__ chunks, const int32_t* __restrict__ cnt,
+                                                        int n, int64_t* __restrict__ roff, const DevRec* __restrict__ recs,
+                                                        DevRec* __restrict__ out, int64_t out_cap,
+                                                        int32_t* __restrict__ out_chunk, long long* __restrict__ ws,
+                                                        long long epoch) {
+    __shared__ long long red[SC_T / 64];
+    __shared__ long long run_s;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+    const int per = (n + nb - 1) / nb;
+    const int c0 = min(n, b * per), c1 = min(n, c0 + per);
+    auto block_sum = [&](long long v) {   // valid in every thread
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        __syncthreads();
+        if (lane == 0) red[w] = v;
+        __syncthreads();
+        long long r = 0;
+        for (int x = 0; x < SC_T / 64; ++x) r += red[x];
+        return r;
+    };
+    long long s = 0;
+    for (int c = c0 + t; c < c1; c += SC_T) s += cnt[c];
+    const long long mine = block_sum(s);
+    if (t == 0) {
+        __hip_atomic_store(ws + b, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ws + SC_NB + b, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    long long pre = 0;
+    for (int x = t; x < b; x += SC_T) {
+        while (__hip_atomic_load(ws + SC_NB + x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+        pre += __hip_atomic_load(ws + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const long long base = block_sum(pre);
+    if (t == 0) run_s = base;
+    __syncthreads();
+    for (int cb = c0; cb < c1; cb += SC_T) {   // exclusive scan of the range, SC_T chunks at a time
+        const int c = cb + t;
+        const long long v = c < c1 ? cnt[c] : 0;
+        long long sc = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long s2 = __shfl_up(sc, off);
+            if (lane >= off) sc += s2;
+        }
+        if (lane == 63) red[w] = sc;
+        __syncthreads();
+        long long p2 = run_s;
+        for (int x = 0; x < w; ++x) p2 += red[x];
+        if (c < c1) roff[c] = p2 + sc - v;
+        __syncthreads();
+        if (t == SC_T - 1) run_s = p2 + sc;
+        __syncthreads();
+    }
+    if (b == nb - 1 && t == 0) roff[n] = base + mine;
+    __threadfence_block();
+    __syncthreads();
+    // compaction of the range: one wave per chunk at a time
+    for (int c = c0 + w; c < c1; c += SC_T / 64) {
+        const int k = cnt[c];
+        const long long off = roff[c];
+        if (off + k > out_cap) continue;   // host re-runs the compaction with a larger buffer
+        const DevRec* src = recs + chunks[c].row0;
+        DevRec* dst = out + off;
+        for (int a = lane; a < k; a += 64) dst[a] = src[k - 1 - a];   // reverse, main.cpp:268
+        if (out_chunk)
+            for (int a = lane; a < k; a += 64) out_chunk[off + a] = c;
+    }
+}
+
 void launch_compact(hipStream_t st, const ChunkDesc* chunks, int n_chunks, const int32_t* cnt,
-                    int64_t* roff, const DevRec* recs, DevRec* out, int64_t out_cap, bool scan, int32_t* out_chunk) {
+                    int64_t* roff, const DevRec* recs, DevRec* out, int64_t out_cap, bool scan, int32_t* out_chunk,
+                    long long* scan_ws, long long epoch) {
+    if (scan && scan_ws != nullptr && n_chunks > 0) {
+        const int nb = std::max(1, std::min(SC_NB, (n_chunks + 31) / 32));
+        hipLaunchKernelGGL(sd_scan_compact, dim3(nb), dim3(SC_T), 0, st, chunks, cnt, n_chunks, roff, recs, out, out_cap,
+                           out_chunk, scan_ws, epoch);
+        return;
+    }
     if (scan) hipLaunchKernelGGL(sd_scan_counts, dim3(1), dim3(1024), 0, st, cnt, n_chunks, roff);
     hipLaunchKernelGGL(sd_compact, dim3(n_chunks), dim3(64), 0, st, chunks, cnt, roff, recs, out,
                        out_cap, out_chunk);

@@ -15,7 +15,10 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 mono = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 mn, ms = synth.make_monomers(mono, seed=1)
 rn, rs = synth.make_reads(ms, reads, read_len=50000, seed=1)
-e = lib.Engine(ms, kernel={"auto": 0, "generic": 1, "fast": 2}[os.environ.get("SD_KERNEL", "auto")])
+kw = {}
+if os.environ.get("SD_SCORING"):   # e.g. SD_SCORING=-2,-3,-4,2 (ins,del,mismatch,match)
+    kw["scoring"] = tuple(int(x) for x in os.environ["SD_SCORING"].split(","))
+e = lib.Engine(ms, kernel={"auto": 0, "generic": 1, "fast": 2}[os.environ.get("SD_KERNEL", "auto")], **kw)
 e.load_reads(rs)
 best = None
 for _ in range(steps + 1):
@@ -31,4 +34,4 @@ recs = e.fetch()
 h = hashlib.sha1(repr(recs).encode()).hexdigest()[:12]
 print("%-40s fill %.2f ms  trace %.2f ms  wall %.2f ms  rows %d  P=%s  sha %s" % (
     os.path.basename(lib.LIB_PATH), best["fill_ms"], best["trace_ms"], best["wall_ms"], n,
-    e.info()["cells_per_lane"], h))
+    e.info()["cells_per_lane"], h), e.info()["cells"], "FL", e.info()["floor_slots"], e.info()["trace"])
