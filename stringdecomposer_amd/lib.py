@@ -661,9 +661,8 @@ def decompose_chunk_range(read_seqs, mono_seqs, chunk_lo, chunk_hi, **kw):
     n = chunk_hi - chunk_lo
     o = np.ctypeslib.as_array(off, shape=(n + 1,)).copy()
     nrec = int(o[n])
-    if nrec:
-        raw = C.string_at(recs, nrec * C.sizeof(Rec))
-        r = np.frombuffer(raw, dtype=_rec_dtype()).copy()
+    if nrec:   # one copy out of the library's buffer
+        r = np.ctypeslib.as_array(C.cast(recs, C.POINTER(C.c_int32)), shape=(nrec * 4,)).copy().view(_rec_dtype())
     else:
         r = np.zeros(0, dtype=_rec_dtype())
     L.sd_free(recs)
