@@ -218,7 +218,10 @@ int sd_engine_info(sd_engine* e, int64_t info[8]);
  * the maximum with the start term [4] low byte: waves per chunk; bits 8..: the proven bound on the magnitude of a
  * stored cell (fp16 cell formats are chosen when it is <= 2040; tests/test_host_cpu.py checks it against the
  * recurrence itself) [5] cells in the shortest first lane of a template
- * [6] cells in the fullest lane [7] common factor divided out of the four scores. */
+ * [6] cells in the fullest lane [7] bits 0..15: common factor divided out of the four scores; bits 16..23: registers per
+ * lane of the packed two-block traceback at its widest level (0 = the one-block int32 traceback runs); bits 24..55: the
+ * proven bound on |E' - base| of that traceback's 16-bit words (tests/test_host_cpu.py checks it against the
+ * recurrence); bit 56: the narrow fill takes its carry scan through ds_bpermute. */
 int sd_plan_info(const sd_params* p, const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono,
                  int64_t info[8], char* errbuf, size_t errlen);
 

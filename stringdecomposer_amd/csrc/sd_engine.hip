@@ -540,7 +540,8 @@ int sd_plan_info(const sd_params* p, const char* const* mono_seqs, const int32_t
     }
     info[5] = min_first;
     info[6] = max_lane;
-    info[7] = g;
+    info[7] = (int64_t)g | ((int64_t)(plan.tr2_ok ? plan.tr2_qm : 0) << 16) | ((int64_t)(plan.tr2_ok ? plan.tr2_bound : 0) << 24) |
+              ((int64_t)((plan.Hx >> 8) & 1) << 56);
     return SD_OK;
 }
 

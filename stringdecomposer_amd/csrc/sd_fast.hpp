@@ -64,6 +64,7 @@ struct FastPlan {
     bool tr2_ok = false;                 // the narrow layout, templates <= 248 bp, scores inside the 16-bit tagged range
     int tr2_qm = 0;                      // ceil(Lmax / 62): registers per lane at the widest level
     int tr2_xlim = 0;                    // |E' - base| a checkpoint cell may have (run-time check of the range proof)
+    int tr2_bound = 0;                   // the proven bound on |E' - base| for this template set and scoring (<= tr2_xlim)
     std::vector<uint32_t> tr2_tab;       // per template and level: table [5][QQ][32] + checkpoint map [QQ][2][32]
 };
 

@@ -355,6 +355,7 @@ void fast_plan_trace2(const std::vector<std::string>& tseq, ScoreArgs sc, FastPl
     const int64_t G = std::max(0, smax - sc.del);
     const int64_t R2 = (int64_t)(plan.Lmax + 1) * ab(sc.del) + 36 * (G + 2 * (int64_t)ab(sc.ins)) + 8 * (int64_t)maxabs + 16;
     if (4 * R2 + 16 > 15000) return;
+    plan.tr2_bound = (int)R2;
     plan.tr2_xlim = (int)(15000 / 4 - 4);
     const int QM = (plan.Lmax + 63) / 64;
     plan.tr2_qm = QM;

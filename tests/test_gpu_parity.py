@@ -174,6 +174,11 @@ def test_full_c2_sample_of_200_reads_equals_the_reference_binary(tmp_path):
         rc, want, err = ob.run_ref_dp(rfa, mfa, threads=8)
         assert rc == 0, err.decode()[-500:]
     else:
+        # Not silently: without the reference binary this is only a comparison with the C restatement (which
+        # tests/test_oracle.py pins against the binary's fixtures) -- it is said so, and SD_REQUIRE_REF=1 turns it into a failure
+        assert not os.environ.get("SD_REQUIRE_REF"), "oracle/_ref/dp is missing: this run cannot compare with the reference binary"
+        import warnings
+        warnings.warn("oracle/_ref/dp not built: full-size C2 compared with the C restatement of the reference only")
         ob.build()
         want = ob.decompose([rn[i] for i in sel], [rs[i] for i in sel], mn, ms, threads=8)
     mine = b"".join(b"\n".join(by_read[rn[i].encode()]) + b"\n" for i in sel)

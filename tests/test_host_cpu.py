@@ -673,6 +673,73 @@ def test_plan_range_bound_covers_the_recurrence(sc):
             assert _stored_extrema(tm, rd, sc) <= info["range_bound"], (sc, trial, info)
 
 
+def _trace_extrema(tmpls, read, sc, block=32):
+    """Largest |X| of the packed two-block traceback (sd_fast_trace2.hip) on one chunk, from the reference recurrence:
+    X = E - r*ins - base with E = D - k*del and base = the start term of the block's first computed row,
+    B(rs) + del - (rs - 1)*ins (rs = max(block start, 1)); taken over the checkpoint row above a block and the block's 32
+    rows, and over the start terms of those rows."""
+    ins, dele, mis, mat = sc
+    n = len(read)
+    rows, Bs = [], [0]
+    D = []
+    for t in tmpls:
+        row = np.empty(len(t), dtype=np.int64)
+        for k in range(len(t)):
+            s_ = mat if t[k] == read[0] else mis
+            row[k] = s_ if k == 0 else max(row[k - 1] + dele, dele * (k - 1) + s_)
+        D.append(row)
+    kd = [np.arange(len(t), dtype=np.int64) * dele for t in tmpls]
+    rows.append([D[j] - kd[j] for j in range(len(tmpls))])
+    for i in range(1, n):
+        B = max(int(d[-1]) for d in D)
+        Bs.append(B)
+        nxt = []
+        for j, t in enumerate(tmpls):
+            s_ = np.where(np.frombuffer(t, dtype=np.uint8) == read[i], mat, mis).astype(np.int64)
+            cand = B + s_ + kd[j]
+            cand[1:] = np.maximum(cand[1:], np.maximum(D[j][:-1] + s_[1:], D[j][1:] + ins))
+            nxt.append(np.maximum.accumulate(cand - kd[j]) + kd[j])
+        D = nxt
+        rows.append([D[j] - kd[j] for j in range(len(tmpls))])
+    worst = 0
+    for ab in range(0, n, block):
+        rs = max(ab, 1)
+        if rs >= n:
+            break
+        base = Bs[rs] + dele - (rs - 1) * ins
+        for r in range(max(ab - 1, 0), min(ab + block, n)):
+            worst = max(worst, max(int(np.abs(e - r * ins - base).max()) for e in rows[r]))
+            if r >= 1:
+                worst = max(worst, abs(Bs[r] + dele - (r - 1) * ins - base))
+    return worst
+
+
+@pytest.mark.parametrize("sc", [(-1, -1, -1, 1), (-2, -3, -4, 2), (0, -4, -4, -1), (-1, -5, -2, 3), (-3, -1, -6, 2), (-9, -7, -8, 9)])
+def test_plan_traceback_word_range_covers_the_recurrence(sc):
+    """The packed two-block traceback keeps cells as 16-bit words 4*(E' - base) + tag + 0x4000, exact while
+    |E' - base| stays below the bound the plan proves per template set and scoring (sd_plan_info: trace_bound; the
+    kernel also checks every checkpoint cell and start term at run time).  Same reads as the fill's range test --
+    repeats of one template, runs of an absent base, random sequence -- through the reference recurrence in numpy."""
+    st = synth.Stream(4242, sc[1] * 5 + sc[3])
+    seen = 0
+    for trial in range(4):
+        nm = 2 + trial
+        ms = [synth._to_ascii(st.below(int(st.below(1, 60)[0]) + 12, 4)) for _ in range(nm)]
+        info = lib.plan_info(ms, scoring=sc)
+        if info["family"] != "fast" or info["trace_regs"] == 0:
+            continue
+        seen += 1
+        assert 4 * info["trace_bound"] + 16 <= 15000
+        tm = ms + [synth.revcomp_bytes(m) for m in ms]
+        reads = [(ms[0] * 40)[:200], (b"A" * 90 + ms[-1] * 20)[:200],
+                 synth._to_ascii(st.below(200, 4)), (ms[0][: len(ms[0]) // 2] * 60)[:200]]
+        for rd in reads:
+            g = info["score_factor"]
+            scr = tuple(x // g for x in sc)   # the device computes with the scores divided by their common factor
+            assert _trace_extrema(tm, rd, scr) <= info["trace_bound"], (sc, trial, info)
+    assert seen or abs(sc[0]) >= 9   # (-9,-7,-8,9 leaves the 16-bit range on longer templates: the one-block form runs)
+
+
 @pytest.mark.parametrize("fail_reserve", [False, True])
 def test_file_writer_on_tmpfs_with_and_without_page_reservation(fail_reserve, tmp_path):
     """sd::write_parts (the TSV writer of sd_run_files): on tmpfs large texts go through a shared mapping, but only
