@@ -1330,6 +1330,19 @@ struct Pipeline {
     double pack_s = 0, wait_s = 0, sink_s = 0;
     int64_t launches = 0, batches = 0, rows = 0;
 
+    bool ident_ok = false;   // a cached pipeline's engines carry the identity tables of their job (run_files_impl)
+    // a pipeline kept from an earlier job with the same parameters and monomers: new borrowed arrays, fresh counters
+    void begin_job(const sd_params* pp, const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono) {
+        p.threads = pp->threads;
+        for (sd_engine* e : eng) if (e) e->p.threads = pp->threads;
+        mseq.assign(mono_seqs, mono_seqs + n_mono);
+        mlen.assign(mono_lens, mono_lens + n_mono);
+        fill_ms = trace_ms = compact_ms = run_ms = ident_ms = 0;
+        ident_pairs = 0;
+        pack_s = wait_s = sink_s = 0;
+        launches = batches = rows = 0;
+        eb[0] = 0;
+    }
     int create(const sd_params* pp, const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono) {
         p = *pp;
         apply_env_overrides(p);
@@ -1719,7 +1732,8 @@ int sd_decompose_files(const char* reads_fa, const char* monomers_fa, const sd_p
 // -------------------------------------------------------------------------------------------
 // chunk-range form: multi-GPU sharding of one job, one process per GPU
 // -------------------------------------------------------------------------------------------
-void sd_release_cache(void) { g_pool.release_all(); g_pinpool.release_all(); }
+namespace { void pipe_cache_clear(); }   // the pipelines kept from finished sd_run_files jobs (defined with run_files_impl)
+void sd_release_cache(void) { pipe_cache_clear(); g_pool.release_all(); g_pinpool.release_all(); }
 
 int64_t sd_chunk_table_size(const int64_t* read_lens, int32_t n_reads, int32_t part_size, int32_t overlap) {
     if (!read_lens || n_reads < 0 || part_size <= 0 || overlap < 0) return -1;
@@ -2353,6 +2367,41 @@ int sd_write_parts_selftest(const char* path, int32_t n_parts, int64_t part_byte
 // past the last read, [2] reads in the file, [3] chunks of this rank.  A read set that cannot be split by
 // reads (one read holds more than half a rank's share, e.g. a single chromosome) gives SD_ERR_UNSUPPORTED
 // before anything is written; the caller then shards by chunk range instead.
+// Pipelines of finished sd_run_files jobs, kept for the next job with the same parameters and monomer set: creating
+// the engines (layout plan, tables, identity masks, streams, events, pinned staging) is 25-40 ms per call, a quarter of
+// a C4 --second-best job.  A process that decomposes many read sets against one monomer set (a service behind the
+// C-ABI, bench.py's steps) pays it once; sd_release_cache() drops them.  At most two are kept.
+namespace {
+struct PipeCacheEntry { std::string key; std::unique_ptr<Pipeline> pipe; };
+std::mutex g_pc_m;
+std::vector<PipeCacheEntry> g_pc;
+std::unique_ptr<Pipeline> pipe_cache_take(const std::string& key) {
+    std::lock_guard<std::mutex> g(g_pc_m);
+    for (size_t i = 0; i < g_pc.size(); ++i)
+        if (g_pc[i].key == key) {
+            std::unique_ptr<Pipeline> q = std::move(g_pc[i].pipe);
+            g_pc.erase(g_pc.begin() + (long)i);
+            return q;
+        }
+    return nullptr;
+}
+void pipe_cache_give(const std::string& key, std::unique_ptr<Pipeline> q) {
+    std::vector<PipeCacheEntry> drop;   // destroyed outside the lock
+    {
+        std::lock_guard<std::mutex> g(g_pc_m);
+        g_pc.push_back(PipeCacheEntry{key, std::move(q)});
+        while (g_pc.size() > 2) { drop.push_back(std::move(g_pc.front())); g_pc.erase(g_pc.begin()); }
+    }
+}
+void pipe_cache_clear() {
+    std::vector<PipeCacheEntry> drop;
+    {
+        std::lock_guard<std::mutex> g(g_pc_m);
+        drop.swap(g_pc);
+    }
+}
+}  // namespace
+
 // stage times of the last sd_run_files / sd_run_files_range call of this process (sd_last_run_stats)
 static std::mutex g_last_m;
 static double g_last_run[24] = {0};
@@ -2466,20 +2515,33 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         set_err(errbuf, errlen, "out of host memory");
         return SD_ERR_INTERNAL;
     }
-    Pipeline pipe;
     // identities of the final TSV in-stream, behind every batch's compaction (sd_ident.hip); template sets the kernel
     // does not take (and SD_IDENT_STREAM=0, developer A/B) leave them to the post-processing as in round 2
     bool stream_ident;
+    std::string pkey;
     {
         sd_params pe = *p;
         apply_env_overrides(pe);
         stream_ident = !(pe.reserved[1] & SD_FLAG_NO_STREAM_IDENT);
+        pe.threads = 0;   // (host threads do not shape an engine)
+        pkey.assign(reinterpret_cast<const char*>(&pe), sizeof pe);
+        pkey.push_back(second_best ? '2' : '1');
+        for (const sd::Seq& m : monos) { pkey.append(m.seq); pkey.push_back('\n'); }
     }
+    std::unique_ptr<Pipeline> pipe_h = getenv("SD_PIPE_CACHE_OFF") ? nullptr : pipe_cache_take(pkey);
+    const bool reused = pipe_h != nullptr;
+    if (!pipe_h) pipe_h.reset(new Pipeline);
+    Pipeline& pipe = *pipe_h;
     pipe.on_engine = [&](sd_engine* e) {
         if (stream_ident && !engine_set_identity(e, pp.interleaved_seqs(), pp.own_interleaved(), second_best != 0)) stream_ident = false;
     };
-    rc = pipe.create(p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size());
-    if (rc) err = pipe.eb;
+    if (reused) {
+        pipe.begin_job(p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size());
+        stream_ident = stream_ident && pipe.ident_ok;
+    } else {
+        rc = pipe.create(p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size());
+        if (rc) err = pipe.eb;
+    }
     if (stream_ident) job.per = second_best ? (int)pp.interleaved_seqs().size() : 1;
     std::vector<std::pair<size_t, size_t>> batches;
     // --second-best makes the host side of a batch (2T identities' worth of text per row) as long as its kernels: a job
@@ -2667,6 +2729,9 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         std::fprintf(stderr, "[sd timing] identities on the device: preparation + staging %.1f ms, uploads %.1f ms, launch %.1f ms, "
                      "kernel + downloads %.1f ms\n", nw[0] * 1e3, nw[1] * 1e3, nw[2] * 1e3, nw[3] * 1e3);
     }
+    pipe.ident_ok = stream_ident;
+    pipe.on_engine = nullptr;   // (it refers to this call's locals)
+    if (rc == SD_OK && !getenv("SD_PIPE_CACHE_OFF")) pipe_cache_give(pkey, std::move(pipe_h));
     if (rc) { set_err(errbuf, errlen, err); return rc; }
     return SD_OK;
 }
