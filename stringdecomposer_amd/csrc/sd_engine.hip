@@ -1533,6 +1533,41 @@ void plan_batches(const std::vector<CRef>& table, size_t c_lo, size_t c_hi, int6
 }
 }  // namespace
 
+// Pipelines of finished jobs (sd_run_files, the chunk-range calls), kept for the next job with the same parameters and monomer set: creating
+// the engines (layout plan, tables, identity masks, streams, events, pinned staging) is 25-40 ms per call, a quarter of
+// a C4 --second-best job.  A process that decomposes many read sets against one monomer set (a service behind the
+// C-ABI, bench.py's steps) pays it once; sd_release_cache() drops them.  At most two are kept.
+namespace {
+struct PipeCacheEntry { std::string key; std::unique_ptr<Pipeline> pipe; };
+std::mutex g_pc_m;
+std::vector<PipeCacheEntry> g_pc;
+std::unique_ptr<Pipeline> pipe_cache_take(const std::string& key) {
+    std::lock_guard<std::mutex> g(g_pc_m);
+    for (size_t i = 0; i < g_pc.size(); ++i)
+        if (g_pc[i].key == key) {
+            std::unique_ptr<Pipeline> q = std::move(g_pc[i].pipe);
+            g_pc.erase(g_pc.begin() + (long)i);
+            return q;
+        }
+    return nullptr;
+}
+void pipe_cache_give(const std::string& key, std::unique_ptr<Pipeline> q) {
+    std::vector<PipeCacheEntry> drop;   // destroyed outside the lock
+    {
+        std::lock_guard<std::mutex> g(g_pc_m);
+        g_pc.push_back(PipeCacheEntry{key, std::move(q)});
+        while (g_pc.size() > 2) { drop.push_back(std::move(g_pc.front())); g_pc.erase(g_pc.begin()); }
+    }
+}
+void pipe_cache_clear() {
+    std::vector<PipeCacheEntry> drop;
+    {
+        std::lock_guard<std::mutex> g(g_pc_m);
+        drop.swap(g_pc);
+    }
+}
+}  // namespace
+
 // Runs the chunks [c_lo, c_hi) of `table` through the device in batches of consecutive chunks sized to
 // the free HBM, so a single 200-Mb sequence and a million reads take the same path; the records of
 // every batch go to `sink(c0, c1, recs, rec_off)` in table order (chunk-local coordinates, rec_off
@@ -1543,8 +1578,24 @@ static int run_chunk_batches(const std::vector<ReadView>& reads, const std::vect
                              const BatchSink& sink) {
     const bool timing = getenv("SD_TIMING") != nullptr;  // developer knob: stage times on stderr
     const double t_begin = now_s();
-    Pipeline pipe;
-    int rc = pipe.create(p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size());
+    std::string pkey;
+    {
+        sd_params pe = *p;
+        apply_env_overrides(pe);
+        pe.threads = 0;
+        pkey.assign(reinterpret_cast<const char*>(&pe), sizeof pe);
+        pkey.push_back('C');
+        for (size_t m = 0; m < ts.mseq.size(); ++m) { pkey.append(ts.mseq[m], (size_t)ts.mlen[m]); pkey.push_back('\n'); }
+    }
+    std::unique_ptr<Pipeline> pipe_h = getenv("SD_PIPE_CACHE_OFF") ? nullptr : pipe_cache_take(pkey);
+    int rc = SD_OK;
+    if (pipe_h) {
+        pipe_h->begin_job(p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size());
+    } else {
+        pipe_h.reset(new Pipeline);
+        rc = pipe_h->create(p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size());
+    }
+    Pipeline& pipe = *pipe_h;
     if (rc) { err = pipe.eb; return rc; }
     std::vector<std::pair<size_t, size_t>> batches;
     plan_batches(table, c_lo, c_hi, pipe.row_budget(), 1, batches);
@@ -1567,6 +1618,7 @@ static int run_chunk_batches(const std::vector<ReadView>& reads, const std::vect
         std::fprintf(stderr, "[sd timing] %zu batches: pack+enqueue %.1f ms, wait %.1f ms, sink %.1f ms, kernels fill %.1f "
                      "trace %.1f compact %.2f ms, total %.1f ms\n", batches.size(), pipe.pack_s * 1e3, pipe.wait_s * 1e3,
                      pipe.sink_s * 1e3, pipe.fill_ms, pipe.trace_ms, pipe.compact_ms, (now_s() - t_begin) * 1e3);
+    if (rc == SD_OK && !getenv("SD_PIPE_CACHE_OFF")) pipe_cache_give(pkey, std::move(pipe_h));
     return rc;
 }
 
@@ -1732,7 +1784,6 @@ int sd_decompose_files(const char* reads_fa, const char* monomers_fa, const sd_p
 // -------------------------------------------------------------------------------------------
 // chunk-range form: multi-GPU sharding of one job, one process per GPU
 // -------------------------------------------------------------------------------------------
-namespace { void pipe_cache_clear(); }   // the pipelines kept from finished sd_run_files jobs (defined with run_files_impl)
 void sd_release_cache(void) { pipe_cache_clear(); g_pool.release_all(); g_pinpool.release_all(); }
 
 int64_t sd_chunk_table_size(const int64_t* read_lens, int32_t n_reads, int32_t part_size, int32_t overlap) {
@@ -2367,41 +2418,6 @@ int sd_write_parts_selftest(const char* path, int32_t n_parts, int64_t part_byte
 // past the last read, [2] reads in the file, [3] chunks of this rank.  A read set that cannot be split by
 // reads (one read holds more than half a rank's share, e.g. a single chromosome) gives SD_ERR_UNSUPPORTED
 // before anything is written; the caller then shards by chunk range instead.
-// Pipelines of finished sd_run_files jobs, kept for the next job with the same parameters and monomer set: creating
-// the engines (layout plan, tables, identity masks, streams, events, pinned staging) is 25-40 ms per call, a quarter of
-// a C4 --second-best job.  A process that decomposes many read sets against one monomer set (a service behind the
-// C-ABI, bench.py's steps) pays it once; sd_release_cache() drops them.  At most two are kept.
-namespace {
-struct PipeCacheEntry { std::string key; std::unique_ptr<Pipeline> pipe; };
-std::mutex g_pc_m;
-std::vector<PipeCacheEntry> g_pc;
-std::unique_ptr<Pipeline> pipe_cache_take(const std::string& key) {
-    std::lock_guard<std::mutex> g(g_pc_m);
-    for (size_t i = 0; i < g_pc.size(); ++i)
-        if (g_pc[i].key == key) {
-            std::unique_ptr<Pipeline> q = std::move(g_pc[i].pipe);
-            g_pc.erase(g_pc.begin() + (long)i);
-            return q;
-        }
-    return nullptr;
-}
-void pipe_cache_give(const std::string& key, std::unique_ptr<Pipeline> q) {
-    std::vector<PipeCacheEntry> drop;   // destroyed outside the lock
-    {
-        std::lock_guard<std::mutex> g(g_pc_m);
-        g_pc.push_back(PipeCacheEntry{key, std::move(q)});
-        while (g_pc.size() > 2) { drop.push_back(std::move(g_pc.front())); g_pc.erase(g_pc.begin()); }
-    }
-}
-void pipe_cache_clear() {
-    std::vector<PipeCacheEntry> drop;
-    {
-        std::lock_guard<std::mutex> g(g_pc_m);
-        drop.swap(g_pc);
-    }
-}
-}  // namespace
-
 // stage times of the last sd_run_files / sd_run_files_range call of this process (sd_last_run_stats)
 static std::mutex g_last_m;
 static double g_last_run[24] = {0};
