@@ -246,12 +246,14 @@ struct FairShare {
         const int sm = lane < nw ? simd[lane] : -1;
         mates = __ballot(sm == (int)hw && lane != wave);
     }
+    bool drained = false;   // the chunk queue was empty at the last update: the launch is in its last round
     __device__ __forceinline__ void update(int remaining) {
         if (lane == 0) __hip_atomic_store(prog + wave, remaining, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const int v = __hip_atomic_load(prog + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // only while no wave can pull another chunk (the end of the launch): before that a wave that is done simply
         // takes the next chunk and priorities would only serialise the SIMD's waves
         const int head = __builtin_amdgcn_readfirstlane(__hip_atomic_load(queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        drained = head >= n_chunks;
         if (head < n_chunks) { __builtin_amdgcn_s_setprio(0); return; }
         const int rank = __popcll(__ballot(v < remaining) & mates);   // mates with fewer rows left
         if (rank == 0) __builtin_amdgcn_s_setprio(0);

@@ -73,9 +73,11 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     ReadStream rs;
     rs.init(bases2 + cd.woff, cd.noff >= 0 ? nmask + cd.noff : nullptr, n);
     // The carry scan through ds_bpermute trades seven VALU instructions per row for three crossbar round trips: a gain
-    // while four waves keep a SIMD's issue slots busy, a loss in the launch's last round, when the SIMDs empty out and
-    // a wave's own latency is what is left (there the DPP form stays)
-    const bool bperm_scan = bperm_ok && (!sched.last_round() || ((Hx >> 9) & 1));
+    // while four waves keep a SIMD's issue slots busy, a loss once the chunk queue is empty and the SIMDs empty out --
+    // a wave's own latency is what is left then, and the DPP form takes over
+    // (decided again every 32 rows from the state of the chunk queue, FairShare::update: the SIMDs stay full while
+    // waves that finish still find chunks)
+    bool bperm_scan = bperm_ok && (!fair.drained || ((Hx >> 9) & 1));
 
     const uint32_t* lc = lane_consts + lane * FAST_LANE_WORDS;
     const uint32_t startMask = lc[FLC_STARTMASK];
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     for (int i = 1; i < n; ++i) {
         if ((i & (FAST_R - 1)) == 0) {
             fair.update(n - i);
+            bperm_scan = bperm_ok && (!fair.drained || ((Hx >> 9) & 1));
             if ((i & (FAST_REBASE - 1)) == 0) {
                 // rebase the int16 state on B_i and fold the row offset tp*ins back in
                 if constexpr (HRED)

@@ -767,3 +767,34 @@ def test_file_writer_on_tmpfs_with_and_without_page_reservation(fail_reserve, tm
         finally:
             if os.path.exists(path):
                 os.unlink(path)
+
+
+def test_alphabet_check_vector_path_names_the_first_bad_byte(tmp_path):
+    """The alphabet check (main.cpp:329-341: the first symbol outside ACGTN of the first offending sequence, exit -1)
+    runs 32 bytes per step where AVX2 is available and hands the offending stretch to the scalar loop: the message must
+    name the same byte wherever it sits -- in a full vector, in the scalar tail, right behind a vector boundary -- for
+    lower case, CR, NUL-free control bytes and bytes with the top bit set; N alone is not an error and is reported."""
+    st = synth.Stream(77, 5)
+    for n in (63, 64, 65, 96, 100, 333, 5000):
+        base = bytearray(synth._ACGT[st.below(n, 4)].tobytes())
+        ok = tmp_path / ("ok%d.fa" % n)
+        ok.write_bytes(b">r\n" + bytes(base) + b"\n")
+        assert lib.fasta_load(str(ok))[2] is False
+        for pos in sorted({0, 1, 31, 32, 33, 62, 63, n // 2, n - 2, n - 1} & set(range(n))):
+            for bad in (b"a", b"\r", b"\x01", b"\xc1", b"M", b"U"):
+                b = bytearray(base)
+                b[pos:pos + 1] = bad
+                if pos + 40 < n:
+                    b[pos + 40] = ord("z")          # a later offender must not be the one reported
+                p = tmp_path / "bad.fa"
+                p.write_bytes(b">r1\n" + bytes(b) + b"\n")
+                with pytest.raises(lib.SdError) as ei:
+                    lib.fasta_load(str(p))
+                assert ei.value.code == lib.SD_ERR_SYMBOL
+                assert ei.value.msg.encode(errors="surrogateescape").endswith(b"(not ACGT): " + bad) or \
+                    ei.value.msg.endswith("(not ACGT): " + bad.decode(errors="replace")), (n, pos, bad, ei.value.msg)
+            b = bytearray(base)
+            b[pos] = ord("N")
+            p = tmp_path / "n.fa"
+            p.write_bytes(b">r1\n" + bytes(b) + b"\n")
+            assert lib.fasta_load(str(p))[2] is True
