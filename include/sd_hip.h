@@ -135,6 +135,13 @@ int sd_convert_raw_tsv(const char* raw_tsv, const char* reads_fa, const char* mo
                        const char* final_tsv_out, const char* alt_tsv_out, int32_t min_identity,
                        int32_t second_best, const double* lr_coef, int32_t device, int32_t threads,
                        char* errbuf, size_t errlen);
+/* The same for one rank of a multi-process launch: the rows of the raw TSV that begin in this rank's byte range (world
+ * ranges cut at line starts) into this rank's own part files; rows are independent (main.py:95-150), so the parts
+ * concatenated in rank order are the files sd_convert_raw_tsv writes (shard.convert_sharded does that). */
+int sd_convert_raw_tsv_range(const char* raw_tsv, const char* reads_fa, const char* monomers_fa,
+                             const char* final_tsv_out, const char* alt_tsv_out, int32_t min_identity,
+                             int32_t second_best, const double* lr_coef, int32_t device, int32_t threads,
+                             int32_t rank, int32_t world, char* errbuf, size_t errlen);
 
 /* ---- chunk-range form: one job sharded over several GPUs, one process per GPU ---------------
  * The chunks of a read set (main.cpp:70-81, all reads, input order) form one global table; a chunk's

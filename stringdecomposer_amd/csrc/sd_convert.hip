@@ -353,15 +353,20 @@ int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd
 // convert_tsv (main.py:168-184) as one native call: raw TSV file + the two FASTA files -> final TSV
 // and _alt TSV files, streamed in batches of reads.
 // ---------------------------------------------------------------------------------------------
-extern "C" int sd_convert_raw_tsv(const char* raw_tsv, const char* reads_fa, const char* monomers_fa,
-                                  const char* final_tsv_out, const char* alt_tsv_out, int32_t min_identity,
-                                  int32_t second_best, const double* lr_coef, int32_t device, int32_t threads,
-                                  char* errbuf, size_t errlen) {
+// convert_tsv on the rows of the raw TSV that begin in the byte range of `rank` (of `world` ranges cut at line starts:
+// range g begins behind the first line end at or after byte size*g/world - 1).  Rows are independent of each other
+// (convert_read, main.py:107-150, and classify, :95-104, work row by row), so the final / _alt texts of the ranges,
+// concatenated in rank order, are the texts of the whole file.
+static int convert_impl(const char* raw_tsv, const char* reads_fa, const char* monomers_fa,
+                        const char* final_tsv_out, const char* alt_tsv_out, int32_t min_identity,
+                        int32_t second_best, const double* lr_coef, int32_t device, int32_t threads,
+                        int32_t rank, int32_t world, char* errbuf, size_t errlen) {
     auto fail = [&](int rc, const std::string& m) {
         if (errbuf && errlen) std::snprintf(errbuf, errlen, "%s", m.c_str());
         return rc;
     };
     if (!raw_tsv || !reads_fa || !monomers_fa || !final_tsv_out || !alt_tsv_out || !lr_coef) return fail(SD_ERR_PARAM, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(SD_ERR_PARAM, "bad rank / world");
     std::string err;
     sd::FastaFile rf, mf;
     int rc = rf.open(reads_fa, threads, err);
@@ -415,13 +420,38 @@ extern "C" int sd_convert_raw_tsv(const char* raw_tsv, const char* reads_fa, con
         row_off.assign(1, 0);
         return SD_OK;
     };
+    // this rank's byte range [lo, hi) of the raw file, cut at line starts
+    int64_t lo = 0, hi = 0;
+    {
+        std::fseek(fr, 0, SEEK_END);
+        const int64_t size = (int64_t)std::ftell(fr);
+        auto bound = [&](int g) -> int64_t {
+            if (g <= 0) return 0;
+            if (g >= world) return size;
+            int64_t at = size / world * g + size % world * g / world;
+            if (at <= 0) return 0;
+            std::fseek(fr, (long)(at - 1), SEEK_SET);
+            int ch;
+            int64_t q = at - 1;
+            while ((ch = std::fgetc(fr)) != EOF) {
+                ++q;
+                if (ch == '\n') return q;
+            }
+            return size;
+        };
+        lo = bound(rank);
+        hi = bound(rank + 1);
+        std::fseek(fr, (long)lo, SEEK_SET);
+    }
+    int64_t pos = lo;
     char* line = nullptr;
     size_t cap = 0;
     ssize_t got;
     std::string prev;
     bool have_prev = false;
     const int64_t batch_blocks = second_best ? 65536 : 1 << 20;
-    while (rc == SD_OK && (got = getline(&line, &cap, fr)) > 0) {
+    while (rc == SD_OK && pos < hi && (got = getline(&line, &cap, fr)) > 0) {
+        pos += got;
         if (line[got - 1] != '\n') break;   // decomposition.split("\n")[:-1] drops an unterminated last line
         // read \t monomer \t start \t end ...
         const char* f[5];
@@ -482,4 +512,20 @@ extern "C" int sd_convert_raw_tsv(const char* raw_tsv, const char* reads_fa, con
     if (rc == SD_OK && !(wf && wa)) { rc = SD_ERR_IO; err = std::string("short write to ") + final_tsv_out; }
     if (rc) return fail(rc, err);
     return SD_OK;
+}
+
+extern "C" int sd_convert_raw_tsv(const char* raw_tsv, const char* reads_fa, const char* monomers_fa,
+                                  const char* final_tsv_out, const char* alt_tsv_out, int32_t min_identity,
+                                  int32_t second_best, const double* lr_coef, int32_t device, int32_t threads,
+                                  char* errbuf, size_t errlen) {
+    return convert_impl(raw_tsv, reads_fa, monomers_fa, final_tsv_out, alt_tsv_out, min_identity, second_best, lr_coef, device,
+                        threads, 0, 1, errbuf, errlen);
+}
+
+extern "C" int sd_convert_raw_tsv_range(const char* raw_tsv, const char* reads_fa, const char* monomers_fa,
+                                        const char* final_tsv_out, const char* alt_tsv_out, int32_t min_identity,
+                                        int32_t second_best, const double* lr_coef, int32_t device, int32_t threads,
+                                        int32_t rank, int32_t world, char* errbuf, size_t errlen) {
+    return convert_impl(raw_tsv, reads_fa, monomers_fa, final_tsv_out, alt_tsv_out, min_identity, second_best, lr_coef, device,
+                        threads, rank, world, errbuf, errlen);
 }

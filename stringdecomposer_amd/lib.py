@@ -34,7 +34,7 @@ EXPORTS = [
     "sd_stream_create", "sd_stream_destroy", "sd_stream_submit", "sd_stream_collect", "sd_stream_stats",
     "sd_stream_info", "sd_pack_bases", "sd_identity_segments_dev", "sd_nw_release_cache", "sd_last_run_stats", "sd_guard_trips",
     "sd_run_files", "sd_convert_raw_tsv", "sd_decompose_files_range", "sd_assemble_files_tsv",
-    "sd_host_stage_rates", "sd_run_files_range", "sd_plan_info", "sd_write_parts_selftest",
+    "sd_host_stage_rates", "sd_run_files_range", "sd_plan_info", "sd_write_parts_selftest", "sd_convert_raw_tsv_range",
 ]
 
 
@@ -280,6 +280,19 @@ def convert_raw_tsv(raw_tsv, reads_fa, monomers_fa, final_tsv_out, alt_tsv_out, 
     rc = L.sd_convert_raw_tsv(os.fsencode(raw_tsv), os.fsencode(reads_fa), os.fsencode(monomers_fa),
                               os.fsencode(final_tsv_out), os.fsencode(alt_tsv_out), int(min_identity),
                               1 if second_best else 0, coef, int(device), int(threads), err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+
+
+def convert_raw_tsv_range(raw_tsv, reads_fa, monomers_fa, final_tsv_out, alt_tsv_out, rank, world, min_identity=0,
+                          second_best=False, lr_coef=(-31.48494996, 0.41784018, 0.69186882), device=-1, threads=1):
+    """convert_tsv on this rank's byte range of the raw TSV (cut at line starts) into this rank's part files."""
+    L = load()
+    err = C.create_string_buffer(4096)
+    coef = (C.c_double * 3)(*[float(x) for x in lr_coef])
+    rc = L.sd_convert_raw_tsv_range(os.fsencode(raw_tsv), os.fsencode(reads_fa), os.fsencode(monomers_fa),
+                                    os.fsencode(final_tsv_out), os.fsencode(alt_tsv_out), int(min_identity),
+                                    1 if second_best else 0, coef, int(device), int(threads), int(rank), int(world), err, 4096)
     if rc != SD_OK:
         raise SdError(rc, err.value.decode(errors="replace"))
 

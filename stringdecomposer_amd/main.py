@@ -389,8 +389,16 @@ def run(sequences, monomers, num_threads, scoring, batch_size, raw_file, ed_thr,
                                              second_best=second_best, lr_coef=_lr_coef(), **common)
             if ok is True:
                 return True if rank == 0 else None
-            # a single huge sequence (or no final file wanted): shard by chunk range, rank 0 assembles
+            # a single huge sequence (or no final file wanted): shard by chunk range, rank 0 assembles the raw TSV
             ok = shard.decompose_files_sharded(sequences, monomers, raw_file, dist, **common)
+            if final_file is not None:
+                # ... and convert_tsv (main.py:168-184) is shared again: every rank converts the rows of its byte range of
+                # the raw file (identities on its own GPU), the parts are copied into the final / _alt files
+                shard.barrier(dist)   # the raw file is complete
+                shard.convert_sharded(raw_file, sequences, monomers, final_file, final_file[:-len(".tsv")] + "_alt.tsv", dist,
+                                      min_identity=min_identity, second_best=second_best, lr_coef=_lr_coef(), device=dev,
+                                      threads=max(1, int(num_threads)))
+                return True if rank == 0 else None
         finally:
             shard.barrier(dist)
             dist.destroy_process_group()

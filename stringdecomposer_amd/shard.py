@@ -253,6 +253,60 @@ def _copy_into(src, dst, offset):
         raise IOError("short copy of %s" % src)
 
 
+def _assemble_parts(dist, rank, ws, outs, parts):
+    """Every rank holds one part file per output: sizes are exchanged, rank 0 creates the outputs at their final
+    size, then all ranks copy their parts in at their offsets.  Every step that can fail locally reports through the
+    status exchange (raised on every rank)."""
+    sizes, failure = [None] * ws, None
+    try:
+        mine = [os.path.getsize(p) for p in parts]
+    except Exception as e:
+        mine, failure = None, _status_of(e)
+    dist.all_gather_object(sizes, mine)
+    if failure is None and rank == 0 and all(sz is not None for sz in sizes):
+        try:
+            for k, p in enumerate(outs):
+                with open(p, "wb") as f:
+                    f.truncate(sum(sz[k] for sz in sizes))
+        except Exception as e:
+            failure = _status_of(e)
+    _raise_first(dist, ws, failure)     # also the barrier in front of the copies
+    try:
+        for k, p in enumerate(outs):
+            _copy_into(parts[k], p, sum(sz[k] for sz in sizes[:rank]))
+    except Exception as e:
+        failure = _status_of(e)
+    _raise_first(dist, ws, failure)
+
+
+def convert_sharded(raw_tsv, reads_fa, monomers_fa, final_out, alt_out, dist, conv_fn=None, **params):
+    """convert_tsv (main.py:168-184) of a raw TSV that rank 0 has written, by ALL ranks: every rank converts the rows
+    that begin in its byte range of the raw file (sd_convert_raw_tsv_range: ranges cut at line starts; rows are
+    independent) into part files, which are then copied into the final / _alt files at their offsets.  The job of
+    one huge sequence (chunk-range sharding) no longer leaves its whole post-processing to rank 0.  A failure on any
+    rank is raised on every rank; no .partN file stays behind.  Returns True."""
+    from . import lib
+    rank, local_rank, ws = world()
+    fn = conv_fn or lib.convert_raw_tsv_range
+    outs = [final_out, alt_out]
+    parts = ["%s.part%d" % (p, rank) for p in outs]
+    failure = None
+    try:
+        try:
+            fn(raw_tsv, reads_fa, monomers_fa, parts[0], parts[1], rank, ws, **params)
+        except Exception as e:
+            failure = _status_of(e)
+        _raise_first(dist, ws, failure)
+        _assemble_parts(dist, rank, ws, outs, parts)
+        return True
+    finally:
+        for p in parts:
+            try:
+                os.remove(p)
+            except OSError:
+                pass
+
+
 def run_files_sharded(reads_fa, monomers_fa, raw_out, final_out, alt_out, dist, run_fn=None, **params):
     """The multi-process command line on a set of reads: the reads are dealt to the ranks in contiguous groups of
     about equal chunk counts and EVERY rank runs its group completely on its GPU -- DP, identities, raw / final /
@@ -282,26 +336,7 @@ def run_files_sharded(reads_fa, monomers_fa, raw_out, final_out, alt_out, dist, 
                 return "unsplittable"
             raise lib.SdError(*first)
         # every later step that can fail locally (stat, truncate, copy) reports through the same exchange
-        sizes, failure = [None] * ws, None
-        try:
-            mine = [os.path.getsize(p) for p in parts]
-        except Exception as e:
-            mine, failure = None, _status_of(e)
-        dist.all_gather_object(sizes, mine)
-        if failure is None and rank == 0 and all(sz is not None for sz in sizes):
-            try:
-                for k, p in enumerate(outs):
-                    with open(p, "wb") as f:
-                        f.truncate(sum(sz[k] for sz in sizes))
-            except Exception as e:
-                failure = _status_of(e)
-        _raise_first(dist, ws, failure)     # also the barrier in front of the copies
-        try:
-            for k, p in enumerate(outs):
-                _copy_into(parts[k], p, sum(sz[k] for sz in sizes[:rank]))
-        except Exception as e:
-            failure = _status_of(e)
-        _raise_first(dist, ws, failure)
+        _assemble_parts(dist, rank, ws, outs, parts)
         return True
     finally:
         for p in parts:   # whatever happened, no .partN file stays behind

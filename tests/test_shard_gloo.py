@@ -371,3 +371,82 @@ def test_strong_scaling_shares_world_size_2():
     assert n_chunks == len(lib.chunk_plan(2_000_123, 5000, 500))
     assert res[0][2] == ("chunks", 0, (n_chunks + 1) // 2, n_chunks) and res[1][2] == ("chunks", (n_chunks + 1) // 2, n_chunks, n_chunks)
     assert all(abs(r[3] - 500.0) < 1e-9 for r in res)
+
+
+def _convert_worker(rank, ws, port, q, d, second_best):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ws),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from stringdecomposer_amd import lib
+    dist = shard.init_process_group("gloo")
+    tag = "sb" if second_best else "light"
+    try:
+        shard.convert_sharded(os.path.join(d, "raw.tsv"), os.path.join(d, "r.fa"), os.path.join(d, "m.fa"),
+                              os.path.join(d, "final_%s.tsv" % tag), os.path.join(d, "alt_%s.tsv" % tag), dist,
+                              second_best=second_best, device=-1, threads=2)
+        # a failure on ONE rank (its raw file is missing) is everybody's
+        try:
+            shard.convert_sharded(os.path.join(d, "raw.tsv") if rank != 1 else os.path.join(d, "nope.tsv"),
+                                  os.path.join(d, "r.fa"), os.path.join(d, "m.fa"), os.path.join(d, "x.tsv"),
+                                  os.path.join(d, "xa.tsv"), dist, second_best=second_best, device=-1, threads=1)
+            q.put((rank, "no error"))
+        except lib.SdError as e:
+            q.put((rank, e.code))
+    finally:
+        shard.barrier(dist)
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("second_best", [False, True])
+def test_convert_tsv_shared_by_three_ranks_equals_one_process(tmp_path, second_best):
+    """SURVEY 8(e) / VERDICT r03 item 3c: the job of one huge sequence is sharded by chunk range, rank 0 assembles the raw
+    TSV -- and convert_tsv (main.py:168-184) is then shared again: every rank converts the rows that begin in its byte
+    range of the raw file (rows are independent, main.py:95-150) into part files, copied into the final / _alt files at
+    their offsets.  Three gloo ranks (host identities, no device) against the same conversion in one process, on the raw
+    rows of the reference's test read (ONE read: every range is a piece of it); a failure on one rank is raised on all,
+    and no part file stays behind."""
+    import shutil
+    from conftest import GOLDEN
+    from stringdecomposer_amd import lib
+    from oracle import binding as oracle
+    d = str(tmp_path)
+    shutil.copy(os.path.join(GOLDEN, "test_data", "read.fa"), os.path.join(d, "r.fa"))
+    shutil.copy(os.path.join(GOLDEN, "test_data", "DXZ1_star_monomers.fa"), os.path.join(d, "m.fa"))
+    raw = oracle.decompose_files(os.path.join(d, "r.fa"), os.path.join(d, "m.fa"), threads=8)
+    with open(os.path.join(d, "raw.tsv"), "wb") as f:
+        f.write(raw)
+    tag = "sb" if second_best else "light"
+    lib.convert_raw_tsv(os.path.join(d, "raw.tsv"), os.path.join(d, "r.fa"), os.path.join(d, "m.fa"),
+                        os.path.join(d, "one_final.tsv"), os.path.join(d, "one_alt.tsv"), second_best=second_best,
+                        device=-1, threads=4)
+    ws, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_convert_worker, args=(r, ws, port, q, d, second_best)) for r in range(ws)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(ws))
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [lib.SD_ERR_IO] * ws
+    for a, b in (("one_final.tsv", "final_%s.tsv" % tag), ("one_alt.tsv", "alt_%s.tsv" % tag)):
+        with open(os.path.join(d, a), "rb") as fa, open(os.path.join(d, b), "rb") as fb:
+            one, many = fa.read(), fb.read()
+        assert one == many and (one or a == "one_alt.tsv")
+    assert open(os.path.join(d, "one_final.tsv"), "rb").read().count(b"\n") == 557
+    assert not any(".part" in f for f in os.listdir(d))
+    # byte ranges that cut lines anywhere: 1..7 ranges of a small file tile it exactly (one process, no exchange)
+    small = raw[: raw.index(b"\n", 3000) + 1]
+    with open(os.path.join(d, "small.tsv"), "wb") as f:
+        f.write(small)
+    lib.convert_raw_tsv(os.path.join(d, "small.tsv"), os.path.join(d, "r.fa"), os.path.join(d, "m.fa"),
+                        os.path.join(d, "s_final.tsv"), os.path.join(d, "s_alt.tsv"), second_best=second_best, device=-1)
+    want = open(os.path.join(d, "s_final.tsv"), "rb").read()
+    for w in (1, 2, 5, 7, 64):
+        got = b""
+        for g in range(w):
+            lib.convert_raw_tsv_range(os.path.join(d, "small.tsv"), os.path.join(d, "r.fa"), os.path.join(d, "m.fa"),
+                                      os.path.join(d, "p_final.tsv"), os.path.join(d, "p_alt.tsv"), g, w,
+                                      second_best=second_best, device=-1)
+            got += open(os.path.join(d, "p_final.tsv"), "rb").read()
+        assert got == want, w
