@@ -464,6 +464,9 @@ static int engine_pick_family(sd_engine* e, bool allow_f16, std::string& err) {
         }
         // run-time guard of the fp16 cell formats (sd_fast_dev.hpp: F16Guard); reserved[2]: a smaller limit (tests)
         e->sc.guard_lim = p->reserved[2] > 0 ? p->reserved[2] : 2040;
+        // the same hook lowers the range check of the packed traceback's 16-bit words (its own run-time guard: a
+        // checkpoint cell or start term beyond it raises the same flag, and the batch is repeated with sd_fast_trace)
+        if (p->reserved[2] > 0 && e->fplan.tr2_ok) e->fplan.tr2_xlim = std::min(e->fplan.tr2_xlim, (int)p->reserved[2]);
         e->d_guard.alloc(1);
         SD_HIP(hipMemset(e->d_guard.p, 0, sizeof(int)));
         e->sc.guard_flag = e->d_guard.p;

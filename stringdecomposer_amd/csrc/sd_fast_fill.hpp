@@ -356,15 +356,16 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
         const uint32_t a = F16 ? L[P - 1] : CO::mx(L[P - 1], K);  // fp16: K already joined the chain
         ++tp;
         if constexpr (HRED) {
+            // the scan's three crossbar trips run under the DPP chain of the B reduction (both need only `a`); the
+            // reduction is ONE piece of code for both scan forms (its accumulator stays in one register)
+            uint32_t t1 = 0;
+            if (bperm_scan) t1 = (uint32_t)__builtin_amdgcn_ds_bpermute(bp1, (int)a);
+            reduce_ends(a, i + 1);
             if (bperm_scan) {
-                // the scan's three crossbar trips run under the DPP chain of the B reduction (both need only `a`)
-                const uint32_t t1 = (uint32_t)__builtin_amdgcn_ds_bpermute(bp1, (int)a);
-                reduce_ends(a, i + 1);
                 const uint32_t i1 = CO::mx(a, t1);
                 const uint32_t i2 = CO::mx(i1, (uint32_t)__builtin_amdgcn_ds_bpermute(bp2, (int)i1));
                 K = (uint32_t)__builtin_amdgcn_ds_bpermute(bp1, (int)i2);
             } else {
-                reduce_ends(a, i + 1);
                 K = excl_scan(a);
             }
         } else {

@@ -852,6 +852,25 @@ def test_f16_range_guard_trips_and_the_batch_is_repeated_with_integer_cells(orac
 
 
 @pytest.mark.gpu
+def test_traceback_word_range_guard_trips_and_the_batch_is_repeated_with_the_one_block_form(oracle):
+    """The packed two-block traceback checks at run time that every checkpoint cell and start term it turns into a
+    16-bit word lies inside the range the plan proved (sd_fast_trace2.hip).  With integer cells in the fill (no fp16
+    guard there) and a limit any input exceeds (sd_params.reserved[2], the test hook) only the traceback's check can
+    trip: the engine repeats the batch with sd_fast_trace and the rows still equal the oracle's."""
+    mn, ms = synth.make_monomers(12, seed=4)
+    rn, rs = synth.make_reads(ms, 4, read_len=7000, seed=6)
+    want = oracle.decompose(rn, rs, mn, ms, threads=8)
+    e = lib.Engine(ms, flags=lib.FLAG_NO_F16, f16_guard=30)
+    assert e.info()["cells"] == "int16" and e.info()["trace"] == "two-block packed16"
+    e.close()
+    t0 = lib.guard_trips()
+    assert lib.decompose(rn, rs, mn, ms, flags=lib.FLAG_NO_F16) == want
+    assert lib.guard_trips() == t0
+    assert lib.decompose(rn, rs, mn, ms, flags=lib.FLAG_NO_F16, f16_guard=30) == want
+    assert lib.guard_trips() > t0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("second_best", [False, True])
 def test_in_stream_identities_equal_the_text_based_path_across_batches(tmp_path, second_best):
     """The identities of the final TSV come in-stream with the records of every device batch (csrc/sd_ident.hip) and
