@@ -321,7 +321,11 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         Lmin = std::min(Lmin, (int)s.size());
     }
     if (T <= 0) { why = "no templates"; return false; }
-    if (Lmin < 2) { why = "a template shorter than 2 bp"; return false; }
+    // A 1-bp template is taken in the narrow layout only: its one cell is a k = 0 cell (start term only, no insertion
+    // move, main.cpp:188-193), whose stored value may FALL from one row to the next, so the pad slots behind it -- which
+    // keep their old value like any cell with an insertion move -- cannot stand for it at the lane's last slot.  The
+    // narrow fills therefore take such a lane's end from slot 0 (FLC_ONE); the wide layouts do not (generic family).
+    const bool has1 = Lmin < 2;
     if (sc.ins > 0 || sc.del > 0) { why = "positive gap scores"; return false; }
     if (T > 65535) { why = "too many templates"; return false; }
     auto ab = [](int v) { return v < 0 ? -v : v; };
@@ -363,6 +367,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     }
     if (!cand.empty()) { P = cand[0].first; split = cand[0].second; }
     bool wide = false;
+    if (P == 0 && has1) { why = "a 1-bp template in a set that needs a wide layout"; return false; }
     if (P == 0) {
         // wide layout: one template per virtual lane
         if (T > 1024) { why = "more than 1024 templates"; return false; }
@@ -541,6 +546,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         put(lc[FLC_TMPL], plane, j >= 0 ? j : 0xffff);
         put(lc[FLC_CONT2], plane, (j >= 0 && uidx[(size_t)v] >= 2) ? 0xffff : 0);
         put(lc[FLC_ENDALL], plane, j >= 0 ? ((int)tseq[(size_t)j].size() - 1) * sc.del : NEG16);
+        put(lc[FLC_ONE], plane, (j >= 0 && tseq[(size_t)j].size() == 1) ? 0xffff : 0);
     }
     // The carry scan of the narrow fills can take its shifted operands from ds_bpermute (no VALU work, and a start lane
     // simply reads an idle lane's -inf instead of being masked) when both planes have the same segment structure --
@@ -558,6 +564,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         }
         if (same && idle >= 0) plan.Hx = plan.H | (1 << 8) | (idle << 16) | (getenv("SD_FILL_BPERM_TAIL") ? 1 << 9 : 0);   // bit 9 (developer A/B): in the last round too
     }
+    if (has1) plan.Hx |= 1 << 10;
     if (wide) {
         // int8 table [5][G][2 halves][64 lanes][4 dwords]; dword d of half h of group g holds slots
         // 16g+8h+2d, +1 as bytes {lo plane, hi plane, lo plane, hi plane}; -128 = transparent padding

@@ -32,6 +32,7 @@ enum FastLaneConst {
     FLC_TMPL,          // template index per plane (for the traceback: vlane -> template)
     FLC_CONT2,         // 0xffff where virtual lane v-2 belongs to the same template
     FLC_ENDALL,        // (L-1)*del on EVERY virtual lane of a template, NEG on idle lanes
+    FLC_ONE,           // 0xffff where the virtual lane holds a 1-bp template: its end is slot 0, not the last slot
 };
 
 struct FastPlan {
@@ -41,7 +42,8 @@ struct FastPlan {
     int P = 0;            // slots per virtual lane
     int P4 = 0;           // P rounded up to a multiple of 4 (LDS table row)
     int H = 0;            // carry hops of the cross-lane chain: Vmax-1
-    int Hx = 0;           // what the narrow fills get: H | (carry scan through ds_bpermute) << 8 | idle lane << 16
+    int Hx = 0;           // what the narrow fills get: H | (carry scan through ds_bpermute) << 8 | (scan form in the last
+                          // round too, developer A/B) << 9 | (the set has 1-bp templates) << 10 | idle lane << 16
     int T = 0;
     int split = 0;        // templates [0,split) in the lo plane
     int Lmax = 0;

@@ -268,16 +268,7 @@ __global__ __launch_bounds__(64 * TR2_NWV, 7) void sd_fast_trace_pk(
             // walk (wave-uniform)
             const int low = hasB ? aB : a0;
             while (i >= low) {
-                if (k == 0) {
-                    // the k = 0 cell holds the start term only (main.cpp:188-193); the reference's traceback still tests the
-                    // insertion there (main.cpp:245): dp[i][j][0] == dp[i-1][j][0] + ins, both sides start terms
-                    if (i == 0) return Pos{i, k, true};
-                    const int ci = rc.code(i), cp = rc.code(i - 1);
-                    const int lhs = Bof(i) + (ci == code0 ? sc.match : sc.mismatch);
-                    const int rhs = (i >= 2 ? Bof(i - 1) : 0) + (cp == code0 ? sc.match : sc.mismatch) + ins;
-                    if (lhs == rhs) { --i; continue; }
-                    return Pos{i, k, true};
-                }
+                if (k == 0) return Pos{i, k, false};   // the k = 0 cell needs no recomputed cells: the caller's rule
                 // Lane l looks at the cell l diagonal moves ahead, (i - l, k - l): the run of DIAG tags from lane 0 on is
                 // taken in one go (reads of ~90 % identity are mostly diagonal runs), then the move that ends it.
                 const int il = i - lane, kl = k - lane;
@@ -304,6 +295,17 @@ __global__ __launch_bounds__(64 * TR2_NWV, 7) void sd_fast_trace_pk(
 
         int cur = 0;
         while (true) {
+            if (k == 0) {
+                // The k = 0 cell holds the start term only (main.cpp:188-193), but the reference's traceback still tests
+                // the insertion there (main.cpp:245): dp[i][j][0] == dp[i-1][j][0] + ins, both sides start terms -- a
+                // matter of B and two read symbols, no block is recomputed for it (a 1-bp template never needs one).
+                if (i == 0) { stop_row0 = true; break; }
+                const int ci = rc.code(i), cp = rc.code(i - 1);
+                const int lhs = Bof(i) + (ci == code0 ? sc.match : sc.mismatch);
+                const int rhs = (i >= 2 ? Bof(i - 1) : 0) + (cp == code0 ? sc.match : sc.mismatch) + ins;
+                if (lhs == rhs) { --i; continue; }
+                break;   // START (stop_row0 stays false: i >= 1)
+            }
             const int need = (k >> 6) + 1;
             Pos ps;
             auto go = [&](auto qq_c) {

