@@ -712,11 +712,19 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
     const bool ranked = cendoff != nullptr;
 #define SD_FILL_K(PP, RK, HF)                                                                        \
     {                                                                                                \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, HF>),          \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-        hipLaunchKernelGGL((sd_fast_fill<PP, RK, HF>), dim3(grid), dim3(nw * 64), lds, st, chunks,    \
-                           n_chunks, bases2, nmask, table, lane_consts, sc, plan.Hx, B, argV, ckpt,  \
-                           ckbase, queue, order, cendoff, crank);                                    \
+        if (has1) {                                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, HF, PP, true>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+            hipLaunchKernelGGL((sd_fast_fill<PP, RK, HF, PP, true>), dim3(grid), dim3(nw * 64), lds, st, chunks, \
+                               n_chunks, bases2, nmask, table, lane_consts, sc, plan.Hx, B, argV, ckpt, \
+                               ckbase, queue, order, cendoff, crank);                                \
+        } else {                                                                                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, HF>),      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+            hipLaunchKernelGGL((sd_fast_fill<PP, RK, HF>), dim3(grid), dim3(nw * 64), lds, st, chunks, \
+                               n_chunks, bases2, nmask, table, lane_consts, sc, plan.Hx, B, argV, ckpt, \
+                               ckbase, queue, order, cendoff, crank);                                \
+        }                                                                                            \
     }
 #define SD_FILL(PP)                                                                                  \
     case PP:                                                                                         \
@@ -728,7 +736,8 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
         break;
     // fp16 cells, 150-200 bp monomers: the variants that skip the dominated start-term maxima (sd_fast_fl.hip);
     // FastPlan::full_floor (SD_FLAG_FULL_FLOOR) keeps the full kernel (developer A/B and the parity test of the two)
-    if (!plan.full_floor &&
+    const bool has1 = ((plan.Hx >> 10) & 1) != 0;   // 1-bp templates: the full-floor kernels carry the FLC_ONE form
+    if (!plan.full_floor && !has1 &&
         (plan.f16 ? launch_fast_fill_fl(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
                                         argV, ckpt, ckbase, queue, order, cendoff, crank)
                   : launch_fast_fill_fl_i16(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc,

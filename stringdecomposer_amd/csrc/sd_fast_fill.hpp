@@ -32,7 +32,9 @@ namespace sd {
 // folds the last two maxima:  u = max(S[x-1], KB);  v = u + tbl;  S_new[x] = max3(S_new[x-1], v, S[x])
 // -- 3 packed ops per cell pair instead of 4.  fast_plan_build() enables it when the score range
 // fits (FastPlan::f16); the checkpoints then hold fp16 pairs (the traceback converts them).
-template <int P, bool RANKED, bool F16, int FL = P>
+// ONE: the set has 1-bp templates (FLC_ONE lanes end at slot 0); instantiated for the full-floor kernels of
+// sd_fast.hip only -- as a run-time branch in every kernel it cost the C2 fill 3 % (12.3 against 11.9 ms, same box)
+template <int P, bool RANKED, bool F16, int FL = P, bool ONE = false>
 __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
@@ -61,7 +63,6 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     (void)wave; (void)nw;
     const int H = Hx & 0xff;                    // carry hops (FastPlan::Hx)
     const bool bperm_ok = (Hx >> 8) & 1;        // both planes segment alike and lane Hx >> 16 is idle in both
-    const bool has_one = (Hx >> 10) & 1;        // the set has 1-bp templates (FLC_ONE)
     // Issue fairness among the waves of a SIMD (FairShare, sd_fast_dev.hpp): the rows a wave still has to fill, one
     // word per wave behind the table
     FairShare fair;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     const uint32_t startMask = lc[FLC_STARTMASK];
     const uint32_t contMask = lc[FLC_CONTMASK];
     const uint32_t cont2Mask = lc[FLC_CONT2];
-    const uint32_t oneMask = lc[FLC_ONE];
+    const uint32_t oneMask = ONE ? lc[FLC_ONE] : 0u;
     const uint32_t endOffPlan = lc[FLC_ENDOFF];
     // --ed_thr: per-chunk end offsets (-inf for dropped templates) and tie-break ranks
     // fp16, unranked: the whole B reduction stays in fp16 (no per-row int conversions); `del` is folded
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
         rs.advance(i + 1);
         uint32_t a = F16 ? L[P - 1] : CO::mx(L[P - 1], K);  // fp16: K already joined the chain
         // a 1-bp template ends in slot 0: the pads behind a k = 0 cell keep their old value when the cell's falls
-        if (has_one) a = bfi(oneMask, L[0], a);   // (wave-uniform branch; the lane is a start lane: no carry to join)
+        if constexpr (ONE) a = bfi(oneMask, L[0], a);   // (the lane is a start lane: no carry to join)
         ++tp;
         if constexpr (HRED) {
             // the scan's three crossbar trips run under the DPP chain of the B reduction (both need only `a`); the
