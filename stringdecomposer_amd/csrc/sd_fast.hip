@@ -368,16 +368,41 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     if (!cand.empty()) { P = cand[0].first; split = cand[0].second; }
     bool wide = false;
     if (P == 0 && has1) { why = "a 1-bp template in a set that needs a wide layout"; return false; }
+    std::vector<int> tiled_v0;   // tiled multi-wave layout: first global virtual lane of each template
     if (P == 0) {
         // wide layout: one template per virtual lane
-        if (T > 1024) { why = "more than 1024 templates"; return false; }
-        if ((int64_t)(3 * Lmax + 2 * FAST_REBASE + 4) * maxabs > 8000) { why = "scores too large for the wide layout"; return false; }
-        for (int p : FAST_WIDE_P_LIST)
-            if (p >= Lmax) { P = p; break; }
-        if (P == 0) { why = "template longer than the widest layout"; return false; }
-        split = std::min(T, 64);
+        if (T <= 1024)
+            for (int p : FAST_WIDE_P_LIST)
+                if (p >= Lmax) { P = p; break; }
+        if (P != 0) {
+            if ((int64_t)(3 * Lmax + 2 * FAST_REBASE + 4) * maxabs > 8000) { why = "scores too large for the wide layout"; return false; }
+            split = std::min(T, 64);
+            if (T > 128) plan.waves = (T + 127) / 128;   // multi-wave wide layout: wave w holds templates [128 w, 128 w + 128)
+        } else {
+            // tiled multi-wave layout (sd_fast_wt.hip): a template over ceil(L / P) consecutive virtual lanes of one
+            // plane of one wave, templates in file order (so that "smallest wave, then smallest virtual lane" among
+            // equal ends is the reference's first template, main.cpp:184-186); the slot count with the least work
+            // per row, W * P, among those that fit eight waves and the CU's LDS (P * 128 bytes of codes per wave)
+            int bestW = 0;
+            for (int p : FAST_TILED_P_LIST) {
+                std::vector<int> v0((size_t)T, 0);
+                int cur = 0;
+                for (int j = 0; j < T; ++j) {
+                    const int V = ((int)tseq[(size_t)j].size() + p - 1) / p;
+                    if (V > 64 - (cur & 63)) cur = (cur + 63) & ~63;
+                    v0[(size_t)j] = cur;
+                    cur += V;
+                }
+                const int Wp = (cur + 127) / 128;
+                if (Wp > 8 || (size_t)Wp * (size_t)(p / 16) * 2048 + 256 > (size_t)160 * 1024) continue;
+                if (P == 0 || Wp * p < bestW * P || (Wp * p == bestW * P && Wp < bestW)) { P = p; bestW = Wp; tiled_v0.swap(v0); }   // ties: fewer waves
+            }
+            if (P == 0) { why = T > 1024 ? "more than 1024 templates, too many cells for the tiled layout" : "template set too large for the tiled layout"; return false; }
+            plan.waves = bestW;
+            plan.tiled = true;
+            split = 0;
+        }
         wide = true;
-        if (T > 128) plan.waves = (T + 127) / 128;   // multi-wave wide layout: wave w holds templates [128 w, 128 w + 128)
     }
     const int W = plan.waves;
 
@@ -496,7 +521,13 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     if (plan.Qk > 8) plan.Qk = plan.Qk <= 16 ? 16 : 32;
     plan.vlane0.assign((size_t)T, 0);
     int Vmax = 1;
-    if (W > 1) {
+    if (plan.tiled) {
+        for (int j = 0; j < T; ++j) {
+            plan.vlane0[(size_t)j] = tiled_v0[(size_t)j];
+            Vmax = std::max(Vmax, ((int)tseq[(size_t)j].size() + P - 1) / P);
+        }
+        plan.bshift = 10;
+    } else if (W > 1) {
         for (int j = 0; j < T; ++j) plan.vlane0[(size_t)j] = j;   // global virtual lane = (wave << 7) | (plane << 6) | lane
         plan.bshift = 10;
     } else {
@@ -586,10 +617,11 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         bool bf_ok = true;
         const int xb = bf8_of(xd, bf_ok), mb = bf8_of(md, bf_ok);
         plan.f16 = bf_ok && ub <= 2040 && allow_f16;
-        if (W > 1) {
+        if (W > 1 || plan.tiled) {
             // multi-wave wide layout (sd_fast_wn.hip): LDS holds the template base codes, [wave][G][2 halves][64
             // lanes][4 dwords], bytes as above; code 7 = padding; the two bf8 table bytes travel as kernel arguments
-            if (!plan.f16) { why = "more than 128 templates need bf8-exact table values and the fp16 score range"; return false; }
+            if (!plan.f16) { why = plan.tiled ? "the tiled layout needs bf8-exact table values and the fp16 score range"
+                                               : "more than 128 templates need bf8-exact table values and the fp16 score range"; return false; }
             plan.bf8_match = (uint32_t)mb & 0xffu;
             plan.bf8_mismatch = (uint32_t)xb & 0xffu;
             plan.table.assign((size_t)W * G * 512, 0x07070707u);
@@ -600,12 +632,16 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
             int64_t xw = 0;
             for (int j = 0; j < T; ++j) {
                 const std::string& s = tseq[(size_t)j];
-                const int wv = j >> 7, plane = (j >> 6) & 1, lane = j & 63;
+                int u = 0;
                 for (int k = 0; k < (int)s.size(); ++k, ++xw) {
+                    // (one lane per template unless tiled: bnd[j] = {0, L})
+                    while (k >= bnd[(size_t)j][(size_t)u + 1]) ++u;
+                    const int v = plan.vlane0[(size_t)j] + u, slot = k - bnd[(size_t)j][(size_t)u];
+                    const int wv = v >> 7, plane = (v >> 6) & 1, lane = v & 63;
                     const int cd = code_of(s[(size_t)k]);
                     plan.tcodes[(size_t)xw] = (uint8_t)cd;
-                    plan.slot_of[(size_t)xw] = ((uint32_t)wv << 16) | ((uint32_t)k << 7) | (uint32_t)(j & 127);
-                    const int g = k / 16, s16 = k & 15, h = s16 >> 3, d = (s16 & 7) >> 1, odd = s16 & 1;
+                    plan.slot_of[(size_t)xw] = ((uint32_t)wv << 16) | ((uint32_t)slot << 7) | (uint32_t)(v & 127);
+                    const int g = slot / 16, s16 = slot & 15, h = s16 >> 3, d = (s16 & 7) >> 1, odd = s16 & 1;
                     uint32_t& w = plan.table[((((size_t)wv * G + g) * 2 + h) * 64 + lane) * 4 + d];
                     const int sh = 16 * odd + 8 * plane;
                     w = (w & ~(0xffu << sh)) | ((uint32_t)cd << sh);
@@ -697,6 +733,11 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
     if (const char* ev = getenv("SD_FILL_GRID")) grid = std::max(1, atoi(ev));   // developer knob
     // `queue` points at a zeroed work-queue head that no earlier launch has used (sd_engine hands out a fresh
     // one per run): no memset kernel sits between the launches of a stream
+    if (plan.tiled) {
+        launch_fast_fill_wt(plan, st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt, ckbase, queue,
+                            order, n_cu, cendoff, crank);
+        return;
+    }
     if (plan.wide && plan.waves > 1) {
         launch_fast_fill_wn(plan, st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt, ckbase, queue,
                             order, n_cu, cendoff, crank);

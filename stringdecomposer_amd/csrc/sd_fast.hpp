@@ -49,6 +49,7 @@ struct FastPlan {
     int Lmax = 0;
     int Qk = 0;           // traceback: template cells per lane = ceil(Lmax/64)
     int waves = 1;        // waves per chunk: 1, or ceil(T/128) for the multi-wave wide layout (sd_fast_wn.hip)
+    bool tiled = false;   // multi-wave layout with templates tiled over consecutive virtual lanes (sd_fast_wt.hip); wide is set too
     int bshift = 7;       // B words: (B_i << bshift) | arg-max (wave << 7 | virtual lane)
     int range_bound = 0;       // proven bound on |stored cell| between two rebases (fp16 formats need <= 2040)
     bool full_floor = false;   // launch the fills that take the start-term maximum in every slot (SD_FLAG_FULL_FLOOR: A/B, parity test)
@@ -81,6 +82,7 @@ bool launch_fast_trace2(const FastPlan& plan, hipStream_t st, const ChunkDesc* c
 static const int FAST_P_LIST[] = {4, 8, 12, 16, 20, 24, 28, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39,
                                   40, 42, 44, 46, 48, 52, 56, 60, 64};
 static const int FAST_WIDE_P_LIST[] = {80, 96, 112, 128, 144, 160, 176, 192, 208, 224};
+static const int FAST_TILED_P_LIST[] = {96, 128, 160, 192, 224};   // slots per lane of the tiled multi-wave layout
 
 // Builds the plan; returns false (with the reason) when the fast family cannot represent the
 // input exactly (then the generic family is used).
@@ -148,6 +150,11 @@ void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* 
                          const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
                          int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank,
                          const int* n_ptr = nullptr);   // n_ptr: the number of chunks lives on the device (order = a class list)
+// tiled multi-wave variant (sd_fast_wt.hip): templates over consecutive virtual lanes, W = plan.waves >= 1 waves per chunk
+void launch_fast_fill_wt(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
+                         const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                         const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
+                         int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank);
 // --ed_thr, more than 128 templates: one class of chunks, filled by wb waves holding their kept templates (sd_fast_wn_ck.hip)
 void launch_fast_fill_wn_compact(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, const uint32_t* bases2,
                                  const uint32_t* nmask, const uint32_t* lane_consts, ScoreArgs sc, int32_t* B,

@@ -29,7 +29,14 @@ __device__ __forceinline__ uint32_t cvt_bf8_pair(uint32_t tb, int pair, uint32_t
 // chunk; (wave, lane) order = filtered order, so "smallest wave, then smallest virtual lane among equal ends" is
 // already the reference's tie-break and the unranked reduction applies.  Same B words and checkpoint layout (the
 // first waves of the W-wave layout).
-template <int P, bool RANKED, int FL = P, bool COMPACT = false>
+//
+// TILED (sd_fast_wt.hip): a template is tiled over V = ceil(L / P) consecutive virtual lanes of one plane of one wave,
+// as in the narrow single-wave fills (sd_fast_fill.hpp) -- sets whose templates are longer than the widest lane (224
+// slots) and too many or too long for one wave.  The in-row deletion chain then crosses lanes: the carry K (exclusive,
+// template-segmented prefix maximum of the lane totals, Vmax - 1 DPP hops) is applied lazily exactly as there -- it
+// joins the chain at slot 0 of the next row, it is the diagonal input of slot 0, and checkpoints / ends take
+// max(value, K).
+template <int P, bool RANKED, int FL = P, bool COMPACT = false, bool TILED = false>
 __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ codes,
@@ -38,9 +45,10 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     int* __restrict__ queue, const int* __restrict__ order, const uint32_t* __restrict__ cendoff,
     const uint32_t* __restrict__ crank, const int* __restrict__ n_ptr, const uint16_t* __restrict__ klist,
     const uint8_t* __restrict__ tcodes, const int32_t* __restrict__ toff, const int32_t* __restrict__ tlen,
-    int klist_stride) {
+    int klist_stride, int H = 0) {
     static_assert(P % 16 == 0, "the code table is streamed 16 slots at a time");
     static_assert(!(COMPACT && RANKED), "the compacted form needs no ranks");
+    static_assert(!(COMPACT && TILED), "the compacted form holds one template per virtual lane");
     constexpr int G = P / 16;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [W][G][2 halves][64 lanes][4 dwords] codes, then the exchange area
     if (n_ptr) n_chunks = *n_ptr;      // the size of a chunk class is known on the device only
@@ -63,6 +71,15 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     const uint32_t endOffPlan = lc[FLC_ENDOFF];
     const uint32_t row0adj = CO::from_i16x2(lc[FLC_ROW0]);
     const uint32_t ins2 = CO::splat(sc.ins);
+    constexpr uint32_t NEGC = CO::NEG;
+    const uint32_t startMask = TILED ? lc[FLC_STARTMASK] : 0xffffffffu;
+    const uint32_t contMask = TILED ? lc[FLC_CONTMASK] : 0u;
+    // exclusive, template-segmented prefix maximum of the lane totals (both planes at once): H = Vmax - 1 hops
+    auto excl_scan = [&](uint32_t a) {
+        uint32_t inc = a;
+        for (int h = 1; h < H; ++h) inc = CO::mx(a, bfi(contMask, lane_up(inc, 1), NEGC));
+        return bfi(contMask, lane_up(inc, 1), NEGC);
+    };
 
     for (;;) {
         if (threadIdx.x == 0) {
@@ -106,6 +123,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
         int32_t* ckb = ckbase + cd.pad;
 
         uint32_t L[P];
+        uint32_t K = NEGC;   // TILED: the lane's carry
         uint32_t cg[2][8];  // 16 slots of codes per buffer: dword d = slots 2d, 2d+1 as {lo, hi, lo, hi} bytes
         int base = 0, Brel = 0, tp = 0;
         int accBV = 0;
@@ -196,7 +214,12 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
                 }
                 pin = run;
             }
-            reduce_ends(L[P - 1], 1);
+            if constexpr (TILED) {
+                K = excl_scan(L[P - 1]);
+                reduce_ends(CO::mx(L[P - 1], K), 1);
+            } else {
+                reduce_ends(L[P - 1], 1);
+            }
         }
         F16Guard<P> guard;   // run-time check of the fp16 exact-integer range (sd_fast_dev.hpp)
         guard.start(L[P - 1], sc.guard_lim);
@@ -215,12 +238,13 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
                     guard.check_high(L);
 #pragma unroll
                     for (int s = 0; s < P; ++s) L[s] = CO::sub(L[s], d2);
+                    if constexpr (TILED) K = bfi(startMask, NEGC, CO::sub(K, d2));
                     guard.check_low(L);
                 }
                 const int q = (i / FAST_R) - 1;
                 uint32_t* ckq = ck + (uint64_t)q * (uint64_t)W * (uint64_t)(P * 64);
 #pragma unroll
-                for (int s = 0; s < P; ++s) ckq[s * 64] = L[s];
+                for (int s = 0; s < P; ++s) ckq[s * 64] = TILED ? CO::mx(L[s], K) : L[s];
                 if (wave == 0 && lane == 0) ckb[q] = base + tp * sc.ins;
             }
             const uint32_t KB = CO::splat(Brel + sc.del - tp * sc.ins);
@@ -228,6 +252,13 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
             pool_of(rcur, plo, phi);
             uint32_t u_[P], v_[P], t_[P];
             uint32_t KBs = (uint32_t)__builtin_amdgcn_readfirstlane((int)KB);
+            // TILED: slot 0's diagonal input is the true last slot of the lane below = the carry; KBv >= K serves the
+            // later slots too (their old values are true up to the same K)
+            uint32_t KBv = 0, w0 = 0;
+            if constexpr (TILED) {
+                KBv = CO::mx(K, KB);
+                w0 = bfi(startMask, NEGC, L[0]);   // no insertion move at k = 0
+            }
             uint32_t one_s = 0x3f800000u;
             uint32_t tbw = 0;
             // 4.5 ops per slot: [perm per 2 slots]; t = cvt(bf8 pair); u = max(S[x-1], KB); v = u + t;
@@ -236,6 +267,8 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
             for (int s = 0; s < P + 4; ++s) {
                 if (s >= 4) {
                     const int q = s - 4;
+                    if constexpr (TILED) L[q] = q == 0 ? CO::mx3(v_[0], w0, K) : CO::mx3(L[q - 1], v_[q], L[q]);
+                    else
                     L[q] = q == 0 ? v_[0] : CO::mx3(L[q - 1], v_[q], L[q]);  // k == 0: start term only
                 }
                 if (s >= 2 && s - 2 < P) {
@@ -246,8 +279,9 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
                     const int q = s;
                     uint32_t u;
                     // behind slot FL the start term is dominated (FastPlan::floor_slots, see sd_fast_fl.hip)
-                    if (q == 0) u = KB;
+                    if (q == 0) u = TILED ? KBv : KB;
                     else if (q > FL) u = L[q - 1];
+                    else if constexpr (TILED) u = CO::mx(L[q - 1], KBv);
                     else asm("v_pk_max_f16 %0, %1, %2" : "=v"(u) : "v"(L[q - 1]), "s"(KBs));
                     u_[q] = u;
                     if ((q & 1) == 0) tbw = __builtin_amdgcn_perm(phi, plo, cg[(q >> 4) & 1][(q & 15) >> 1]);
@@ -262,7 +296,12 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
             rs.advance(i + 1);
             load_group(0, 0, L[P - 1]);
             ++tp;
-            reduce_ends(L[P - 1], i + 1);
+            if constexpr (TILED) {
+                K = excl_scan(L[P - 1]);   // totals never decrease: the new carry replaces the old one
+                reduce_ends(CO::mx(L[P - 1], K), i + 1);
+            } else {
+                reduce_ends(L[P - 1], i + 1);
+            }
         }
         guard.check_high(L);
         guard.finish(sc.guard_flag);

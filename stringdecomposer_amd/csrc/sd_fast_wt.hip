@@ -1,0 +1,52 @@
+// sd_fast_wt.hip -- tiled multi-wave variant of the fast fill: template sets that neither the narrow layout (at most
+// 128 virtual lanes of up to 64 slots) nor the wide ones (one template per virtual lane of up to 224 slots) hold --
+// e.g. sixty 340-bp templates, or two hundred 500-bp ones (the reference takes any monomer set, main.cpp:187-207).
+//
+// The kernel is sd_fast_fill_wn (sd_fast_wn_fill.hpp: W waves per chunk, template base codes in LDS, table bytes made
+// on the fly, one workgroup barrier per row for B_i) with its TILED parameter: a template lies over V = ceil(L / P)
+// consecutive virtual lanes of one plane of one wave and the deletion chain crosses the lanes through the lazily
+// applied carry of the narrow fills (sd_fast_fill.hpp).  fast_plan_build() picks P from FAST_TILED_P_LIST as the slot
+// count with the least work per row (W * P) that fits eight waves and the LDS of a CU; W may be 1.
+//
+// Outputs as the multi-wave wide fill: checkpoints [checkpoint][wave][P][64] (true values, max(cell, carry)), one word
+// per row (B_i << 10) | (wave << 7 | virtual lane) -> sd_fast_trace (bshift = 10), whose cell -> (wave, lane, slot) map
+// (FastPlan::slot_of) knows the tiling.  --ed_thr runs the ranked form (per-chunk end offsets and ranks on every lane
+// of a template, sd_rank_keep); the compacted form of sd_fast_wn_ck.hip assumes one template per lane and is not used.
+#include "sd_fast_wn_fill.hpp"
+
+namespace sd {
+
+void launch_fast_fill_wt(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
+                         const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                         const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
+                         int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank) {
+    const int W = plan.waves;
+    const size_t lds = ((size_t)W * (plan.P / 16) * 512 + 64) * sizeof(uint32_t);
+    // two waves per SIMD (the register budget of the kernel), and as many workgroups per CU as their LDS allows
+    const int per_cu = std::max(1, std::min(8 / W, (int)((size_t)160 * 1024 / lds)));
+    const int grid = std::min(n_chunks, per_cu * n_cu);
+    const bool ranked = cendoff != nullptr;
+    const bool fl48 = !plan.full_floor && plan.floor_slots >= 1 && plan.floor_slots <= 48;
+#define SD_FILLWT_K(PP, RK, FLV)                                                                                   \
+    {                                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill_wn<PP, RK, FLV, false, true>),        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+        hipLaunchKernelGGL((sd_fast_fill_wn<PP, RK, FLV, false, true>), dim3(grid), dim3(W * 64), lds, st, chunks,  \
+                           n_chunks, bases2, nmask, table, lane_consts, sc, W, plan.bf8_match, plan.bf8_mismatch, B, \
+                           ckpt, ckbase, queue, order, cendoff, crank, nullptr, nullptr, nullptr, nullptr, nullptr, 0, \
+                           plan.H);                                                                                \
+    }
+#define SD_FILLWT(PP)                                                               \
+    case PP:                                                                        \
+        if (fl48) { if (ranked) SD_FILLWT_K(PP, true, 48) else SD_FILLWT_K(PP, false, 48) } \
+        else { if (ranked) SD_FILLWT_K(PP, true, PP) else SD_FILLWT_K(PP, false, PP) }      \
+        break;
+    switch (plan.P) {
+        SD_FILLWT(96) SD_FILLWT(128) SD_FILLWT(160) SD_FILLWT(192) SD_FILLWT(224)
+        default: break;
+    }
+#undef SD_FILLWT
+#undef SD_FILLWT_K
+}
+
+}  // namespace sd

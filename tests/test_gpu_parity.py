@@ -572,7 +572,7 @@ def test_nw_identity_kernel_equals_host_and_edlib(shape):
     assert all((x == y).all() for x, y in zip(a, b))
 
 
-@pytest.mark.parametrize("nm,lo,hi", [(100, 165, 178), (260, 150, 176), (70, 300, 480), (520, 90, 120)])
+@pytest.mark.parametrize("nm,lo,hi", [(100, 165, 178), (260, 150, 176), (70, 300, 480), (520, 90, 120), (48, 300, 340), (20, 700, 1100)])
 def test_template_sets_beyond_the_fast_family_vs_oracle(oracle, nm, lo, hi):
     """Hundreds of monomers (the reference takes any monomer set, main.cpp:187-207): more than 128
     templates run on the generic family, more than 32 768 template cells on its tiled form (previous row
@@ -595,10 +595,12 @@ def test_template_sets_beyond_the_fast_family_vs_oracle(oracle, nm, lo, hi):
     e = lib.Engine(ms)
     info = e.info()
     e.close()
-    # up to 1024 templates of <= 224 bp run on the multi-wave wide layout, longer ones on the generic family
-    assert info["sum_template_len"] > (32768 if nm != 100 else 30000)
-    # (more than 1024 templates, or templates longer than 224 bp in a set of more than 128: generic family, tiled)
+    # up to 1024 templates of <= 224 bp run on the multi-wave wide layout, longer ones on the tiled multi-wave layout
+    # (sd_fast_wt.hip: a template over several virtual lanes) while eight waves hold them
+    assert info["sum_template_len"] > (32768 if nm > 100 else 28000)
+    # (more than 1024 virtual lanes: generic family, tiled over HBM)
     assert (info["family"], info["cells"]) == (("fast", "f16/bf8-codes x waves") if hi <= 224 and 2 * nm <= 1024
+                                               else ("fast", "f16/bf8-codes tiled x waves") if 2 * nm <= 1024
                                                else ("generic", "int32"))
     for sc, part, ov, ed in [((-1, -1, -1, 1), 5000, 500, -1), ((-2, -3, -4, 2), 400, 60, -1),
                              ((-1, -1, -1, 1), 700, 100, 40), ((-1, -1, -1, 1), 5000, 500, 0)]:
@@ -607,6 +609,45 @@ def test_template_sets_beyond_the_fast_family_vs_oracle(oracle, nm, lo, hi):
         assert got == exp, (nm, sc, ed)
         gen = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed, kernel=lib.KERNEL_GENERIC)
         assert gen == exp, (nm, sc, ed, "generic")
+
+
+@pytest.mark.parametrize("nm,lo,hi,waves", [(24, 400, 420, 2), (5, 950, 1000, 1), (40, 230, 700, None), (90, 120, 330, None)])
+def test_tiled_multiwave_layout_vs_oracle(oracle, nm, lo, hi, waves):
+    """csrc/sd_fast_wt.hip: template sets beyond the narrow layout (8192 cells in one wave) whose templates are longer
+    than the widest lane (224 slots) -- a template lies over several virtual lanes of one of up to eight waves and the
+    deletion chain crosses lanes and 32-row checkpoints.  Reads long enough for a dozen rebases of the fp16 state, N in
+    reads and templates, small chunks (many seams), --ed_thr (ranked form: per-chunk end offsets on every lane of a
+    template), against the oracle and the generic family."""
+    st = synth.Stream(9090 + nm, hi)
+    ms = _random_monomers(st, nm, lo, hi, with_n=True)
+    mn = ["m%d" % j for j in range(nm)]
+    pi = lib.plan_info(ms)
+    assert (pi["family"], pi["cells"]) == ("fast", "f16/bf8-codes tiled x waves"), pi
+    if waves:
+        assert pi["waves"] == waves, pi
+    reads = []
+    for r in range(3):
+        parts = []
+        while sum(len(x) for x in parts) < 2600 + 900 * r:
+            j = int(st.below(1, nm)[0])
+            codes = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), np.frombuffer(ms[j].replace(b"N", b"A"), dtype=np.uint8))
+            x = synth._to_ascii(synth.mutate(codes, st, 0.06, 0.03, 0.03))
+            parts.append(synth.revcomp_bytes(x) if st.below(1, 2)[0] else x)
+        b = bytearray(b"".join(parts))
+        b[len(b) // 3] = ord("N")
+        reads.append(bytes(b))
+    reads.append(reads[0][:37])          # shorter than any template
+    reads.append(reads[1][100:100 + hi])  # one template long
+    rn = ["r%d" % i for i in range(len(reads))]
+    for sc, part, ov, ed in [((-1, -1, -1, 1), 5000, 500, -1), ((-1, -1, -1, 1), 700, 100, -1),
+                             ((-1, -1, -1, 1), 1500, 300, 60), ((-1, -1, -1, 1), 5000, 500, 0),
+                             ((-1, -2, -1, 1), 1100, 150, -1)]:
+        if lib.plan_info(ms, scoring=sc)["family"] != "fast":
+            continue                    # (a scoring beyond the fp16 range of the set: the generic family, tested elsewhere)
+        exp = oracle.decompose(rn, reads, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc, part=part, overlap=ov, ed_thr=ed)
+        got = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed)
+        assert got == exp, (nm, sc, part, ed)
+        assert lib.guard_trips() == 0
 
 
 def _late_base_monomers():
