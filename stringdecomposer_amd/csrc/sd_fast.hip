@@ -321,10 +321,10 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         Lmin = std::min(Lmin, (int)s.size());
     }
     if (T <= 0) { why = "no templates"; return false; }
-    // A 1-bp template is taken in the narrow layout only: its one cell is a k = 0 cell (start term only, no insertion
-    // move, main.cpp:188-193), whose stored value may FALL from one row to the next, so the pad slots behind it -- which
-    // keep their old value like any cell with an insertion move -- cannot stand for it at the lane's last slot.  The
-    // narrow fills therefore take such a lane's end from slot 0 (FLC_ONE); the wide layouts do not (generic family).
+    // A 1-bp template: its one cell is a k = 0 cell (start term only, no insertion move, main.cpp:188-193), whose stored
+    // value may FALL from one row to the next, so the pad slots behind it -- which keep their old value like any cell
+    // with an insertion move -- cannot stand for it at the lane's last slot.  The narrow and the tiled fills take such a
+    // lane's end from slot 0 (FLC_ONE); the plain wide layouts do not know the form (such sets take the tiled one).
     const bool has1 = Lmin < 2;
     if (sc.ins > 0 || sc.del > 0) { why = "positive gap scores"; return false; }
     if (T > 65535) { why = "too many templates"; return false; }
@@ -367,11 +367,10 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     }
     if (!cand.empty()) { P = cand[0].first; split = cand[0].second; }
     bool wide = false;
-    if (P == 0 && has1) { why = "a 1-bp template in a set that needs a wide layout"; return false; }
     std::vector<int> tiled_v0;   // tiled multi-wave layout: first global virtual lane of each template
     if (P == 0) {
         // wide layout: one template per virtual lane
-        if (T <= 1024)
+        if (T <= 1024 && !has1)   // (a 1-bp template ends its lane at slot 0: the narrow and the tiled fills know that form)
             for (int p : FAST_WIDE_P_LIST)
                 if (p >= Lmax) { P = p; break; }
         if (P != 0) {

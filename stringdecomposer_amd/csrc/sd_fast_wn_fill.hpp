@@ -45,7 +45,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     int* __restrict__ queue, const int* __restrict__ order, const uint32_t* __restrict__ cendoff,
     const uint32_t* __restrict__ crank, const int* __restrict__ n_ptr, const uint16_t* __restrict__ klist,
     const uint8_t* __restrict__ tcodes, const int32_t* __restrict__ toff, const int32_t* __restrict__ tlen,
-    int klist_stride, int H = 0) {
+    int klist_stride, int Hx = 0) {   // Hx (TILED): carry hops | 1-bp templates present << 8
     static_assert(P % 16 == 0, "the code table is streamed 16 slots at a time");
     static_assert(!(COMPACT && RANKED), "the compacted form needs no ranks");
     static_assert(!(COMPACT && TILED), "the compacted form holds one template per virtual lane");
@@ -74,6 +74,11 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     constexpr uint32_t NEGC = CO::NEG;
     const uint32_t startMask = TILED ? lc[FLC_STARTMASK] : 0xffffffffu;
     const uint32_t contMask = TILED ? lc[FLC_CONTMASK] : 0u;
+    const int H = Hx & 0xff;
+    // a 1-bp template ends in slot 0 (FLC_ONE): the pads behind a k = 0 cell keep their old value when the cell's falls
+    // (no insertion move there, main.cpp:188-193); one wave-uniform branch per row of >= 96 slots
+    const bool has_one = TILED && ((Hx >> 8) & 1);
+    const uint32_t oneMask = TILED ? lc[FLC_ONE] : 0u;
     // exclusive, template-segmented prefix maximum of the lane totals (both planes at once): H = Vmax - 1 hops
     auto excl_scan = [&](uint32_t a) {
         uint32_t inc = a;
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
                 pin = run;
             }
             if constexpr (TILED) {
-                K = excl_scan(L[P - 1]);
+                K = excl_scan(L[P - 1]);   // (row 0: the pads of a 1-bp lane equal its cell)
                 reduce_ends(CO::mx(L[P - 1], K), 1);
             } else {
                 reduce_ends(L[P - 1], 1);
@@ -297,8 +302,10 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
             load_group(0, 0, L[P - 1]);
             ++tp;
             if constexpr (TILED) {
-                K = excl_scan(L[P - 1]);   // totals never decrease: the new carry replaces the old one
-                reduce_ends(CO::mx(L[P - 1], K), i + 1);
+                uint32_t a = L[P - 1];
+                if (has_one) a = bfi(oneMask, L[0], a);   // (such a lane is a start lane: no carry to join)
+                K = excl_scan(a);   // totals never decrease: the new carry replaces the old one
+                reduce_ends(CO::mx(a, K), i + 1);
             } else {
                 reduce_ends(L[P - 1], i + 1);
             }

@@ -34,7 +34,7 @@ void launch_fast_fill_wt(const FastPlan& plan, hipStream_t st, const ChunkDesc* 
         hipLaunchKernelGGL((sd_fast_fill_wn<PP, RK, FLV, false, true>), dim3(grid), dim3(W * 64), lds, st, chunks,  \
                            n_chunks, bases2, nmask, table, lane_consts, sc, W, plan.bf8_match, plan.bf8_mismatch, B, \
                            ckpt, ckbase, queue, order, cendoff, crank, nullptr, nullptr, nullptr, nullptr, nullptr, 0, \
-                           plan.H);                                                                                \
+                           plan.H | (((plan.Hx >> 10) & 1) << 8));                                                                                \
     }
 #define SD_FILLWT(PP)                                                               \
     case PP:                                                                        \

@@ -1077,6 +1077,7 @@ ONE_BP_SETS = [
     [b"G", b"C", b"ACGTTGCAAGGCTTAACCGG" * 4],                # two 1-bp monomers (each other's reverse complements twice over)
     [b"T", b"AC", b"ACGTACGTAGCTAGCTAGGATCCTAG" * 6, b"N"],   # with a 2-bp and an N monomer
     None,                                                     # 12 synthetic ~171-bp monomers + "A" in the middle of the order
+    70,                                                       # 70 of them + "A": beyond one wave -> the tiled multi-wave layout
 ]
 
 
@@ -1092,6 +1093,12 @@ def test_one_bp_templates_on_the_fast_family_vs_oracle(oracle, k, sc):
     if ONE_BP_SETS[k] is None:
         mn, ms = synth.make_monomers(12, seed=9)
         ms = list(ms[:5]) + [b"A"] + list(ms[5:])
+    elif ONE_BP_SETS[k] == 70:
+        mn, ms = synth.make_monomers(70, seed=9)
+        ms = list(ms[:33]) + [b"A"] + list(ms[33:])
+        if lib.plan_info(ms, scoring=sc)["family"] != "fast":
+            pytest.skip("scoring beyond the fp16 range of the tiled layout")
+        assert lib.plan_info(ms, scoring=sc)["cells"] == "f16/bf8-codes tiled x waves"
     else:
         ms = list(ONE_BP_SETS[k])
     mn = ["m%d" % j for j in range(len(ms))]

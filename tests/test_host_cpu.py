@@ -586,7 +586,8 @@ def test_plan_layouts_of_the_baseline_sets_and_fuzz_fixtures():
     one = lib.plan_info([b"A", b"ACGTACGT"])                                   # a 1-bp monomer: a lane of its own, ended at slot 0
     assert one["family"] == "fast" and one["trace_regs"] == 1, one
     mn, ms = synth.make_monomers(70, seed=1)
-    assert lib.plan_info(list(ms) + [b"G"])["family"] == "generic"            # ... but not in a set that needs a wide layout
+    w1 = lib.plan_info(list(ms) + [b"G"])                                      # in a set beyond one wave: the tiled layout knows the form too
+    assert (w1["family"], w1["cells"]) == ("fast", "f16/bf8-codes tiled x waves"), w1
     assert lib.plan_info([b"ACGTACGT"], scoring=(1, -1, -1, 1))["family"] == "generic"   # positive gap score
     # templates longer than the widest lane (224 slots) in a set beyond one wave of the narrow layout: tiled over the
     # virtual lanes of up to eight waves (sd_fast_wt.hip); the slot count with the least work per row, fewer waves on ties

@@ -42,7 +42,8 @@ for case in range(cases):
     shape = [(1, 5, 40), (3, 20, 90), (6, 100, 200), (12, 160, 180), (25, 150, 190), (50, 100, 180),
              (64, 165, 178), (4, 300, 500), (2, 1, 30), (10, 60, 64), (90, 100, 180), (230, 140, 176),
              (16, 150, 190), (20, 160, 180), (14, 120, 175),             # these three: P = 42..64 (sd_fast_fl_long.hip)
-             (3, 520, 1000), (2, 1000, 2000), (1, 600, 2040)][rnd(18)]  # round 3: monomers of up to 2048 bp on the fast family
+             (3, 520, 1000), (2, 1000, 2000), (1, 600, 2040),            # round 3: monomers of up to 2048 bp on the fast family
+             (30, 230, 420), (10, 600, 1150), (70, 90, 330), (40, 1, 500)][rnd(22)]   # round 4: the tiled multi-wave layout (sd_fast_wt.hip)
     nm = max(1, shape[0] - rnd(2))
     ms = monomers(nm, shape[1], shape[2], 0.15 if rnd(3) == 0 else 0.0)
     mn = ["m%d" % j for j in range(nm)]
