@@ -192,6 +192,17 @@ def main():
     synth.write_fasta(os.path.join(d, "monomers.fa"), ["L0", "L1"], ms)
     emit(work, "long_block", os.path.join(d, "reads.fa"), os.path.join(d, "monomers.fa"), ["--second-best", "-b", "30000"],
          ["final/long_block/reads.fa", "final/long_block/monomers.fa"], keep_alt=True)
+    # thirty 342-bp monomers (pairs of synthetic ones): 60 templates of 20.5 k cells -- beyond one wave of the narrow
+    # layout with templates longer than the widest lane: the tiled multi-wave layout of csrc/sd_fast_wt.hip
+    d = os.path.join(OUT, "tiled_second_best")
+    os.makedirs(d, exist_ok=True)
+    mn, ms = synth.make_monomers(60, seed=21)
+    mn, ms = ["T%d" % j for j in range(30)], [ms[2 * j] + ms[2 * j + 1] for j in range(30)]
+    rn, rs = synth.make_reads(ms, 2, read_len=6000, seed=23)
+    synth.write_fasta(os.path.join(d, "reads.fa"), rn, rs, width=80)
+    synth.write_fasta(os.path.join(d, "monomers.fa"), mn, ms)
+    emit(work, "tiled_second_best", os.path.join(d, "reads.fa"), os.path.join(d, "monomers.fa"), ["--second-best"],
+         ["final/tiled_second_best/reads.fa", "final/tiled_second_best/monomers.fa"], keep_alt=True)
     shutil.rmtree(work, ignore_errors=True)
 
 

@@ -867,13 +867,19 @@ def test_bench_line_contract():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nm", [12, 64, 140])
+@pytest.mark.parametrize("nm", [12, 64, 140, "tiled"])
 def test_f16_range_guard_trips_and_the_batch_is_repeated_with_integer_cells(oracle, nm):
     """VERDICT r02 (weak 6): the fp16 fills check at run time that their cells stay in the exact-integer range
     (F16Guard, csrc/sd_fast_dev.hpp).  With the real limit nothing trips; with a limit any input exceeds
     (sd_params.reserved[2], the test hook) the guard raises its flag, the engine repeats the batch with integer
     cells -- for more than 128 templates on the generic family -- and the rows still equal the oracle's."""
-    mn, ms = synth.make_monomers(nm, seed=3)
+    if nm == "tiled":   # thirty 342-bp monomers: the tiled multi-wave layout (fp16 only: the repeat runs on the generic family)
+        mn, ms = synth.make_monomers(60, seed=3)
+        mn, ms = mn[:30], [ms[2 * j] + ms[2 * j + 1] for j in range(30)]
+        assert lib.plan_info(ms)["cells"] == "f16/bf8-codes tiled x waves"
+        nm = 30
+    else:
+        mn, ms = synth.make_monomers(nm, seed=3)
     rn, rs = synth.make_reads(ms, 5, read_len=3000 if nm > 64 else 6000, seed=5)
     want = oracle.decompose(rn, rs, mn, ms, threads=8)
     t0 = lib.guard_trips()
