@@ -222,9 +222,10 @@ int sd_engine_info(sd_engine* e, int64_t info[8]);
 /* Host only (no device needed): the layout sd_engine_create would choose for this monomer set and scoring.
  * info: [0] kernel family of "auto" (2 fast, 1 generic; generic: the reason is in errbuf, rc is still SD_OK)
  * [1] slots per lane P [2] cell arithmetic code (as sd_engine_info [4] >> 8) [3] last slot of a lane that needs
- * the maximum with the start term [4] low byte: waves per chunk; bits 8..: the proven bound on the magnitude of a
+ * the maximum with the start term [4] low byte: waves per chunk; bits 8..39: the proven bound on the magnitude of a
  * stored cell (fp16 cell formats are chosen when it is <= 2040; tests/test_host_cpu.py checks it against the
- * recurrence itself) [5] cells in the shortest first lane of a template
+ * recurrence itself); bits 40..: rows between two rebases of the stored cells (128, or 64 where only that keeps
+ * the set inside the fp16 range) [5] cells in the shortest first lane of a template
  * [6] cells in the fullest lane [7] bits 0..15: common factor divided out of the four scores; bits 16..23: registers per
  * lane of the packed two-block traceback at its widest level (0 = the one-block int32 traceback runs); bits 24..55: the
  * proven bound on |E' - base| of that traceback's 16-bit words (tests/test_host_cpu.py checks it against the

@@ -22,6 +22,9 @@ struct ScoreArgs {
     // with integer cells)
     int32_t guard_lim = 0;
     int* guard_flag = nullptr;
+    // fast fills: the stored cells are rebased on B every rebase_mask + 1 rows (FastPlan::rebase: 128, or 64 where
+    // only the shorter period keeps a template set and scoring inside the fp16 range)
+    int32_t rebase_mask = 127;
 };
 
 // Device-side record as emitted by the traceback kernels (emission order = reverse read order).

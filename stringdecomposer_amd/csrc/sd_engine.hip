@@ -440,6 +440,7 @@ static int engine_pick_family(sd_engine* e, bool allow_f16, std::string& err) {
     const bool tr2 = allow_f16 && !(p->reserved[1] & SD_FLAG_TRACE_V1);
     const bool fast_ok = sd::fast_plan_build(e->tseq, e->sc, p->part_size + p->overlap, e->fplan, why, !no_f16, tr2);
     e->fplan.full_floor = (p->reserved[1] & SD_FLAG_FULL_FLOOR) != 0;
+    e->sc.rebase_mask = fast_ok ? e->fplan.rebase - 1 : 127;
     if (family == 0) family = fast_ok ? 2 : 1;
     if (family == 2 && !fast_ok) { err = "fast kernel family not applicable: " + why; return SD_ERR_UNSUPPORTED; }
     if (family != 1 && family != 2) { err = "bad kernel family"; return SD_ERR_PARAM; }
@@ -521,7 +522,7 @@ int sd_plan_info(const sd_params* p, const char* const* mono_seqs, const int32_t
     info[1] = plan.P;
     info[2] = plan.tiled ? 6 : plan.waves > 1 ? 5 : plan.wide ? (plan.f16 ? 4 : 3) : plan.f16 ? 2 : 1;   // as sd_engine_info [4] >> 8
     info[3] = plan.floor_slots;
-    info[4] = plan.waves | ((int64_t)plan.range_bound << 8);
+    info[4] = plan.waves | ((int64_t)plan.range_bound << 8) | ((int64_t)plan.rebase << 40);
     // narrow layout: cells in the shortest first lane of a template and in the fullest lane (from slot_of)
     int64_t min_first = 1 << 30, max_lane = 0, x = 0;
     for (size_t j = 0; j < tseq.size(); ++j) {

@@ -342,10 +342,19 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     // fp16 cells left the exact-integer range; found by tools/fuzz_gpu.py seed 906.)
     const int smax = std::max(sc.match, sc.mismatch);
     const int64_t G = std::max(0, smax - sc.del);
-    const int64_t ub = (int64_t)(Lmax - 1) * ab(sc.del) + (int64_t)(FAST_REBASE + 1) * G +
-                       (int64_t)FAST_REBASE * ab(sc.ins) + 8 * (int64_t)maxabs + 8;
+    auto ub_of = [&](int R) {
+        return (int64_t)(Lmax - 1) * ab(sc.del) + (int64_t)(R + 1) * G + (int64_t)R * ab(sc.ins) + 8 * (int64_t)maxabs + 8;
+    };
+    // The rebase period is 128 rows; where only a shorter one keeps the cells inside the exact-integer range of fp16
+    // (long templates, large gap scores) the plan takes 64 -- P + 6 packed ops per period against the fourth op
+    // per cell pair of the integer cells, and the multi-wave layouts have no integer form at all.
+    // (Not 32: the fp16 fills turn the row maxima into B words 64 rows at a time with the base of that moment.)
+    int rebase = FAST_REBASE;
+    if (ub_of(rebase) > 2040 && allow_f16 && ub_of(64) <= 2040) rebase = 64;
+    const int64_t ub = ub_of(rebase);
     if (ub > 12000) { why = "scores too large for int16 cells"; return false; }
     plan.range_bound = (int)ub;
+    plan.rebase = rebase;
     if (Lmax > 64 * 32) { why = "template longer than 2048 bp"; return false; }
 
     // narrow layout: the smallest slot counts P whose lanes fit the two planes; the first three are candidates,
@@ -595,6 +604,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         if (same && idle >= 0) plan.Hx = plan.H | (1 << 8) | (idle << 16) | (getenv("SD_FILL_BPERM_TAIL") ? 1 << 9 : 0);   // bit 9 (developer A/B): in the last round too
     }
     if (has1) plan.Hx |= 1 << 10;
+    if (plan.rebase == 64) plan.Hx |= 1 << 11;
     if (wide) {
         // int8 table [5][G][2 halves][64 lanes][4 dwords]; dword d of half h of group g holds slots
         // 16g+8h+2d, +1 as bytes {lo plane, hi plane, lo plane, hi plane}; -128 = transparent padding

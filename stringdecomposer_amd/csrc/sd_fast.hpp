@@ -51,6 +51,7 @@ struct FastPlan {
     int waves = 1;        // waves per chunk: 1, or ceil(T/128) for the multi-wave wide layout (sd_fast_wn.hip)
     bool tiled = false;   // multi-wave layout with templates tiled over consecutive virtual lanes (sd_fast_wt.hip); wide is set too
     int bshift = 7;       // B words: (B_i << bshift) | arg-max (wave << 7 | virtual lane)
+    int rebase = FAST_REBASE;  // rows between two rebases of the stored cells (ScoreArgs::rebase_mask + 1; the narrow fills read it from Hx bit 11): 128 or 64
     int range_bound = 0;       // proven bound on |stored cell| between two rebases (fp16 formats need <= 2040)
     bool full_floor = false;   // launch the fills that take the start-term maximum in every slot (SD_FLAG_FULL_FLOOR: A/B, parity test)
     int floor_slots = 0;  // last slot of a lane whose diagonal input needs the max with the start term (see sd_fast_fill)

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
         if ((i & (FAST_R - 1)) == 0) {
             fair.update(n - i);
             bperm_scan = bperm_ok && (!fair.drained || ((Hx >> 9) & 1));
-            if ((i & (FAST_REBASE - 1)) == 0) {
+            if ((i & (127 >> ((Hx >> 11) & 1))) == 0) {   // FastPlan::rebase rows: 128, or 64 (Hx bit 11; Hx is live here anyway)
                 // rebase the int16 state on B_i and fold the row offset tp*ins back in
                 if constexpr (HRED)
                     Brel = __builtin_amdgcn_readfirstlane((int)(float)__builtin_bit_cast(_Float16, (unsigned short)bdel16)) -

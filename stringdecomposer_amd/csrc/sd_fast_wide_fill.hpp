@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wide(
     for (int i = 1; i < n; ++i) {
         if ((i & (FAST_R - 1)) == 0) {
             fair.update(n - i);
-            if ((i & (FAST_REBASE - 1)) == 0) {
+            if ((i & sc.rebase_mask) == 0) {   // FastPlan::rebase rows
                 const uint32_t d2 = CO::splat(Brel - tp * sc.ins);
                 base += Brel;
                 Brel = 0;

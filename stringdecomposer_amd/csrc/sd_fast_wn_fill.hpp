@@ -235,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
         for (int i = 1; i < n; ++i) {
             const int rcur = rnext;
             if ((i & (FAST_R - 1)) == 0) {
-                if ((i & (FAST_REBASE - 1)) == 0) {
+                if ((i & sc.rebase_mask) == 0) {   // FastPlan::rebase rows
                     const uint32_t d2 = CO::splat(Brel - tp * sc.ins);
                     base += Brel;
                     Brel = 0;

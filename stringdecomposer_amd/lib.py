@@ -203,7 +203,7 @@ def plan_info(mono_seqs, **kw):
         raise SdError(rc, err.value.decode(errors="replace"))
     cells = {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table", 4: "f16/bf8-table", 5: "f16/bf8-codes x waves", 6: "f16/bf8-codes tiled x waves"}
     return {"family": {1: "generic", 2: "fast"}[v[0]], "cells_per_lane": v[1], "cells": cells.get(v[2], "?") if v[0] == 2 else "int32",
-            "floor_slots": v[3], "waves": v[4] & 0xff, "range_bound": v[4] >> 8, "min_first_lane_cells": v[5], "max_lane_cells": v[6],
+            "floor_slots": v[3], "waves": v[4] & 0xff, "range_bound": (v[4] >> 8) & 0xffffffff, "rebase": v[4] >> 40, "min_first_lane_cells": v[5], "max_lane_cells": v[6],
             "score_factor": v[7] & 0xffff, "trace_regs": (v[7] >> 16) & 0xff, "trace_bound": (v[7] >> 24) & 0xffffffff,
             "bperm_scan": bool((v[7] >> 56) & 1), "why": err.value.decode(errors="replace") if v[0] == 1 else ""}
 

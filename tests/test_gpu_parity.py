@@ -185,15 +185,22 @@ def test_full_c2_sample_of_200_reads_equals_the_reference_binary(tmp_path):
     assert mine == want
 
 
-@pytest.mark.parametrize("sc,cells", [((-2, -1, -3, 6), "f16"), ((-2, -2, -3, 8), "f16"), ((-2, -2, -3, 9), "int16"),
-                                      ((-1, -1, -1, 1), "f16"), ((0, 0, -1, 14), "f16"), ((0, 0, -1, 15), "int16"),
-                                      # a large |del| with non-positive scores: the range is (Lmax-1)*|del| wide
-                                      ((0, -6, -4, -1), "f16"), ((0, -7, -4, -1), "int16"), ((-1, -5, -2, 1), "f16"),
-                                      # a common factor is divided out on the device and multiplied back
-                                      ((-10, -10, -10, 10), "f16"), ((-4, -6, -8, 4), "f16"), ((0, 0, -3, 45), "int16")])
-def test_fill_cell_format_switch_at_the_fp16_range_limit(oracle, sc, cells):
+@pytest.mark.parametrize("sc,cells,rebase", [((-2, -1, -3, 6), "f16", 128), ((-2, -2, -3, 8), "f16", 128),
+                                             # beyond the range at 128 rows between rebases: 64 rows, then integer cells
+                                             ((-2, -2, -3, 9), "f16", 64), ((-2, -2, -3, 18), "f16", 64), ((-2, -2, -3, 33), "int16", 128),
+                                             ((-2, -2, -3, 40), "int16", 128),
+                                             ((-1, -1, -1, 1), "f16", 128), ((0, 0, -1, 14), "f16", 128), ((0, 0, -1, 15), "f16", 64),
+                                             ((0, 0, -1, 31), "int16", 128), ((0, 0, -1, 50), "int16", 128),
+                                             # a large |del| with non-positive scores: the range is (Lmax-1)*|del| wide
+                                             ((0, -6, -4, -1), "f16", 128), ((0, -7, -4, -1), "f16", 64), ((0, -9, -4, -1), "int16", 128),
+                                             ((0, -10, -4, -1), "int16", 128), ((-1, -5, -2, 1), "f16", 128),
+                                             # a common factor is divided out on the device and multiplied back
+                                             ((-10, -10, -10, 10), "f16", 128), ((-4, -6, -8, 4), "f16", 128), ((0, 0, -3, 45), "f16", 64),
+                                             ((0, 0, -3, 150), "int16", 128)])
+def test_fill_cell_format_switch_at_the_fp16_range_limit(oracle, sc, cells, rebase):
     """The fill uses packed fp16 cells while the score range keeps every value an exact integer
-    (fast_plan_build), packed int16 beyond.  Scorings on both sides of the switch, on reads that
+    (fast_plan_build: with 128 or 64 rows between two rebases of the stored cells), packed int16 beyond.
+    Scorings on both sides of every switch, on reads that
     maximise score growth (exact repeats), insertions (unrelated sequence) and ordinary noise."""
     mn, ms = synth.make_monomers(12, seed=3)
     st = synth.Stream(3, 5)
@@ -201,9 +208,11 @@ def test_fill_cell_format_switch_at_the_fp16_range_limit(oracle, sc, cells):
     rs = list(rs) + [(ms[0] * 40)[:6100], synth._ACGT[st.below(5600, 4)].tobytes(), ms[5] * 3 + b"A" * 700 + ms[2] * 20]
     rn = ["r%d" % i for i in range(len(rs))]
     e = lib.Engine(ms, scoring=sc, kernel=lib.KERNEL_FAST)
-    assert e.info()["cells"] == cells
+    assert e.info()["cells"] == cells and lib.plan_info(ms, scoring=sc)["rebase"] == rebase
     e.close()
+    t0 = lib.guard_trips()
     got = lib.decompose(rn, rs, mn, ms, scoring=sc, kernel=lib.KERNEL_FAST)
+    assert lib.guard_trips() == t0   # (the run-time check of the fp16 range agrees with the plan's period)
     assert got == oracle.decompose(rn, rs, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc)
 
 
@@ -673,11 +682,11 @@ def test_fill_without_dominated_start_maxima(oracle, name):
     if name.startswith("synthetic12"):
         mn, ms = synth.make_monomers(12, seed=1)
         if name.endswith("_i16"):
-            sc = (-2, -2, -3, 9)                       # beyond the fp16 range: packed int16 cells (sd_fast_fl_i16.hip)
+            sc = (-2, -2, -3, 40)                      # beyond the fp16 range: packed int16 cells (sd_fast_fl_i16.hip)
     elif name.startswith("dxz1"):
         mn, ms, _ = lib.fasta_load(os.path.join(GOLDEN, "test_data", "DXZ1_star_monomers.fa"))
         if name.endswith("_i16_ed"):
-            sc, ed = (0, 0, -1, 15), 45
+            sc, ed = (0, 0, -1, 30), 45          # (0,0,-1,15) takes fp16 cells with 64 rows between rebases since round 4
     elif name == "synthetic16":
         mn, ms = synth.make_monomers(16, seed=4)       # 32 templates of 4 lanes: P = 44 (sd_fast_fl_long.hip)
     elif name == "synthetic20_ed":

@@ -561,16 +561,24 @@ def test_two_decimal_text_equals_python_format():
     assert not bad, bad[:5]
 
 
-@pytest.mark.parametrize("sc,cells", [((-2, -1, -3, 6), "f16"), ((-2, -2, -3, 8), "f16"), ((-2, -2, -3, 9), "int16"),
-                                      ((-1, -1, -1, 1), "f16"), ((0, 0, -1, 14), "f16"), ((0, 0, -1, 15), "int16"),
-                                      ((0, -6, -4, -1), "f16"), ((0, -7, -4, -1), "int16"), ((-1, -5, -2, 1), "f16"),
-                                      ((-10, -10, -10, 10), "f16"), ((-4, -6, -8, 4), "f16"), ((0, 0, -3, 45), "int16")])
-def test_plan_cell_format_switch(sc, cells):
+@pytest.mark.parametrize("sc,cells,rebase", [((-2, -1, -3, 6), "f16", 128), ((-2, -2, -3, 8), "f16", 128),
+                                             # beyond the range at 128 rows between rebases: 64 rows, then integer cells
+                                             ((-2, -2, -3, 9), "f16", 64), ((-2, -2, -3, 18), "f16", 64), ((-2, -2, -3, 33), "int16", 128),
+                                             ((-2, -2, -3, 40), "int16", 128),
+                                             ((-1, -1, -1, 1), "f16", 128), ((0, 0, -1, 14), "f16", 128), ((0, 0, -1, 15), "f16", 64),
+                                             ((0, 0, -1, 31), "int16", 128), ((0, 0, -1, 50), "int16", 128),
+                                             # a large |del| with non-positive scores: the range is (Lmax-1)*|del| wide
+                                             ((0, -6, -4, -1), "f16", 128), ((0, -7, -4, -1), "f16", 64), ((0, -9, -4, -1), "int16", 128),
+                                             ((0, -10, -4, -1), "int16", 128), ((-1, -5, -2, 1), "f16", 128),
+                                             # a common factor is divided out on the device and multiplied back
+                                             ((-10, -10, -10, 10), "f16", 128), ((-4, -6, -8, 4), "f16", 128), ((0, 0, -3, 45), "f16", 64),
+                                             ((0, 0, -3, 150), "int16", 128)])
+def test_plan_cell_format_switch(sc, cells, rebase):
     """sd_plan_info (host only): the fp16 / int16 decision of fast_plan_build for scorings on both sides of the
     exact-integer range of fp16 -- the same cases the GPU test runs against the oracle."""
     mn, ms = synth.make_monomers(12, seed=3)
     info = lib.plan_info(ms, scoring=sc)
-    assert info["family"] == "fast" and info["cells"] == cells, info
+    assert info["family"] == "fast" and info["cells"] == cells and info["rebase"] == rebase, info
 
 
 def test_plan_layouts_of_the_baseline_sets_and_fuzz_fixtures():
@@ -669,7 +677,8 @@ def _stored_extrema(tmpls, read, sc, rebase=128):
     return worst
 
 
-@pytest.mark.parametrize("sc", [(-1, -1, -1, 1), (-2, -3, -4, 2), (0, -4, -4, -1), (-1, -5, -2, 3), (-3, -1, -6, 2)])
+@pytest.mark.parametrize("sc", [(-1, -1, -1, 1), (-2, -3, -4, 2), (0, -4, -4, -1), (-1, -5, -2, 3), (-3, -1, -6, 2),
+                                (0, 0, -1, 15), (-2, -2, -3, 33), (0, -40, -4, -1)])   # the last three: 64 rows between rebases, or integer cells
 def test_plan_range_bound_covers_the_recurrence(sc):
     """VERDICT r02 (weak 6): the fp16 fills rest on fast_plan_build's bound |stored cell| <= range_bound.  Here the
     stored values are computed from the reference recurrence in numpy for reads built to push them -- repeats of one
@@ -686,7 +695,7 @@ def test_plan_range_bound_covers_the_recurrence(sc):
         reads = [(ms[0] * 40)[:300], (b"A" * 150 + ms[-1] * 20)[:300],
                  synth._to_ascii(st.below(300, 4)), (ms[0][: len(ms[0]) // 2] * 60)[:300]]
         for rd in reads:
-            assert _stored_extrema(tm, rd, sc) <= info["range_bound"], (sc, trial, info)
+            assert _stored_extrema(tm, rd, sc, rebase=info["rebase"]) <= info["range_bound"], (sc, trial, info)
 
 
 def _trace_extrema(tmpls, read, sc, block=32):
