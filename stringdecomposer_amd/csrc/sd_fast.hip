@@ -389,10 +389,17 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         } else {
             // tiled multi-wave layout (sd_fast_wt.hip): a template over ceil(L / P) consecutive virtual lanes of one
             // plane of one wave, templates in file order (so that "smallest wave, then smallest virtual lane" among
-            // equal ends is the reference's first template, main.cpp:184-186); the slot count with the least work
-            // per row, W * P, among those that fit eight waves and the CU's LDS (P * 128 bytes of codes per wave)
+            // equal ends is the reference's first template, main.cpp:184-186); the slot count with the least SIMD time
+            // per row among those that fit eight waves and the CU's LDS (P * 128 bytes of codes per wave): a wave
+            // spends 4.5 P + ~60 instructions on a row, W waves per chunk, and how well that runs depends on the waves
+            // a CU holds (two per SIMD at the kernel's register count; five to seven leave SIMDs half empty or, in one
+            // lock-stepped workgroup, uneven) -- efficiencies measured on three sets (tools/scratch/tiled_p.py,
+            // profiles/r04_tiled_layout.txt: the order of the five slot counts follows this figure)
             int bestW = 0;
+            int64_t best_cost = 0;
+            const int force_p = getenv("SD_TILED_P") ? atoi(getenv("SD_TILED_P")) : 0;   // developer knob
             for (int p : FAST_TILED_P_LIST) {
+                if (force_p && p != force_p) continue;
                 std::vector<int> v0((size_t)T, 0);
                 int cur = 0;
                 for (int j = 0; j < T; ++j) {
@@ -403,7 +410,11 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
                 }
                 const int Wp = (cur + 127) / 128;
                 if (Wp > 8 || (size_t)Wp * (size_t)(p / 16) * 2048 + 256 > (size_t)160 * 1024) continue;
-                if (P == 0 || Wp * p < bestW * P || (Wp * p == bestW * P && Wp < bestW)) { P = p; bestW = Wp; tiled_v0.swap(v0); }   // ties: fewer waves
+                const size_t ldsb = (size_t)Wp * (size_t)(p / 16) * 2048 + 256;
+                const int per_cu = std::max(1, std::min(8 / Wp, (int)((size_t)160 * 1024 / ldsb)));
+                static const int eff_pct[9] = {0, 21, 43, 64, 85, 72, 80, 87, 100};   // by waves per CU
+                const int64_t cost = (int64_t)Wp * (9 * p / 2 + 60) * 100 / eff_pct[std::min(8, per_cu * Wp)];
+                if (P == 0 || cost < best_cost) { P = p; bestW = Wp; best_cost = cost; tiled_v0.swap(v0); }
             }
             if (P == 0) { why = T > 1024 ? "more than 1024 templates, too many cells for the tiled layout" : "template set too large for the tiled layout"; return false; }
             plan.waves = bestW;

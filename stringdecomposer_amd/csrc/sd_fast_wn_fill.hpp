@@ -174,7 +174,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
             }
             const int vw = mlo ? (__ffsll((long long)mlo) - 1) : (64 + __ffsll((long long)mhi) - 1);
             int b = bw, arg = vw;
-            if (!COMPACT || Wb > 1) {
+            if (Wb > 1) {   // (one wave per chunk -- the compacted and the tiled forms can be -- needs no exchange)
                 const int par = (row & 1) * 8;
                 if (lane == 0) { xv[par + wave] = bw; xa[par + wave] = vw; xr[par + wave] = kw; }
                 __syncthreads();

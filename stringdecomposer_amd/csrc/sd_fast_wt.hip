@@ -6,7 +6,8 @@
 // on the fly, one workgroup barrier per row for B_i) with its TILED parameter: a template lies over V = ceil(L / P)
 // consecutive virtual lanes of one plane of one wave and the deletion chain crosses the lanes through the lazily
 // applied carry of the narrow fills (sd_fast_fill.hpp).  fast_plan_build() picks P from FAST_TILED_P_LIST as the slot
-// count with the least work per row (W * P) that fits eight waves and the LDS of a CU; W may be 1.
+// count with the least SIMD time per row at the occupancy it gets, among those that fit eight waves and the LDS of a CU;
+// W may be 1.
 //
 // Outputs as the multi-wave wide fill: checkpoints [checkpoint][wave][P][64] (true values, max(cell, carry)), one word
 // per row (B_i << 10) | (wave << 7 | virtual lane) -> sd_fast_trace (bshift = 10), whose cell -> (wave, lane, slot) map

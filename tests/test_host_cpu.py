@@ -598,11 +598,11 @@ def test_plan_layouts_of_the_baseline_sets_and_fuzz_fixtures():
     assert (w1["family"], w1["cells"]) == ("fast", "f16/bf8-codes tiled x waves"), w1
     assert lib.plan_info([b"ACGTACGT"], scoring=(1, -1, -1, 1))["family"] == "generic"   # positive gap score
     # templates longer than the widest lane (224 slots) in a set beyond one wave of the narrow layout: tiled over the
-    # virtual lanes of up to eight waves (sd_fast_wt.hip); the slot count with the least work per row, fewer waves on ties
+    # virtual lanes of up to eight waves (sd_fast_wt.hip); the slot count with the least SIMD time per row at the occupancy it gets
     st = synth.Stream(5, 5)
     rnd = lambda n: synth._to_ascii(st.below(n, 4))
-    t1 = lib.plan_info([rnd(330 + j % 20) for j in range(30)])                 # 60 templates of two 192-slot lanes: one wave
-    assert (t1["family"], t1["cells"], t1["cells_per_lane"], t1["waves"]) == ("fast", "f16/bf8-codes tiled x waves", 192, 1), t1
+    t1 = lib.plan_info([rnd(330 + j % 20) for j in range(30)])                 # 60 templates of four 96-slot lanes: two waves, four
+    assert (t1["family"], t1["cells"], t1["cells_per_lane"], t1["waves"]) == ("fast", "f16/bf8-codes tiled x waves", 96, 2), t1   # chunks per CU (one wave of 192 slots: six)
     t2 = lib.plan_info([rnd(400 + j) for j in range(100)])                     # 200 templates of two or three 224-slot lanes
     assert (t2["cells"], t2["cells_per_lane"], t2["waves"]) == ("f16/bf8-codes tiled x waves", 224, 4), t2
     t3 = lib.plan_info([rnd(1000)] * 5)                                        # ten templates of eleven lanes: one wave of 96 slots
