@@ -2529,6 +2529,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     job.threads = p->threads;
     build_chunk_table(reads, p, job.table, job.nch);
     if (info) info[3] = (int64_t)job.table.size();
+    lap("chunk table");
     job.row_off = static_cast<int64_t*>(std::calloc(reads.size() + 1, sizeof(int64_t)));
     if (!job.row_off) {
         close_all();
@@ -2562,6 +2563,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         rc = pipe.create(p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size());
         if (rc) err = pipe.eb;
     }
+    lap(reused ? "pipeline from the cache" : "engine (HIP runtime start, layout plan, tables, identity masks)");
     if (stream_ident) job.per = second_best ? (int)pp.interleaved_seqs().size() : 1;
     std::vector<std::pair<size_t, size_t>> batches;
     // --second-best makes the host side of a batch (2T identities' worth of text per row) as long as its kernels: a job
@@ -2573,7 +2575,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     }
     if (const char* ev = getenv("SD_MIN_BATCHES")) min_batches = std::max(1, atoi(ev));   // developer A/B
     if (rc == SD_OK) plan_batches(job.table, 0, job.table.size(), pipe.row_budget(), min_batches, batches);
-    lap("chunk table, engine");
+    lap("batch plan");
     const double t_setup = now_s() - t_begin;
     if (progress) std::fprintf(stderr, "Prepared reads\n");   // main.cpp:82
     // The rows of a batch are assembled on the driver thread (they come out of the engine's pinned buffer, which
