@@ -2573,6 +2573,14 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         const size_t nc = job.table.size();
         min_batches = nc >= 2048 ? 4 : nc >= 1024 ? 2 : 1;   // C4 shape, 2 560 chunks: 170 / 159 / 149 / 140 / 134+ ms for 1 / 2 / 3 / 4 / 5+
     }
+    // A process's first job pays for every byte it allocates: the driver scrubs memory another process released before
+    // it hands it out -- the 17 GB a 50-Mbp job takes as ONE batch cost 0.2-1.2 s, more than the job (0.3 s).  Such a
+    // job is cut into eight batches (two run side by side, stream mode 2), so that its buffers are an eighth as large;
+    // a pipeline that comes from the cache has its buffers, and a job of many batches allocates full-size ones once.
+    if (!reused && rc == SD_OK) {
+        const size_t nc = job.table.size();
+        min_batches = std::max(min_batches, nc >= 4096 ? 8 : nc >= 1024 ? 4 : 1);
+    }
     if (const char* ev = getenv("SD_MIN_BATCHES")) min_batches = std::max(1, atoi(ev));   // developer A/B
     if (rc == SD_OK) plan_batches(job.table, 0, job.table.size(), pipe.row_budget(), min_batches, batches);
     lap("batch plan");
