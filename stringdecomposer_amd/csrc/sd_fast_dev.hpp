@@ -306,11 +306,13 @@ struct ReadStream {
     int last;            // n - 1
     uint32_t cur, nxt;   // words holding rows [16k, 16k+16) and the following 16
     uint32_t ncur;
+    int adv_at;          // next row after which the words move on (one scalar compare per row instead of two tests)
     __device__ __forceinline__ void init(const uint32_t* w_, const uint32_t* nm_, int n) {
         w = w_; has_n = nm_ != nullptr; nmp = has_n ? nm_ : w_; last = n - 1;
         cur = w[0];
         nxt = w[last >= 16 ? 1 : 0];
         ncur = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmp[0]);
+        adv_at = 15 < last ? 15 : INT_MAX;
     }
     // code of row i; rows must be requested in non-decreasing order (clamped to the last row)
     __device__ __forceinline__ int code(int i) {
@@ -321,7 +323,8 @@ struct ReadStream {
     }
     // call after consuming row i
     __device__ __forceinline__ void advance(int i) {
-        if ((i & 15) == 15 && i < last) {
+        if (i == adv_at) {   // (i & 15) == 15 && i < last
+            adv_at = i + 16 < last ? i + 16 : INT_MAX;
             cur = nxt;
             const int k = (i >> 4) + 2;
             nxt = w[(k << 4) <= last ? k : (last >> 4)];

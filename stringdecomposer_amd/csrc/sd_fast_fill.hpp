@@ -116,6 +116,7 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     int base = 0, Brel = 0, tp = 0;
     uint32_t bdel16 = 0;  // HRED: fp16 bits of (row maximum + del), relative like the cells
     int accBV = 0;  // (B << 7 | arg-max virtual lane) of the last <=64 rows, one row per lane
+    int flush_at = min(n, 64);   // next row whose B word completes a group of 64 (or the chunk): one scalar compare per row
 
     // `after` pins the LDS reads behind the value it names (the last slot of the row being
     // finished): hoisted above the slot loop they would need a second register set + 35 copies
@@ -193,12 +194,13 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
                     mhi = __ballot(khi == kmin);
                 }
             }
-            const int vlo = __ffsll((long long)mlo) - 1, vhi = 63 + __ffsll((long long)mhi);  // both scalar
-            const int v = vlo >= 0 ? vlo : vhi;
+            // (some lane attains the maximum: ctz never sees two empty masks -- s_ff1 x 2, add, compare, select)
+            const int v = mlo ? __builtin_ctzll(mlo) : 64 + __builtin_ctzll(mhi);
             bdel16 = b16;
             const int slot = (row - 1) & 63;
             acc_put(accBV, (int)((b16 << 7) | (uint32_t)v), slot);
-            if (slot == 63 || row == n) {
+            if (row == flush_at) {   // slot == 63 || row == n
+                flush_at = min(n, row + 64);
                 // 64 rows at once: fp16 -> int, B = base + (b + del) - del + tp_row * ins
                 asm volatile("");   // keeps this a scalar branch: the lane test below is not evaluated on every row
                 const uint32_t w = (uint32_t)accBV;
@@ -233,7 +235,8 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
         Brel = b + tp * sc.ins;
         const int slot = (row - 1) & 63;
         acc_put(accBV, (int)(((uint32_t)(base + Brel) << 7) | (uint32_t)v), slot);
-        if (slot == 63 || row == n) {
+        if (row == flush_at) {   // slot == 63 || row == n
+            flush_at = min(n, row + 64);
             if (lane <= slot) Bc[row - slot + lane] = accBV;
         }
     };
