@@ -260,7 +260,9 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     uint32_t Eend = CO::mx(L[P - 1], K);
     if constexpr (!HRED) reduce_ends(Eend, 1);
 
-    for (int i = 1; i < n; ++i) {
+    // rows in groups of FAST_R: the per-group work (fairness, scan form, rebase, checkpoint) sits between two inner loops
+    // instead of behind a test in every row
+    for (int i = 1; i < n;) {
         if ((i & (FAST_R - 1)) == 0) {
             fair.update(n - i);
             bperm_scan = bperm_ok && (!fair.drained || ((Hx >> 9) & 1));
@@ -294,6 +296,8 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
             for (int s = 0; s < P; ++s) ck[(uint64_t)q * (P * 64) + s * 64] = CO::mx(L[s], K);
             if (lane == 0) ckb[q] = base + tp * sc.ins;
         }
+        const int iend = min(n, (i | (FAST_R - 1)) + 1);
+        for (; i < iend; ++i) {
         uint32_t KB;
         if constexpr (HRED) {
             // max(K, {b+del, b+del}): the scalar's low half feeds both lanes of the packed op
@@ -381,6 +385,7 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
             Eend = CO::mx(a, K);
             reduce_ends(Eend, i + 1);
         }
+        }   // rows of the group
     }
     if constexpr (F16) {
         guard.check_high(L);
