@@ -643,6 +643,17 @@ def main():
         # `peak` prices the 4.1 cycles at the 2.4-GHz peak clock; under this load the chip holds 2.27-2.33 GHz (the
         # micro-benchmark's wall time per instruction, profiles/r03_ubench_issue.txt: 1.806 ns per SIMD for the fill's
         # instruction mix at 4 waves per SIMD): what the machine delivered there, for reference
+        # In the default stream mode the launches of consecutive batches overlap (a fill starts in the previous fill's
+        # drain and shares the machine with the previous traceback), so `frac` -- instructions over the fill's own
+        # HIP-event span, as the contract asks -- falls when the overlap grows even if the step gets faster.  The figure
+        # that cannot be gamed by overlap: the vector instructions of BOTH kernels of a step over the step time.
+        roofline["frac_note"] = ("frac = fill instructions / the fill's in-stream HIP-event span (spans of consecutive batches "
+                                 "overlap in stream mode 2); isolated_frac = the same launch alone; step_frac = (fill + traceback "
+                                 "instructions) / step time, the issue slots the whole path uses")
+        if tj.get("traceback_SQ_INSTS_VALU_per_launch") and ws == 1 and args.sub_batches == 1:
+            both = valu["wave_insts_per_launch"] + tj["traceback_SQ_INSTS_VALU_per_launch"] * rows / tj["workload_rows"]
+            roofline["step_frac"] = both * K / dt / 1e9 / VALU_PEAK_GINST
+            valu["traceback_wave_insts_per_launch"] = tj["traceback_SQ_INSTS_VALU_per_launch"] * rows / tj["workload_rows"]
         valu["wall_ceiling_ginst"] = N_SIMDS / VALU_WALL_NS_PER_INST
         valu["isolated_frac_of_wall_ceiling"] = None if v_iso is None else v_iso / valu["wall_ceiling_ginst"]
     else:   # no instruction count for this workload / binary: only the notional figure

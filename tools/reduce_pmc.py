@@ -78,6 +78,11 @@ def main():
             ft["write_bytes"] = 1024.0 * h["WRITE_SIZE_KiB_median"]
             ft["hbm_bytes_per_launch"] = ft["fetch_bytes_corrected_x2"] + ft["write_bytes"]
             ft["kernel_instance"] = fill[0].split(":", 1)[1]
+            # the traceback of the same workload (the other kernel of a C2 step): for the step's combined issue fraction
+            tr = [k for k in res["valu"] if k.startswith("c2:sd_fast_trace")]
+            if tr:
+                ft["traceback_SQ_INSTS_VALU_per_launch"] = res["valu"][tr[0]]["SQ_INSTS_VALU_per_launch"]
+                ft["traceback_kernel_instance"] = tr[0].split(":", 1)[1]
             json.dump(ft, open(sys.argv[3], "w"), indent=1, sort_keys=True)
             print("updated", sys.argv[3])
 
