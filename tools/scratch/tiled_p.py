@@ -4,7 +4,7 @@ import numpy as np
 from stringdecomposer_amd import lib, synth
 NR = 128
 st = synth.Stream(11, 3)
-for nm, lo, hi in ((30, 330, 350), (100, 400, 500), (12, 900, 1100)):
+for nm, lo, hi in ((30, 330, 350), (100, 400, 500), (12, 900, 1100), (20, 700, 1100), (70, 300, 480)):
     anc = st.below(hi + 16, 4)
     ms = []
     for j in range(nm):
