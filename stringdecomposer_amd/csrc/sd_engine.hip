@@ -257,6 +257,7 @@ struct sd_engine {
     // --ed_thr with more than 128 templates (compacted fill, sd_fast_wn_ck.hip): per chunk the kept templates in
     // filtered order [T], every template's place [T], the kept count; the W chunk classes (by waves needed) and their sizes
     DevBuf<uint16_t> d_klist, d_kpos;
+    DevBuf<uint32_t> d_lanet;        // --ed_thr on the tiled layout: [chunk][W * 128] template | part << 16 of every lane (sd_tiled_place)
     DevBuf<int32_t> d_nkept;
     DevBuf<int> d_orders, d_cls;
     bool compact_edthr = false;
@@ -811,7 +812,8 @@ static void engine_alloc_batch(sd_engine* e, int64_t nck) {
             e->d_crank.alloc(C * 64 * (size_t)e->fplan.waves);
             // SD_FLAG_NO_EDTHR_COMPACT (SD_EDTHR_COMPACT=0 arrives as that flag through apply_env_overrides):
             // every chunk on the W-wave ranked kernel (A/B, tests)
-            e->compact_edthr = e->fplan.wide && e->fplan.waves > 1 && !e->fplan.tiled && !(e->p.reserved[1] & SD_FLAG_NO_EDTHR_COMPACT);
+            e->compact_edthr = e->fplan.wide && e->fplan.waves > 1 && !(e->p.reserved[1] & SD_FLAG_NO_EDTHR_COMPACT);
+            if (e->compact_edthr && e->fplan.tiled) e->d_lanet.alloc(C * (size_t)e->fplan.waves * 128);
             if (e->compact_edthr) {
                 e->d_klist.alloc(C * (size_t)e->T + 2);
                 e->d_kpos.alloc(C * (size_t)e->T);
@@ -1012,13 +1014,30 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                     // that need all W waves by the W-wave ranked kernel.  The class sizes stay on the device.
                     const int W = e->fplan.waves;
                     int* ord = e->d_orders.p;   // [W][C]: class w-1 = the chunks whose kept templates need w waves
+                    // tiled layout: the kept templates' lanes per chunk (d_kpos becomes "first lane", d_nkept "lanes used")
+                    if (e->fplan.tiled)
+                        sd::launch_tiled_place(st, C, e->T, e->fplan.P, W, e->d_klist.p, e->d_nkept.p, e->d_tlen.p,
+                                               e->d_kpos.p, e->d_lanet.p);
                     sd::launch_split_order(st, e->dp_order, C, e->d_nkept.p, ord, e->d_cls.p, W);
                     for (int w = 1; w < W; ++w)
+                        if (e->fplan.tiled)
+                            sd::launch_fast_fill_wt_compact(e->fplan, st, e->dp_chunks, e->dp_bases2, e->dp_nmask, e->d_flane.p,
+                                                            e->sc, e->d_B.p, e->d_fckpt.p, e->d_fckbase.p,
+                                                            w == 1 ? qfill : qfill + 1 + w, ord + (size_t)(w - 1) * C,
+                                                            e->d_cls.p + (w - 1), e->n_cu, e->d_lanet.p, e->d_ftcodes.p,
+                                                            e->d_toff.p, e->d_tlen.p, w);
+                        else
                         sd::launch_fast_fill_wn_compact(e->fplan, st, e->dp_chunks, e->dp_bases2, e->dp_nmask, e->d_flane.p,
                                                         e->sc, e->d_B.p, e->d_fckpt.p, e->d_fckbase.p,
                                                         w == 1 ? qfill : qfill + 1 + w, ord + (size_t)(w - 1) * C,
                                                         e->d_cls.p + (w - 1), e->n_cu, e->d_klist.p, e->d_ftcodes.p,
                                                         e->d_toff.p, e->d_tlen.p, w);
+                    if (e->fplan.tiled)
+                        sd::launch_fast_fill_wt(e->fplan, st, e->dp_chunks, C, e->dp_bases2, e->dp_nmask, e->d_ftable.p,
+                                                e->d_flane.p, e->sc, e->d_B.p, e->d_fckpt.p, e->d_fckbase.p, qfill + 2,
+                                                ord + (size_t)(W - 1) * C, e->n_cu, e->d_cendoff.p, e->d_crank.p,
+                                                e->d_cls.p + (W - 1));
+                    else
                     sd::launch_fast_fill_wn(e->fplan, st, e->dp_chunks, C, e->dp_bases2, e->dp_nmask, e->d_ftable.p,
                                             e->d_flane.p, e->sc, e->d_B.p, e->d_fckpt.p, e->d_fckbase.p, qfill + 2,
                                             ord + (size_t)(W - 1) * C, e->n_cu, e->d_cendoff.p, e->d_crank.p,
@@ -1037,7 +1056,8 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                                       e->d_tlen.p, e->sc, e->d_B.p, e->d_argB.p, e->d_fckpt.p,
                                       e->d_fckbase.p, e->d_recs.p, e->d_cnt.p, qtrace, e->dp_order,
                                       e->n_cu, compact ? e->d_klist.p : nullptr, compact ? e->d_kpos.p : nullptr,
-                                      compact ? e->d_nkept.p : nullptr, e->fplan.tr2_ok ? e->d_ftr2.p : nullptr);
+                                      compact ? e->d_nkept.p : nullptr, e->fplan.tr2_ok ? e->d_ftr2.p : nullptr,
+                                      compact && e->fplan.tiled ? e->d_lanet.p : nullptr);
                 SD_HIP(hipEventRecord(e->ev_trace[1], ts));
                 e->fill_launches = 1;
             }

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(64 * trace_waves_per_group(QK), (QK <= 4 ? SD_TRACE
     const uint32_t* __restrict__ ckpt, const int32_t* __restrict__ ckbase,
     DevRec* __restrict__ recs, int32_t* __restrict__ rec_cnt, int* __restrict__ queue,
     const int* __restrict__ order, int ckf16, int bshift, int W, const uint16_t* __restrict__ klist,
-    const uint16_t* __restrict__ kpos, const int32_t* __restrict__ nkept, int T) {
+    const uint16_t* __restrict__ kpos, const int32_t* __restrict__ nkept, int T,
+    const uint32_t* __restrict__ lane_t) {   // compacted TILED chunks (sd_tiled_place): lane table; kpos = first lane of a template
     // QK = ceil(Lmax / 64) cells per lane: 1..8 for templates of up to 512 bp; 16 / 32 for the long ones (up to 2048 bp:
     // a handful of templates, each over up to 32 virtual lanes of the fill)
     constexpr int QP = QK <= 4 ? 4 : QK <= 8 ? 8 : QK <= 16 ? 16 : 32;   // cells per lane rounded up to whole 8-byte loads
@@ -86,7 +87,9 @@ __global__ __launch_bounds__(64 * trace_waves_per_group(QK), (QK <= 4 ? SD_TRACE
     const bool cmp = klist != nullptr && nkept[c] <= 128 * (W - 1);
     const uint16_t* klc = cmp ? klist + (size_t)c * (size_t)T : nullptr;
     const uint16_t* kpc = cmp ? kpos + (size_t)c * (size_t)T : nullptr;
+    const uint32_t* ltc = (cmp && lane_t) ? lane_t + (size_t)c * (size_t)(W * 128) : nullptr;
     auto tmpl_of = [&](int v) {
+        if (ltc) return (int)(ltc[v] & 0xffffu);   // tiled: any lane of the template names it
         if (cmp) return (int)klc[v];   // v = (wave << 7) | virtual lane = the place in the filtered order
         const uint32_t t = lane_consts[(((v >> 7) << 6) | (v & 63)) * FAST_LANE_WORDS + FLC_TMPL];
         return (int)(((v >> 6) & 1) ? (t >> 16) : (t & 0xffffu));
@@ -116,7 +119,9 @@ __global__ __launch_bounds__(64 * trace_waves_per_group(QK), (QK <= 4 ? SD_TRACE
             for (int q = 0; q < QQ; ++q) {
                 const int kk = lane * QQ + q;
                 cl.code[q] = kk < Lj ? (int)tcodes[x0 + kk] : 7;
-                cl.slot[q] = kk < Lj ? (cmp ? ((((int)kpc[j] >> 7) << 16) | (kk << 7) | ((int)kpc[j] & 127))
+                // compacted chunk: one lane per template, slot = cell -- or, tiled, lane = first lane + cell / P
+                const int gl = ltc ? (int)kpc[j] + kk / P : (cmp ? (int)kpc[j] : 0);
+                cl.slot[q] = kk < Lj ? (cmp ? (((gl >> 7) << 16) | ((ltc ? kk % P : kk) << 7) | (gl & 127))
                                                  : (int)slot_of[x0 + kk]) : 0;
 #pragma unroll
                 for (int b = 0; b < 5; ++b) mt[b][lane][q] = (int16_t)(4 * ((cl.code[q] == b ? mD : xD) - ins) - 1);
@@ -821,7 +826,7 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
                        const int32_t* tlen, ScoreArgs sc, const int32_t* B, const int32_t* argV,
                        const uint32_t* ckpt, const int32_t* ckbase, DevRec* recs,
                        int32_t* rec_cnt, int* queue, const int* order, int n_cu, const uint16_t* klist,
-                       const uint16_t* kpos, const int32_t* nkept, const uint32_t* tr2_tab) {
+                       const uint16_t* kpos, const int32_t* nkept, const uint32_t* tr2_tab, const uint32_t* lane_t) {
     // the packed two-block form where the plan has it (narrow layout, templates <= 248 bp, 16-bit tagged range)
     if (klist == nullptr && launch_fast_trace2(plan, st, chunks, n_chunks, bases2, nmask, lane_consts, tcodes, toff, tlen, sc,
                                                B, ckpt, ckbase, tr2_tab, recs, rec_cnt, queue, order, n_cu))
@@ -835,7 +840,7 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
     hipLaunchKernelGGL(sd_fast_trace<QQ>, dim3(grid), dim3(64 * trace_waves_per_group(QQ)), 0, st, chunks, n_chunks, bases2, \
                        nmask, slot_of, tcodes, lane_consts, toff, tlen, sc, plan.P, B, argV, ckpt, \
                        ckbase, recs, rec_cnt, queue, order, plan.f16 ? 1 : 0, plan.bshift, plan.waves, klist, kpos, \
-                       nkept, plan.T)
+                       nkept, plan.T, lane_t)
     switch (plan.Qk) {
         case 1: SD_TRACE(1); break;
         case 2: SD_TRACE(2); break;

@@ -103,6 +103,9 @@ void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, 
                                                    // and all have that many words (sd_hw_dist_u); -1: general kernel
                          const int32_t* vlane0 = nullptr);   // first virtual lane of each template (narrow layout)
 // --ed_thr with more than 128 templates: the chunk order split into W classes by ceil(kept templates / 128)
+// --ed_thr on the tiled multi-wave layout: per chunk, the kept templates' lanes (sd_filter.hip: sd_tiled_place)
+void launch_tiled_place(hipStream_t st, int n_chunks, int T, int P, int W, const uint16_t* klist, int32_t* nkept,
+                        const int32_t* tlen, uint16_t* kpos, uint32_t* lane_t);
 void launch_split_order(hipStream_t st, const int* order, int n, const int32_t* nkept, int* orders, int* counts,
                         int W);   // orders: [W][n] -- class w-1 = the chunks that need w waves, in the given order
 
@@ -155,7 +158,14 @@ void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* 
 void launch_fast_fill_wt(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                          const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                          const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
-                         int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank);
+                         int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank,
+                         const int* n_ptr = nullptr);   // n_ptr: the number of chunks lives on the device (order = a class list)
+// --ed_thr on the tiled layout: one class of chunks, filled by wb waves holding their kept templates (lane_t: sd_tiled_place)
+void launch_fast_fill_wt_compact(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, const uint32_t* bases2,
+                                 const uint32_t* nmask, const uint32_t* lane_consts, ScoreArgs sc, int32_t* B,
+                                 uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order_w, const int* n_ptr,
+                                 int n_cu, const uint32_t* lane_t, const uint8_t* tcodes, const int32_t* toff,
+                                 const int32_t* tlen, int wb);
 // --ed_thr, more than 128 templates: one class of chunks, filled by wb waves holding their kept templates (sd_fast_wn_ck.hip)
 void launch_fast_fill_wn_compact(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, const uint32_t* bases2,
                                  const uint32_t* nmask, const uint32_t* lane_consts, ScoreArgs sc, int32_t* B,
@@ -176,6 +186,7 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
                        const uint32_t* ckpt, const int32_t* ckbase, DevRec* recs,
                        int32_t* rec_cnt, int* queue, const int* order, int n_cu,
                        const uint16_t* klist = nullptr, const uint16_t* kpos = nullptr, const int32_t* nkept = nullptr,
-                       const uint32_t* tr2_tab = nullptr);   // device copy of FastPlan::tr2_tab: the second form where it applies
+                       const uint32_t* tr2_tab = nullptr,
+                       const uint32_t* lane_t = nullptr);   // compacted tiled chunks: the lane table (kpos = first lanes then)   // device copy of FastPlan::tr2_tab: the second form where it applies
 
 }  // namespace sd

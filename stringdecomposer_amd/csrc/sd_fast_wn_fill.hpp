@@ -45,10 +45,10 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     int* __restrict__ queue, const int* __restrict__ order, const uint32_t* __restrict__ cendoff,
     const uint32_t* __restrict__ crank, const int* __restrict__ n_ptr, const uint16_t* __restrict__ klist,
     const uint8_t* __restrict__ tcodes, const int32_t* __restrict__ toff, const int32_t* __restrict__ tlen,
-    int klist_stride, int Hx = 0) {   // Hx (TILED): carry hops | 1-bp templates present << 8
+    int klist_stride, int Hx = 0,     // Hx (TILED): carry hops | 1-bp templates present << 8
+    const uint32_t* __restrict__ lane_t = nullptr) {   // COMPACT && TILED: [chunk][W * 128] template | part << 16 of every virtual lane
     static_assert(P % 16 == 0, "the code table is streamed 16 slots at a time");
     static_assert(!(COMPACT && RANKED), "the compacted form needs no ranks");
-    static_assert(!(COMPACT && TILED), "the compacted form holds one template per virtual lane");
     constexpr int G = P / 16;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [W][G][2 halves][64 lanes][4 dwords] codes, then the exchange area
     if (n_ptr) n_chunks = *n_ptr;      // the size of a chunk class is known on the device only
@@ -69,16 +69,16 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     uint32_t* myc = lds + wave * (G * 512);
     const uint32_t* lc = lane_consts + (size_t)(wave * 64 + lane) * FAST_LANE_WORDS;
     const uint32_t endOffPlan = lc[FLC_ENDOFF];
-    const uint32_t row0adj = CO::from_i16x2(lc[FLC_ROW0]);
+    uint32_t row0adj = CO::from_i16x2(lc[FLC_ROW0]);   // (not const: the compacted tiled form derives the lane constants per chunk)
     const uint32_t ins2 = CO::splat(sc.ins);
     constexpr uint32_t NEGC = CO::NEG;
-    const uint32_t startMask = TILED ? lc[FLC_STARTMASK] : 0xffffffffu;
-    const uint32_t contMask = TILED ? lc[FLC_CONTMASK] : 0u;
+    uint32_t startMask = TILED ? lc[FLC_STARTMASK] : 0xffffffffu;
+    uint32_t contMask = TILED ? lc[FLC_CONTMASK] : 0u;
     const int H = Hx & 0xff;
     // a 1-bp template ends in slot 0 (FLC_ONE): the pads behind a k = 0 cell keep their old value when the cell's falls
     // (no insertion move there, main.cpp:188-193); one wave-uniform branch per row of >= 96 slots
     const bool has_one = TILED && ((Hx >> 8) & 1);
-    const uint32_t oneMask = TILED ? lc[FLC_ONE] : 0u;
+    uint32_t oneMask = TILED ? lc[FLC_ONE] : 0u;
     // exclusive, template-segmented prefix maximum of the lane totals (both planes at once): H = Vmax - 1 hops
     auto excl_scan = [&](uint32_t a) {
         uint32_t inc = a;
@@ -104,22 +104,48 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
         uint32_t endOffC = 0;
         if constexpr (COMPACT) {
             // this lane's two templates (lo plane: place 128 wave + lane of the filtered order, hi plane: + 64);
-            // klist: [chunk][T], 0xffff behind the kept ones
+            // klist: [chunk][T], 0xffff behind the kept ones.  TILED: the placement kernel's lane table instead
+            // (sd_tiled_place: template | part << 16 of every virtual lane, 0xffffffff = idle) -- the lane holds the cells
+            // [part * P, part * P + P) of its template, and the lane constants of the carry follow from (part, parts).
             const int T = klist_stride;
-            const uint16_t* kl = klist + (size_t)c * (size_t)T;
-            const int plo = 128 * wave + lane, phi_ = plo + 64;
-            const int tlo = plo < T ? kl[plo] : 0xffff, thi = phi_ < T ? kl[phi_] : 0xffff;
+            int tlo, thi, ulo = 0, uhi = 0;
+            if constexpr (TILED) {
+                const uint32_t* lt = lane_t + (size_t)c * (size_t)(W * 128) + 128 * wave + lane;
+                const uint32_t elo_ = lt[0], ehi_ = lt[64];
+                tlo = elo_ == 0xffffffffu ? 0xffff : (int)(elo_ & 0xffffu);
+                thi = ehi_ == 0xffffffffu ? 0xffff : (int)(ehi_ & 0xffffu);
+                ulo = tlo != 0xffff ? (int)(elo_ >> 16) : 0;
+                uhi = thi != 0xffff ? (int)(ehi_ >> 16) : 0;
+            } else {
+                const uint16_t* kl = klist + (size_t)c * (size_t)T;
+                const int plo = 128 * wave + lane, phi_ = plo + 64;
+                tlo = plo < T ? kl[plo] : 0xffff;
+                thi = phi_ < T ? kl[phi_] : 0xffff;
+            }
             const int Llo = tlo != 0xffff ? tlen[tlo] : 0, Lhi = thi != 0xffff ? tlen[thi] : 0;
-            const uint8_t* clo = tcodes + (tlo != 0xffff ? toff[tlo] : 0);
-            const uint8_t* chi = tcodes + (thi != 0xffff ? toff[thi] : 0);
+            const int klo = ulo * P, khi = uhi * P;   // first cell of the lane
+            const uint8_t* clo = tcodes + (tlo != 0xffff ? toff[tlo] : 0) + klo;
+            const uint8_t* chi = tcodes + (thi != 0xffff ? toff[thi] : 0) + khi;
+            const int nlo = Llo - klo, nhi = Lhi - khi;   // cells from there on (more than P: the next lane's)
             for (int dw = 0; dw < G * 8; ++dw) {       // dword dw of the lane: slots 2 dw, 2 dw + 1 as {lo, hi, lo, hi}
                 const int a = 2 * dw;
-                const uint32_t b0 = a < Llo ? clo[a] : 7u, b1 = a < Lhi ? chi[a] : 7u;
-                const uint32_t b2 = a + 1 < Llo ? clo[a + 1] : 7u, b3 = a + 1 < Lhi ? chi[a + 1] : 7u;
+                const uint32_t b0 = a < nlo ? clo[a] : 7u, b1 = a < nhi ? chi[a] : 7u;
+                const uint32_t b2 = a + 1 < nlo ? clo[a + 1] : 7u, b3 = a + 1 < nhi ? chi[a + 1] : 7u;
                 myc[(dw >> 2) * 256 + lane * 4 + (dw & 3)] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
             }
-            const int elo = Llo ? (Llo - 1) * sc.del : -32768, ehi = Lhi ? (Lhi - 1) * sc.del : -32768;
+            // the end of a template sits in its last lane
+            const bool endlo = Llo > 0 && nlo <= P, endhi = Lhi > 0 && nhi <= P;
+            const int elo = endlo ? (Llo - 1) * sc.del : -32768, ehi = endhi ? (Lhi - 1) * sc.del : -32768;
             endOffC = ((uint32_t)elo & 0xffffu) | ((uint32_t)ehi << 16);
+            if constexpr (TILED) {
+                const uint32_t slo = (tlo == 0xffff || ulo == 0) ? 0xffffu : 0u, shi = (thi == 0xffff || uhi == 0) ? 0xffffu : 0u;
+                startMask = slo | (shi << 16);
+                contMask = ~startMask;
+                oneMask = (Llo == 1 ? 0xffffu : 0u) | (Lhi == 1 ? 0xffff0000u : 0u);
+                const int rlo = (tlo != 0xffff && ulo == 0) ? sc.ins + sc.del : sc.ins;
+                const int rhi = (thi != 0xffff && uhi == 0) ? sc.ins + sc.del : sc.ins;
+                row0adj = CO::from_i16x2(((uint32_t)rlo & 0xffffu) | ((uint32_t)rhi << 16));
+            }
         }
         const uint32_t endOff = CO::from_i16x2(COMPACT ? endOffC : RANKED ? cendoff[cl] : endOffPlan);
         const uint32_t rank2 = RANKED ? crank[cl] : 0u;

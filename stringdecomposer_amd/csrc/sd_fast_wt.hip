@@ -20,7 +20,8 @@ namespace sd {
 void launch_fast_fill_wt(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, int n_chunks,
                          const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                          const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase,
-                         int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank) {
+                         int* queue, const int* order, int n_cu, const uint32_t* cendoff, const uint32_t* crank,
+                         const int* n_ptr) {
     const int W = plan.waves;
     const size_t lds = ((size_t)W * (plan.P / 16) * 512 + 64) * sizeof(uint32_t);
     // two waves per SIMD (the register budget of the kernel), and as many workgroups per CU as their LDS allows
@@ -34,7 +35,7 @@ void launch_fast_fill_wt(const FastPlan& plan, hipStream_t st, const ChunkDesc* 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
         hipLaunchKernelGGL((sd_fast_fill_wn<PP, RK, FLV, false, true>), dim3(grid), dim3(W * 64), lds, st, chunks,  \
                            n_chunks, bases2, nmask, table, lane_consts, sc, W, plan.bf8_match, plan.bf8_mismatch, B, \
-                           ckpt, ckbase, queue, order, cendoff, crank, nullptr, nullptr, nullptr, nullptr, nullptr, 0, \
+                           ckpt, ckbase, queue, order, cendoff, crank, n_ptr, nullptr, nullptr, nullptr, nullptr, 0,   \
                            plan.H | (((plan.Hx >> 10) & 1) << 8));                                                                                \
     }
 #define SD_FILLWT(PP)                                                               \
@@ -48,6 +49,39 @@ void launch_fast_fill_wt(const FastPlan& plan, hipStream_t st, const ChunkDesc* 
     }
 #undef SD_FILLWT
 #undef SD_FILLWT_K
+}
+
+// --ed_thr: the chunks whose kept templates need wb < W waves, filled by wb waves that hold exactly those (the point of
+// the reference's prefilter, main.cpp:128-149: less DP work) -- the compacted form of sd_fast_wn_ck.hip with the
+// per-chunk lane table of sd_tiled_place in place of "one kept template per lane".
+void launch_fast_fill_wt_compact(const FastPlan& plan, hipStream_t st, const ChunkDesc* chunks, const uint32_t* bases2,
+                                 const uint32_t* nmask, const uint32_t* lane_consts, ScoreArgs sc, int32_t* B,
+                                 uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order_w, const int* n_ptr,
+                                 int n_cu, const uint32_t* lane_t, const uint8_t* tcodes, const int32_t* toff,
+                                 const int32_t* tlen, int wb) {
+    const size_t lds = ((size_t)wb * (plan.P / 16) * 512 + 64) * sizeof(uint32_t);
+    const int per_cu = std::max(1, std::min(8 / wb, (int)((size_t)160 * 1024 / lds)));
+    const int grid = per_cu * n_cu;
+    const bool fl48 = !plan.full_floor && plan.floor_slots >= 1 && plan.floor_slots <= 48;
+#define SD_CKT_K(PP, FLV)                                                                                          \
+    {                                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill_wn<PP, false, FLV, true, true>),      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+        hipLaunchKernelGGL((sd_fast_fill_wn<PP, false, FLV, true, true>), dim3(grid), dim3(64 * wb), lds, st, chunks, \
+                           0, bases2, nmask, nullptr, lane_consts, sc, plan.waves, plan.bf8_match, plan.bf8_mismatch, \
+                           B, ckpt, ckbase, queue, order_w, nullptr, nullptr, n_ptr, nullptr, tcodes, toff, tlen,   \
+                           plan.T, plan.H | (((plan.Hx >> 10) & 1) << 8), lane_t);                                  \
+    }
+#define SD_CKT(PP)                                              \
+    case PP:                                                    \
+        if (fl48) SD_CKT_K(PP, 48) else SD_CKT_K(PP, PP)        \
+        break;
+    switch (plan.P) {
+        SD_CKT(96) SD_CKT(128) SD_CKT(160) SD_CKT(192) SD_CKT(224)
+        default: break;
+    }
+#undef SD_CKT
+#undef SD_CKT_K
 }
 
 }  // namespace sd

@@ -283,6 +283,42 @@ __global__ __launch_bounds__(64) void sd_split_order(const int* __restrict__ ord
         if (lane == w) counts[w] = cnt[w];
 }
 
+// --ed_thr on the tiled multi-wave layout (sd_fast_wt.hip): the kept templates of a chunk, in their filtered order, over
+// consecutive virtual lanes -- ceil(L / P) lanes each, never across a plane (64 lanes), as fast_plan_build places the
+// whole set.  One thread per chunk (a serial walk: where a template starts depends on the padding before it).
+// Out: first lane of every kept template (into the place table kpos, which the tiled traceback reads as such), the
+// template | part << 16 of every lane (lane_t, 0xffffffff = idle; cleared by the launcher), and the lanes used (into
+// nkept, which the class split and the traceback read as "what the chunk needs": more than 128 (W - 1) = all W waves,
+// the ranked kernel on the plan's layout).
+__global__ void sd_tiled_place(int n_chunks, int T, int P, int W, const uint16_t* __restrict__ klist,
+                               int32_t* __restrict__ nkept, const int32_t* __restrict__ tlen,
+                               uint16_t* __restrict__ kpos, uint32_t* __restrict__ lane_t) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const int nk = nkept[c];
+    const uint16_t* kl = klist + (size_t)c * (size_t)T;
+    uint32_t* lt = lane_t + (size_t)c * (size_t)(W * 128);
+    int cur = 0;
+    for (int r = 0; r < nk; ++r) {
+        const int j = kl[r];
+        const int V = (tlen[j] + P - 1) / P;
+        if (V > 64 - (cur & 63)) cur = (cur + 63) & ~63;
+        if (cur + V > W * 128) { cur = W * 128 + 1; break; }   // (padding in another order than the plan's: all W waves)
+        kpos[(size_t)c * (size_t)T + (size_t)j] = (uint16_t)cur;
+        for (int u = 0; u < V; ++u) lt[cur + u] = (uint32_t)j | ((uint32_t)u << 16);
+        cur += V;
+    }
+    nkept[c] = cur;
+}
+
+void launch_tiled_place(hipStream_t st, int n_chunks, int T, int P, int W, const uint16_t* klist, int32_t* nkept,
+                        const int32_t* tlen, uint16_t* kpos, uint32_t* lane_t) {
+    const size_t words = (size_t)n_chunks * (size_t)W * 128;
+    hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, lane_t, words, 0xffffffffu);
+    hipLaunchKernelGGL(sd_tiled_place, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), 0, st, n_chunks, T, P, W, klist, nkept,
+                       tlen, kpos, lane_t);
+}
+
 void launch_split_order(hipStream_t st, const int* order, int n, const int32_t* nkept, int* orders, int* counts, int W) {
     hipLaunchKernelGGL(sd_split_order, dim3(1), dim3(64), 0, st, order, n, nkept, orders, counts, W);
 }

@@ -625,8 +625,8 @@ def test_tiled_multiwave_layout_vs_oracle(oracle, nm, lo, hi, waves):
     """csrc/sd_fast_wt.hip: template sets beyond the narrow layout (8192 cells in one wave) whose templates are longer
     than the widest lane (224 slots) -- a template lies over several virtual lanes of one of up to eight waves and the
     deletion chain crosses lanes and 32-row checkpoints.  Reads long enough for a dozen rebases of the fp16 state, N in
-    reads and templates, small chunks (many seams), --ed_thr (ranked form: per-chunk end offsets on every lane of a
-    template), against the oracle and the generic family."""
+    reads and templates, small chunks (many seams), --ed_thr (compacted: a chunk's kept templates re-dealt over as many
+    waves as they need; and the ranked form: per-chunk end offsets on every lane of a template), against the oracle."""
     st = synth.Stream(9090 + nm, hi)
     ms = _random_monomers(st, nm, lo, hi, with_n=True)
     mn = ["m%d" % j for j in range(nm)]
@@ -657,6 +657,9 @@ def test_tiled_multiwave_layout_vs_oracle(oracle, nm, lo, hi, waves):
         got = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed)
         assert got == exp, (nm, sc, part, ed)
         assert lib.guard_trips() == 0
+        if ed >= 0:   # the filter compacts a chunk's kept templates into fewer waves (sd_tiled_place); without: every template, ranked
+            full = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed, flags=lib.FLAG_NO_EDTHR_COMPACT)
+            assert full == exp, (nm, sc, part, ed, "ranked form")
 
 
 def _late_base_monomers():
