@@ -11,8 +11,9 @@
 //
 // Outputs as the multi-wave wide fill: checkpoints [checkpoint][wave][P][64] (true values, max(cell, carry)), one word
 // per row (B_i << 10) | (wave << 7 | virtual lane) -> sd_fast_trace (bshift = 10), whose cell -> (wave, lane, slot) map
-// (FastPlan::slot_of) knows the tiling.  --ed_thr runs the ranked form (per-chunk end offsets and ranks on every lane
-// of a template, sd_rank_keep); the compacted form of sd_fast_wn_ck.hip assumes one template per lane and is not used.
+// (FastPlan::slot_of) knows the tiling.  --ed_thr: the chunks whose kept templates need fewer than W waves are filled by
+// that many (launch_fast_fill_wt_compact below: per-chunk lane table from sd_tiled_place), the others by the ranked form
+// (per-chunk end offsets and ranks on every lane of a template, sd_rank_keep).
 #include "sd_fast_wn_fill.hpp"
 
 namespace sd {
