@@ -834,7 +834,9 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
     int bpc = 8;
     if (const char* ev = getenv("SD_TRACE_BPC")) bpc = std::max(1, atoi(ev));  // developer knob
     int grid = std::min((n_chunks + 3) / 4, bpc * n_cu);  // persistent: 8 workgroups of 4 waves per CU
-    if (plan.Qk > 8) grid = std::min(n_chunks, 4 * n_cu);   // long templates: one wave per workgroup (36 KB of LDS each)
+    // long templates: one wave per workgroup; 16 cells per lane: 239 registers and 18 KB of LDS, two waves per SIMD (5.2 ->
+    // 3.4 ms on five 1-kb monomers); 32 cells per lane: 412 registers, one
+    if (plan.Qk > 8) grid = std::min(n_chunks, (plan.Qk == 16 ? 8 : 4) * n_cu);
     if (const char* ev = getenv("SD_TRACE_GRID")) grid = std::max(1, atoi(ev));   // developer knob
 #define SD_TRACE(QQ)                                                                              \
     hipLaunchKernelGGL(sd_fast_trace<QQ>, dim3(grid), dim3(64 * trace_waves_per_group(QQ)), 0, st, chunks, n_chunks, bases2, \
