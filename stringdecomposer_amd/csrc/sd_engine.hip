@@ -439,7 +439,8 @@ static int engine_pick_family(sd_engine* e, bool allow_f16, std::string& err) {
     const bool no_f16 = !allow_f16 || (p->reserved[1] & SD_FLAG_NO_F16);
     // the packed two-block traceback unless switched off, and not after a range guard tripped (its own check raises the same flag)
     const bool tr2 = allow_f16 && !(p->reserved[1] & SD_FLAG_TRACE_V1);
-    const bool fast_ok = sd::fast_plan_build(e->tseq, e->sc, p->part_size + p->overlap, e->fplan, why, !no_f16, tr2);
+    const bool fast_ok = sd::fast_plan_build(e->tseq, e->sc, p->part_size + p->overlap, e->fplan, why, !no_f16, tr2,
+                                             p->ed_thr > -1 && !(p->reserved[1] & SD_FLAG_NO_EDTHR_COMPACT));
     e->fplan.full_floor = (p->reserved[1] & SD_FLAG_FULL_FLOOR) != 0;
     e->sc.rebase_mask = fast_ok ? e->fplan.rebase - 1 : 127;
     if (family == 0) family = fast_ok ? 2 : 1;
@@ -516,7 +517,8 @@ int sd_plan_info(const sd_params* p, const char* const* mono_seqs, const int32_t
     std::string why;
     sd_params pe = *p;
     apply_env_overrides(pe);
-    const bool ok = sd::fast_plan_build(tseq, sc, p->part_size + p->overlap, plan, why, !(pe.reserved[1] & SD_FLAG_NO_F16));
+    const bool ok = sd::fast_plan_build(tseq, sc, p->part_size + p->overlap, plan, why, !(pe.reserved[1] & SD_FLAG_NO_F16), true,
+                                        pe.ed_thr > -1 && !(pe.reserved[1] & SD_FLAG_NO_EDTHR_COMPACT));
     for (int i = 0; i < 8; ++i) info[i] = 0;
     info[0] = ok ? 2 : 1;                       // kernel family "auto" would take: 2 fast, 1 generic
     if (!ok) { set_err(errbuf, errlen, why); return SD_OK; }
@@ -1017,7 +1019,7 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                     // tiled layout: the kept templates' lanes per chunk (d_kpos becomes "first lane", d_nkept "lanes used")
                     if (e->fplan.tiled)
                         sd::launch_tiled_place(st, C, e->T, e->fplan.P, W, e->d_klist.p, e->d_nkept.p, e->d_tlen.p,
-                                               e->d_kpos.p, e->d_lanet.p);
+                                               e->d_kpos.p, e->d_lanet.p, e->fplan.filter_only ? e->d_guard.p : nullptr);
                     sd::launch_split_order(st, e->dp_order, C, e->d_nkept.p, ord, e->d_cls.p, W);
                     for (int w = 1; w < W; ++w)
                         if (e->fplan.tiled)
@@ -1032,7 +1034,12 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                                                         w == 1 ? qfill : qfill + 1 + w, ord + (size_t)(w - 1) * C,
                                                         e->d_cls.p + (w - 1), e->n_cu, e->d_klist.p, e->d_ftcodes.p,
                                                         e->d_toff.p, e->d_tlen.p, w);
-                    if (e->fplan.tiled)
+                    if (e->fplan.filter_only)   // no layout of the whole set: the chunks that need all W waves are compacted too
+                        sd::launch_fast_fill_wt_compact(e->fplan, st, e->dp_chunks, e->dp_bases2, e->dp_nmask, e->d_flane.p,
+                                                        e->sc, e->d_B.p, e->d_fckpt.p, e->d_fckbase.p, qfill + 2,
+                                                        ord + (size_t)(W - 1) * C, e->d_cls.p + (W - 1), e->n_cu,
+                                                        e->d_lanet.p, e->d_ftcodes.p, e->d_toff.p, e->d_tlen.p, W);
+                    else if (e->fplan.tiled)
                         sd::launch_fast_fill_wt(e->fplan, st, e->dp_chunks, C, e->dp_bases2, e->dp_nmask, e->d_ftable.p,
                                                 e->d_flane.p, e->sc, e->d_B.p, e->d_fckpt.p, e->d_fckbase.p, qfill + 2,
                                                 ord + (size_t)(W - 1) * C, e->n_cu, e->d_cendoff.p, e->d_crank.p,

@@ -84,9 +84,16 @@ __global__ __launch_bounds__(64 * trace_waves_per_group(QK), (QK <= 4 ? SD_TRACE
 
     // --ed_thr with more than 128 templates: a chunk filled in the compacted form (sd_fast_wn_ck.hip) has its kept
     // templates, in their filtered order, in the virtual lanes of its first ceil(kept / 128) waves
-    const bool cmp = klist != nullptr && nkept[c] <= 128 * (W - 1);
-    const uint16_t* klc = cmp ? klist + (size_t)c * (size_t)T : nullptr;
-    const uint16_t* kpc = cmp ? kpos + (size_t)c * (size_t)T : nullptr;
+    // (lane_t with T < 0: FastPlan::filter_only -- every chunk is compacted, up to all W waves; a chunk whose kept
+    // templates did not fit was not filled, count -1: no records, the host repeats the batch)
+    if (klist != nullptr && nkept[c] < 0) {
+        if (lane == 0) rec_cnt[c] = 0;
+        continue;
+    }
+    const bool cmp = klist != nullptr && (T < 0 || nkept[c] <= 128 * (W - 1));
+    const int Tk = T < 0 ? -T : T;
+    const uint16_t* klc = cmp ? klist + (size_t)c * (size_t)Tk : nullptr;
+    const uint16_t* kpc = cmp ? kpos + (size_t)c * (size_t)Tk : nullptr;
     const uint32_t* ltc = (cmp && lane_t) ? lane_t + (size_t)c * (size_t)(W * 128) : nullptr;
     auto tmpl_of = [&](int v) {
         if (ltc) return (int)(ltc[v] & 0xffffu);   // tiled: any lane of the template names it
@@ -316,7 +323,7 @@ static int code_of(char ch) {
 }
 
 bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max_rows,
-                     FastPlan& plan, std::string& why, bool allow_f16, bool allow_tr2) {
+                     FastPlan& plan, std::string& why, bool allow_f16, bool allow_tr2, bool filter_only_ok) {
     (void)max_rows;
     plan = FastPlan();
     const int T = (int)tseq.size();
@@ -420,6 +427,21 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
                 static const int eff_pct[9] = {0, 21, 43, 64, 85, 72, 80, 87, 100};   // by waves per CU
                 const int64_t cost = (int64_t)Wp * (9 * p / 2 + 60) * 100 / eff_pct[std::min(8, per_cu * Wp)];
                 if (P == 0 || cost < best_cost) { P = p; bestW = Wp; best_cost = cost; tiled_v0.swap(v0); }
+            }
+            if (P == 0 && filter_only_ok) {
+                // --ed_thr: the set as a whole does not fit eight waves, a chunk's KEPT templates mostly do (the reason the
+                // reference has the prefilter, main.cpp:128-149).  No layout of the whole set: every chunk is filled in the
+                // compacted form; slot count by lanes x instructions per lane over the set, among those whose eight waves
+                // fit the LDS.
+                int64_t bc = 0;
+                for (int p : {96, 128}) {
+                    int64_t cst = 0;
+                    for (int j = 0; j < T; ++j) cst += (int64_t)(((int)tseq[(size_t)j].size() + p - 1) / p) * (9 * p / 2 + 60);
+                    if (P == 0 || cst < bc) { P = p; bc = cst; }
+                }
+                bestW = 8;
+                tiled_v0.assign((size_t)T, 0);
+                plan.filter_only = true;
             }
             if (P == 0) { why = T > 1024 ? "more than 1024 templates, too many cells for the tiled layout" : "template set too large for the tiled layout"; return false; }
             plan.waves = bestW;
@@ -569,7 +591,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     plan.end_off.assign((size_t)T, 0);
     for (int j = 0; j < T; ++j) {
         const int L = (int)tseq[(size_t)j].size();
-        plan.end_vlane[(size_t)j] = plan.vlane0[(size_t)j] + (L + P - 1) / P - 1;
+        plan.end_vlane[(size_t)j] = plan.filter_only ? -1 : plan.vlane0[(size_t)j] + (L + P - 1) / P - 1;   // (no static lanes)
         plan.end_off[(size_t)j] = (L - 1) * sc.del;
     }
 
@@ -842,7 +864,7 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
     hipLaunchKernelGGL(sd_fast_trace<QQ>, dim3(grid), dim3(64 * trace_waves_per_group(QQ)), 0, st, chunks, n_chunks, bases2, \
                        nmask, slot_of, tcodes, lane_consts, toff, tlen, sc, plan.P, B, argV, ckpt, \
                        ckbase, recs, rec_cnt, queue, order, plan.f16 ? 1 : 0, plan.bshift, plan.waves, klist, kpos, \
-                       nkept, plan.T, lane_t)
+                       nkept, plan.filter_only ? -plan.T : plan.T, lane_t)
     switch (plan.Qk) {
         case 1: SD_TRACE(1); break;
         case 2: SD_TRACE(2); break;

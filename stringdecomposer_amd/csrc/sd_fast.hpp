@@ -50,6 +50,9 @@ struct FastPlan {
     int Qk = 0;           // traceback: template cells per lane = ceil(Lmax/64)
     int waves = 1;        // waves per chunk: 1, or ceil(T/128) for the multi-wave wide layout (sd_fast_wn.hip)
     bool tiled = false;   // multi-wave layout with templates tiled over consecutive virtual lanes (sd_fast_wt.hip); wide is set too
+    bool filter_only = false;   // tiled, and the whole set does NOT fit eight waves: only with --ed_thr, every chunk in the
+                                // compacted form (its kept templates re-dealt, sd_tiled_place); a chunk whose kept templates
+                                // do not fit either raises the guard flag and the batch is repeated on the generic family
     int bshift = 7;       // B words: (B_i << bshift) | arg-max (wave << 7 | virtual lane)
     int rebase = FAST_REBASE;  // rows between two rebases of the stored cells (ScoreArgs::rebase_mask + 1; the narrow fills read it from Hx bit 11): 128 or 64
     int range_bound = 0;       // proven bound on |stored cell| between two rebases (fp16 formats need <= 2040)
@@ -88,7 +91,8 @@ static const int FAST_TILED_P_LIST[] = {96, 128, 160, 192, 224};   // slots per 
 // Builds the plan; returns false (with the reason) when the fast family cannot represent the
 // input exactly (then the generic family is used).
 bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max_rows,
-                     FastPlan& plan, std::string& why, bool allow_f16 = true, bool allow_tr2 = true);
+                     FastPlan& plan, std::string& why, bool allow_f16 = true, bool allow_tr2 = true,
+                     bool filter_only_ok = false);   // --ed_thr is on: a set beyond eight waves may take the filter-only form
 
 // --ed_thr prefilter on the device (sd_filter.hip): infix edit distances, kept set and ranks per
 // chunk -> per-chunk lane constants of the fast family (cendoff, crank: [chunk][64] packed {lo,hi}
@@ -105,7 +109,7 @@ void launch_edthr_filter(hipStream_t st, const ChunkDesc* chunks, int n_chunks, 
 // --ed_thr with more than 128 templates: the chunk order split into W classes by ceil(kept templates / 128)
 // --ed_thr on the tiled multi-wave layout: per chunk, the kept templates' lanes (sd_filter.hip: sd_tiled_place)
 void launch_tiled_place(hipStream_t st, int n_chunks, int T, int P, int W, const uint16_t* klist, int32_t* nkept,
-                        const int32_t* tlen, uint16_t* kpos, uint32_t* lane_t);
+                        const int32_t* tlen, uint16_t* kpos, uint32_t* lane_t, int* overflow_flag = nullptr);
 void launch_split_order(hipStream_t st, const int* order, int n, const int32_t* nkept, int* orders, int* counts,
                         int W);   // orders: [W][n] -- class w-1 = the chunks that need w waves, in the given order
 
@@ -187,6 +191,7 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
                        int32_t* rec_cnt, int* queue, const int* order, int n_cu,
                        const uint16_t* klist = nullptr, const uint16_t* kpos = nullptr, const int32_t* nkept = nullptr,
                        const uint32_t* tr2_tab = nullptr,
-                       const uint32_t* lane_t = nullptr);   // compacted tiled chunks: the lane table (kpos = first lanes then)   // device copy of FastPlan::tr2_tab: the second form where it applies
+                       const uint32_t* lane_t = nullptr);   // compacted tiled chunks: the lane table (kpos = first lanes then)
+                                                            // (FastPlan::filter_only: every chunk is one, or skipped)   // device copy of FastPlan::tr2_tab: the second form where it applies
 
 }  // namespace sd

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64) void sd_split_order(const int* __restrict__ ord
     for (int base = 0; base < n; base += 64) {
         const int x = base + lane;
         const int c = x < n ? order[x] : -1;
-        const int cls = c >= 0 ? min(W, max(1, (nkept[c] + 127) / 128)) - 1 : -1;
+        const int cls = (c >= 0 && nkept[c] >= 0) ? min(W, max(1, (nkept[c] + 127) / 128)) - 1 : -1;   // (-1: a skipped chunk)
         for (int w = 0; w < W; ++w) {
             const unsigned long long m = __ballot(cls == w);
             if (cls == w) orders[(size_t)w * n + cnt[w] + __popcll(m & ((1ull << lane) - 1ull))] = c;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(64) void sd_split_order(const int* __restrict__ ord
 // the ranked kernel on the plan's layout).
 __global__ void sd_tiled_place(int n_chunks, int T, int P, int W, const uint16_t* __restrict__ klist,
                                int32_t* __restrict__ nkept, const int32_t* __restrict__ tlen,
-                               uint16_t* __restrict__ kpos, uint32_t* __restrict__ lane_t) {
+                               uint16_t* __restrict__ kpos, uint32_t* __restrict__ lane_t, int* __restrict__ overflow_flag) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chunks) return;
     const int nk = nkept[c];
@@ -303,7 +303,13 @@ __global__ void sd_tiled_place(int n_chunks, int T, int P, int W, const uint16_t
         const int j = kl[r];
         const int V = (tlen[j] + P - 1) / P;
         if (V > 64 - (cur & 63)) cur = (cur + 63) & ~63;
-        if (cur + V > W * 128) { cur = W * 128 + 1; break; }   // (padding in another order than the plan's: all W waves)
+        if (cur + V > W * 128) {   // (padding in another order than the plan's: all W waves, on the plan's layout)
+            cur = W * 128 + 1;
+            // FastPlan::filter_only -- there is no layout of the whole set: the chunk is skipped (count -1) and the flag
+            // makes the host repeat the batch on the generic family
+            if (overflow_flag) { cur = -1; atomicOr(overflow_flag, 4); }
+            break;
+        }
         kpos[(size_t)c * (size_t)T + (size_t)j] = (uint16_t)cur;
         for (int u = 0; u < V; ++u) lt[cur + u] = (uint32_t)j | ((uint32_t)u << 16);
         cur += V;
@@ -312,11 +318,11 @@ __global__ void sd_tiled_place(int n_chunks, int T, int P, int W, const uint16_t
 }
 
 void launch_tiled_place(hipStream_t st, int n_chunks, int T, int P, int W, const uint16_t* klist, int32_t* nkept,
-                        const int32_t* tlen, uint16_t* kpos, uint32_t* lane_t) {
+                        const int32_t* tlen, uint16_t* kpos, uint32_t* lane_t, int* overflow_flag) {
     const size_t words = (size_t)n_chunks * (size_t)W * 128;
     hipLaunchKernelGGL(sd_fill_u32, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, lane_t, words, 0xffffffffu);
     hipLaunchKernelGGL(sd_tiled_place, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), 0, st, n_chunks, T, P, W, klist, nkept,
-                       tlen, kpos, lane_t);
+                       tlen, kpos, lane_t, overflow_flag);
 }
 
 void launch_split_order(hipStream_t st, const int* order, int n, const int32_t* nkept, int* orders, int* counts, int W) {

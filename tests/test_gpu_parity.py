@@ -662,6 +662,48 @@ def test_tiled_multiwave_layout_vs_oracle(oracle, nm, lo, hi, waves):
             assert full == exp, (nm, sc, part, ed, "ranked form")
 
 
+@pytest.mark.gpu
+def test_ed_thr_on_a_set_beyond_eight_waves_filter_only_form(oracle):
+    """1 200 templates (600 monomers of 100-250 bp) do not fit eight waves: without --ed_thr the generic family.  With it a
+    chunk's KEPT templates mostly do (what the reference's prefilter is for, main.cpp:128-149): every chunk is filled in
+    the compacted tiled form (FastPlan::filter_only, sd_tiled_place); a chunk whose kept templates do not fit either
+    (--ed_thr 250 keeps everything) raises the guard flag and the batch is repeated on the generic family."""
+    st = synth.Stream(606, 6)
+    nm = 600
+    ms = _random_monomers(st, nm, 100, 250)
+    mn = ["m%d" % j for j in range(nm)]
+    assert lib.plan_info(ms)["family"] == "generic"
+    pi = lib.plan_info(ms, ed_thr=25)
+    assert (pi["family"], pi["cells"], pi["waves"]) == ("fast", "f16/bf8-codes tiled x waves", 8), pi
+    reads = []
+    for r in range(4):
+        parts = []
+        while sum(len(x) for x in parts) < 1500 + 700 * r:
+            j = int(st.below(1, nm)[0])
+            codes = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), np.frombuffer(ms[j], dtype=np.uint8))
+            x = synth._to_ascii(synth.mutate(codes, st, 0.05, 0.03, 0.03))
+            parts.append(synth.revcomp_bytes(x) if st.below(1, 2)[0] else x)
+        b = bytearray(b"".join(parts))
+        b[len(b) // 2] = ord("N")
+        reads.append(bytes(b))
+    reads.append(reads[0][:50])
+    rn = ["r%d" % i for i in range(len(reads))]
+    thr = min(32, os.cpu_count() or 1)
+    for part, ov, ed in ((5000, 500, 25), (600, 100, 40), (5000, 500, 0)):
+        exp = oracle.decompose(rn, reads, mn, ms, threads=thr, part=part, overlap=ov, ed_thr=ed)
+        t0 = lib.guard_trips()
+        got = lib.decompose(rn, reads, mn, ms, part_size=part, overlap=ov, ed_thr=ed)
+        assert got == exp, (part, ed)
+        assert lib.guard_trips() == t0, (part, ed)        # every chunk's kept templates fit: no repeat
+    e = lib.Engine(ms, ed_thr=25)
+    assert e.info()["family"] == "fast"
+    e.close()
+    exp = oracle.decompose(rn, reads, mn, ms, threads=thr, ed_thr=250)
+    t0 = lib.guard_trips()
+    assert lib.decompose(rn, reads, mn, ms, ed_thr=250) == exp
+    assert lib.guard_trips() > t0                          # kept sets beyond eight waves: repeated on the generic family
+
+
 def _late_base_monomers():
     """Monomers whose lanes meet a base late or never: long homopolymer / two-letter prefixes, a base that is
     missing altogether, an N in the middle of a lane -- the cases that decide FastPlan::floor_slots."""

@@ -608,7 +608,11 @@ def test_plan_layouts_of_the_baseline_sets_and_fuzz_fixtures():
     t3 = lib.plan_info([rnd(1000)] * 5)                                        # ten templates of eleven lanes: one wave of 96 slots
     assert (t3["cells"], t3["cells_per_lane"], t3["waves"]) == ("f16/bf8-codes tiled x waves", 96, 1), t3
     assert lib.plan_info([rnd(1000)] * 5, scoring=(-1, -2, -1, 1))["family"] == "generic"   # beyond the fp16 range: no tiled form
-    assert lib.plan_info([rnd(100 + j % 150) for j in range(600)])["family"] == "generic"   # more lanes than eight waves hold
+    huge = [rnd(100 + j % 150) for j in range(600)]
+    assert lib.plan_info(huge)["family"] == "generic"                           # more lanes than eight waves hold ...
+    h2 = lib.plan_info(huge, ed_thr=30)                                         # ... but with --ed_thr a chunk's kept templates mostly fit:
+    assert (h2["family"], h2["cells"], h2["waves"]) == ("fast", "f16/bf8-codes tiled x waves", 8), h2   # the filter-only form
+    assert lib.plan_info(huge, ed_thr=30, flags=lib.FLAG_NO_EDTHR_COMPACT)["family"] == "generic"
     fz = os.path.join(GOLDEN, "fuzz")
     # the scoring that overran fp16 before the range bound charged B's growth (seed 906)
     mn, ms, _ = lib.fasta_load(os.path.join(fz, "fuzz_fail_906_791", "m.fa"))
