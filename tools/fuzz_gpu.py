@@ -43,7 +43,8 @@ for case in range(cases):
              (64, 165, 178), (4, 300, 500), (2, 1, 30), (10, 60, 64), (90, 100, 180), (230, 140, 176),
              (16, 150, 190), (20, 160, 180), (14, 120, 175),             # these three: P = 42..64 (sd_fast_fl_long.hip)
              (3, 520, 1000), (2, 1000, 2000), (1, 600, 2040),            # round 3: monomers of up to 2048 bp on the fast family
-             (30, 230, 420), (10, 600, 1150), (70, 90, 330), (40, 1, 500)][rnd(22)]   # round 4: the tiled multi-wave layout (sd_fast_wt.hip)
+             (30, 230, 420), (10, 600, 1150), (70, 90, 330), (40, 1, 500),           # round 4: the tiled multi-wave layout (sd_fast_wt.hip)
+             (560, 60, 120), (300, 150, 400)][rnd(24)]   # beyond eight waves: generic family, or with --ed_thr the filter-only form
     nm = max(1, shape[0] - rnd(2))
     ms = monomers(nm, shape[1], shape[2], 0.15 if rnd(3) == 0 else 0.0)
     mn = ["m%d" % j for j in range(nm)]
@@ -86,6 +87,8 @@ for case in range(cases):
         reads.append(bytes(b))
     rn = ["r%d" % i for i in range(len(reads))]
     ed = -1 if rnd(3) else rnd(80)
+    if shape[0] >= 300 and rnd(2):   # the big sets mostly with the filter (their fast form exists only then); sometimes one that keeps everything
+        ed = rnd(60) if rnd(6) else 400
     try:
         got = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed,
                             threads=1 + rnd(6), max_batch_rows=[0, 0, 200, 1500][rnd(4)])
