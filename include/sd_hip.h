@@ -55,7 +55,8 @@ typedef struct sd_params {
 } sd_params;
 #define SD_FLAG_NO_F16 1           /* no fp16 cell format: integer cells (or the generic family)                   */
 #define SD_FLAG_FULL_FLOOR 2       /* fills that take the start-term maximum in every slot (A/B of the FL variants) */
-#define SD_FLAG_NO_EDTHR_COMPACT 4 /* --ed_thr with > 128 templates: every chunk on the W-wave ranked kernel        */
+#define SD_FLAG_NO_EDTHR_COMPACT 4 /* --ed_thr with > 128 templates: every chunk on the W-wave ranked kernel (a set
+                                    * beyond eight waves, whose only fast form is the compacted one: generic family)   */
 #define SD_FLAG_FILTER_GENERAL 8   /* --ed_thr: the general prefilter kernel instead of the uniform one             */
 #define SD_FLAG_NO_STREAM_IDENT 16 /* sd_run_files: identities from the read text in the post-processing (round 2)  */
 #define SD_FLAG_TRACE_V1 64        /* the one-block int32 traceback (sd_fast_trace) where the packed two-block form would run */
