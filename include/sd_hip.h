@@ -80,7 +80,13 @@ int sd_device_count(void);           /* number of visible HIP devices (0 if none
 void sd_free(void* p);               /* frees anything this library returned                     */
 /* Engines return their large device buffers to a process-wide cache instead of the driver (hipMalloc /
  * hipFree of the multi-GB workspaces can take longer than the kernels); this hands the cached buffers
- * back.  Environment SD_DEVICE_POOL=0 disables the cache. */
+ * back.  Environment SD_DEVICE_POOL=0 disables the cache.
+ * The file and chunk-range entry points (sd_run_files*, sd_decompose_files*, sd_decompose_chunk_range) also keep the
+ * device pipeline of a finished job -- engines, streams, pinned staging and their device buffers, i.e. GIGABYTES of
+ * HBM that other users of the GPU in this process or on this device do not see as free -- for the next job with the
+ * same parameters and monomer set (at most two pipelines, none above SD_PIPE_CACHE_GB [96] GB, none whose engines had
+ * to leave their layout; SD_PIPE_CACHE_OFF=1 disables it).  sd_release_cache() destroys them too; nothing of either
+ * cache is torn down at process exit. */
 void sd_release_cache(void);
 
 /* ---- one-shot entry points (replace main.py:194) ------------------------------------------- */
@@ -143,6 +149,45 @@ int sd_convert_raw_tsv_range(const char* raw_tsv, const char* reads_fa, const ch
                              const char* final_tsv_out, const char* alt_tsv_out, int32_t min_identity,
                              int32_t second_best, const double* lr_coef, int32_t device, int32_t threads,
                              int32_t rank, int32_t world, char* errbuf, size_t errlen);
+
+/* ---- on-disk binary record stream ---------------------------------------
+ * The reference's only hand-over between its DP stage and everything downstream is text: <out>_raw.tsv, written by
+ * SaveBatch (main.cpp:272-285) and re-read line by line by convert_tsv (main.py:168-184; column spec README.md:77-83).
+ * The record stream holds the same rows -- per read, in read order -- as 16-byte sd_rec records, so a consumer
+ * skips the text round trip; the raw TSV is a pure function of it (sd_records_to_raw_tsv gives SaveBatch's bytes).
+ * Layout: csrc/sd_records.hpp and stringdecomposer_amd/formats.py (read_records / write_records, pure Python).
+ * Template names are column 2 of the raw TSV: the monomers in file order, then their names + "'" (main.cpp:364-371). */
+typedef struct sd_records {
+    int32_t ins, del, mismatch, match, part_size, overlap, ed_thr;   /* the job's argv (main.cpp:374-402)           */
+    int32_t n_templates;
+    char** tmpl_names;
+    int32_t n_reads;
+    char** read_names;
+    int64_t* read_lens;    /* -1 where the writer did not know it                                              */
+    int64_t* row_off;      /* n_reads + 1: read r owns rows[row_off[r] .. row_off[r+1]), read-global coordinates */
+    int64_t n_rows;
+    sd_rec* rows;
+} sd_records;
+/* Host only.  rows / row_off as sd_stream_collect returns them (or any rows in SaveBatch order). */
+int sd_write_records(const char* path, const sd_params* p, const char* const* tmpl_names, int32_t n_templates,
+                     const char* const* read_names, const int64_t* read_lens, int32_t n_reads, const sd_rec* rows,
+                     const int64_t* row_off, char* errbuf, size_t errlen);
+/* Host only.  Checks the file (magic, bounds, template indices, the trailer's totals: a stream whose writer did not
+ * finish is SD_ERR_FORMAT); *out is filled with malloc'ed arrays, released by sd_records_free. */
+int sd_read_records(const char* path, sd_records* out, char* errbuf, size_t errlen);
+void sd_records_free(sd_records* r);
+/* Host only: the raw TSV of a record stream, byte for byte what `dp` prints for the same job. */
+int sd_records_to_raw_tsv(const char* records_path, const char* raw_tsv_out, int32_t threads, char* errbuf,
+                          size_t errlen);
+/* sd_decompose_files with the record stream as its output (no text is made anywhere). */
+int sd_decompose_files_records(const char* reads_fa, const char* monomers_fa, const sd_params* p,
+                               const char* records_out, char* errbuf, size_t errlen);
+/* sd_run_files that also writes the record stream, read by read as the batches complete (records_out == NULL:
+ * exactly sd_run_files).  Single process only. */
+int sd_run_files_records(const char* reads_fa, const char* monomers_fa, const sd_params* p, const char* raw_tsv_out,
+                         const char* final_tsv_out, const char* alt_tsv_out, const char* records_out,
+                         int32_t min_identity, int32_t second_best, const double* lr_coef, char* errbuf,
+                         size_t errlen);
 
 /* ---- chunk-range form: one job sharded over several GPUs, one process per GPU ---------------
  * The chunks of a read set (main.cpp:70-81, all reads, input order) form one global table; a chunk's

@@ -30,6 +30,7 @@
 #include "sd_fast.hpp"
 #include "sd_host.hpp"
 #include "sd_kernels.hpp"
+#include "sd_records.hpp"
 
 namespace {
 
@@ -317,6 +318,7 @@ struct sd_engine {
     hipStream_t copy_stream = nullptr;   // pipeline: H2D of the batch / D2H of its records (not owned)
     bool lds_gate = false;               // pipeline mode 2: the fill asks for LDS that admits two workgroups per CU only
     bool ran = false;
+    bool replanned = false;              // a guard trip made this engine give up the layout it was created with
     std::vector<hipEvent_t> ev_fill, ev_trace;  // pairs
     hipEvent_t ev_run0 = nullptr, ev_run1 = nullptr, ev_cmp0 = nullptr, ev_cmp1 = nullptr;
     int fill_launches = 0;
@@ -1134,6 +1136,7 @@ static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errle
             // layout plan's bound did not hold for this input.  Nothing of the run is used; the batch (still packed on
             // the device) is repeated with integer cells, which this engine keeps from now on.
             ++g_guard_trips;
+            e->replanned = true;
             std::string err2;
             int rc2 = engine_pick_family(e, false, err2);
             if (rc2) { set_err(errbuf, errlen, "fp16 cell range exceeded, and no integer-cell layout: " + err2); return rc2; }
@@ -1408,6 +1411,11 @@ struct Pipeline {
         for (sd_engine* e : eng) if (e) h += e->workspace_bytes();
         return h;
     }
+    // an engine repeated a batch under another layout (fp16 guard trip, filter-only overflow) and kept it
+    bool degraded() const {
+        for (sd_engine* e : eng) if (e && e->replanned) return true;
+        return false;
+    }
     int inflight() const { return (int)(pushed - popped); }
     // SD_PIPE_MODE: 0 = every kernel of every batch in order on one stream (clean per-kernel event spans);
     // 1 = fills in order on one stream, traceback + compaction on a second, lower-priority one (the traceback
@@ -1567,37 +1575,60 @@ void plan_batches(const std::vector<CRef>& table, size_t c_lo, size_t c_hi, int6
 // Pipelines of finished jobs (sd_run_files, the chunk-range calls), kept for the next job with the same parameters and monomer set: creating
 // the engines (layout plan, tables, identity masks, streams, events, pinned staging) is 25-40 ms per call, a quarter of
 // a C4 --second-best job.  A process that decomposes many read sets against one monomer set (a service behind the
-// C-ABI, bench.py's steps) pays it once; sd_release_cache() drops them.  At most two are kept.
+// C-ABI, bench.py's steps) pays it once; sd_release_cache() drops them.  At most two are kept, none that holds more
+// than SD_PIPE_CACHE_GB (default 96) GB of device memory, and none whose engines left the layout they were created
+// with (a tripped fp16 guard, an overflowing filter-only batch: the next job should start from the plan again).
+// The entries are never destroyed at process exit (as g_pool / g_pinpool: the HIP runtime may be gone by then);
+// sd_release_cache() is the only place that tears them down.
+extern "C++" {
 namespace {
 struct PipeCacheEntry { std::string key; std::unique_ptr<Pipeline> pipe; };
-std::mutex g_pc_m;
-std::vector<PipeCacheEntry> g_pc;
+struct PipeCache { std::mutex m; std::vector<PipeCacheEntry> v; };
+PipeCache& pipe_cache() { static PipeCache* c = new PipeCache; return *c; }   // leaked on purpose
+// the cache key, field by field (the raw bytes of an sd_params would carry its padding and the host-thread count)
+std::string pipe_cache_key(const sd_params& pe, char kind, const std::vector<const char*>& mseq, const std::vector<int32_t>& mlen) {
+    std::string k;
+    for (int32_t v : {pe.ins, pe.del, pe.mismatch, pe.match, pe.part_size, pe.overlap, pe.ed_thr, pe.device, pe.kernel,
+                      pe.max_batch_rows, pe.reserved[0], pe.reserved[1], pe.reserved[2], pe.reserved[3], pe.reserved[4]}) {
+        k += std::to_string(v);
+        k.push_back(',');
+    }
+    k.push_back(kind);
+    for (size_t m = 0; m < mseq.size(); ++m) { k.append(mseq[m], (size_t)mlen[m]); k.push_back('\n'); }
+    return k;
+}
 std::unique_ptr<Pipeline> pipe_cache_take(const std::string& key) {
-    std::lock_guard<std::mutex> g(g_pc_m);
-    for (size_t i = 0; i < g_pc.size(); ++i)
-        if (g_pc[i].key == key) {
-            std::unique_ptr<Pipeline> q = std::move(g_pc[i].pipe);
-            g_pc.erase(g_pc.begin() + (long)i);
+    PipeCache& c = pipe_cache();
+    std::lock_guard<std::mutex> g(c.m);
+    for (size_t i = 0; i < c.v.size(); ++i)
+        if (c.v[i].key == key) {
+            std::unique_ptr<Pipeline> q = std::move(c.v[i].pipe);
+            c.v.erase(c.v.begin() + (long)i);
             return q;
         }
     return nullptr;
 }
 void pipe_cache_give(const std::string& key, std::unique_ptr<Pipeline> q) {
+    static const size_t cap = [] { const char* e = getenv("SD_PIPE_CACHE_GB"); return (size_t)(e ? std::max(0, atoi(e)) : 96) << 30; }();
+    if (!q || q->degraded() || q->held_bytes() > cap) return;   // (destroyed here, outside the lock)
     std::vector<PipeCacheEntry> drop;   // destroyed outside the lock
     {
-        std::lock_guard<std::mutex> g(g_pc_m);
-        g_pc.push_back(PipeCacheEntry{key, std::move(q)});
-        while (g_pc.size() > 2) { drop.push_back(std::move(g_pc.front())); g_pc.erase(g_pc.begin()); }
+        PipeCache& c = pipe_cache();
+        std::lock_guard<std::mutex> g(c.m);
+        c.v.push_back(PipeCacheEntry{key, std::move(q)});
+        while (c.v.size() > 2) { drop.push_back(std::move(c.v.front())); c.v.erase(c.v.begin()); }
     }
 }
 void pipe_cache_clear() {
     std::vector<PipeCacheEntry> drop;
     {
-        std::lock_guard<std::mutex> g(g_pc_m);
-        drop.swap(g_pc);
+        PipeCache& c = pipe_cache();
+        std::lock_guard<std::mutex> g(c.m);
+        drop.swap(c.v);
     }
 }
 }  // namespace
+}  // extern "C++"
 
 // Runs the chunks [c_lo, c_hi) of `table` through the device in batches of consecutive chunks sized to
 // the free HBM, so a single 200-Mb sequence and a million reads take the same path; the records of
@@ -1613,10 +1644,7 @@ static int run_chunk_batches(const std::vector<ReadView>& reads, const std::vect
     {
         sd_params pe = *p;
         apply_env_overrides(pe);
-        pe.threads = 0;
-        pkey.assign(reinterpret_cast<const char*>(&pe), sizeof pe);
-        pkey.push_back('C');
-        for (size_t m = 0; m < ts.mseq.size(); ++m) { pkey.append(ts.mseq[m], (size_t)ts.mlen[m]); pkey.push_back('\n'); }
+        pkey = pipe_cache_key(pe, 'C', ts.mseq, ts.mlen);
     }
     std::unique_ptr<Pipeline> pipe_h = getenv("SD_PIPE_CACHE_OFF") ? nullptr : pipe_cache_take(pkey);
     int rc = SD_OK;
@@ -1666,6 +1694,7 @@ struct ReadAssembler {
     std::vector<sd_rec> cur;      // records of the read being assembled
     size_t next_read = 0;         // first read not yet written
     int32_t chunks_seen = 0;
+    sd::RecordsWriter* rec_out = nullptr;   // set: completed reads go to the binary record stream and no text is made
     ReadAssembler(const std::vector<ReadView>& r, const std::vector<CRef>& t, const std::vector<int32_t>& n,
                   const std::vector<std::string>& tn, int th, std::string& out)
         : reads(r), table(t), nch(n), tnames(tn), threads(th), tsv(out) {}
@@ -1690,6 +1719,13 @@ struct ReadAssembler {
         }
         sd::parallel_for((int64_t)done_ids.size(), threads, 4,
                          [&](int64_t q) { sd::seam_merge(done_rows[(size_t)q]); });
+        if (rec_out) {
+            for (size_t q = 0; q < done_ids.size(); ++q) {
+                const ReadView& rd = reads[done_ids[q]];
+                rec_out->add_read(rd.name, rd.name_len, rd.len, done_rows[q].data(), (int64_t)done_rows[q].size());
+            }
+            return;
+        }
         // text in slices of 32 k rows, so that one huge read (a whole chromosome) is formatted by all
         // host threads as well; a slice only needs the end of the row before it (SaveBatch's prev_end)
         struct Slice { size_t q, r0, r1; };
@@ -1715,7 +1751,7 @@ struct ReadAssembler {
 }  // namespace
 
 static int decompose_impl(const std::vector<ReadView>& reads, const std::vector<sd::Seq>& monos,
-                          const sd_params* p, std::string& tsv, std::string& err) {
+                          const sd_params* p, std::string& tsv, std::string& err, const char* records_out = nullptr) {
     if (monos.empty()) { err = "no monomers"; return SD_ERR_PARAM; }
     for (const ReadView& r : reads)
         if (r.len <= 0) { err = "ERROR: Sequence " + std::string(r.name, r.name_len) + " is empty"; return SD_ERR_EMPTY; }
@@ -1724,10 +1760,18 @@ static int decompose_impl(const std::vector<ReadView>& reads, const std::vector<
     std::vector<int32_t> nch;
     build_chunk_table(reads, p, table, nch);
     ReadAssembler as(reads, table, nch, ts.tnames, p->threads, tsv);
-    return run_chunk_batches(reads, table, 0, table.size(), ts, p, err,
-                             [&](size_t c0, size_t c1, const sd_rec* recs, const int64_t* roff) {
-                                 as.add(c0, c1, recs, roff);
-                             });
+    sd::RecordsWriter rw;
+    if (records_out) {
+        const int orc = rw.open(records_out, *p, ts.tnames, err);
+        if (orc) return orc;
+        as.rec_out = &rw;
+    }
+    int rc = run_chunk_batches(reads, table, 0, table.size(), ts, p, err,
+                               [&](size_t c0, size_t c1, const sd_rec* recs, const int64_t* roff) {
+                                   as.add(c0, c1, recs, roff);
+                               });
+    if (records_out && rc == SD_OK) rc = rw.close(err, records_out);
+    return rc;
 }
 
 int sd_decompose(const char* const* read_names, const char* const* read_seqs,
@@ -1782,12 +1826,13 @@ int sd_decompose(const char* const* read_names, const char* const* read_seqs,
     return SD_OK;
 }
 
-int sd_decompose_files(const char* reads_fa, const char* monomers_fa, const sd_params* p,
-                       const char* raw_tsv_out, char* errbuf, size_t errlen) {
+// raw_tsv_out: the text `dp` prints; records_out: the same rows as the binary record stream (sd_records.hpp), no text made
+static int decompose_files_impl(const char* reads_fa, const char* monomers_fa, const sd_params* p,
+                                const char* raw_tsv_out, const char* records_out, char* errbuf, size_t errlen) {
     std::string err;
     int rc = validate_params(p, err);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
-    if (!reads_fa || !monomers_fa || !raw_tsv_out) return SD_ERR_PARAM;
+    if (!reads_fa || !monomers_fa || (!raw_tsv_out && !records_out)) return SD_ERR_PARAM;
     sd::FastaFile rf, mf;
     rc = rf.open(reads_fa, p->threads, err);                                  // main.cpp:394
     if (rc == SD_OK) rc = rf.validate(0, rf.recs.size(), p->threads, err);
@@ -1800,8 +1845,9 @@ int sd_decompose_files(const char* reads_fa, const char* monomers_fa, const sd_p
     std::vector<ReadView> views;
     views.reserve(rf.recs.size());
     for (const auto& r : rf.recs) views.push_back(ReadView{r.name, r.name_len, r.seq, r.len});
-    rc = decompose_impl(views, monos, p, out, err);
+    rc = decompose_impl(views, monos, p, out, err, records_out);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
+    if (!raw_tsv_out) return SD_OK;
     FILE* fp = std::fopen(raw_tsv_out, "wb");
     if (!fp) { set_err(errbuf, errlen, std::string("cannot write ") + raw_tsv_out); return SD_ERR_IO; }
     const size_t w = std::fwrite(out.data(), 1, out.size(), fp);
@@ -1809,6 +1855,105 @@ int sd_decompose_files(const char* reads_fa, const char* monomers_fa, const sd_p
         set_err(errbuf, errlen, std::string("short write to ") + raw_tsv_out);
         return SD_ERR_IO;
     }
+    return SD_OK;
+}
+
+int sd_decompose_files(const char* reads_fa, const char* monomers_fa, const sd_params* p,
+                       const char* raw_tsv_out, char* errbuf, size_t errlen) {
+    if (!raw_tsv_out) return SD_ERR_PARAM;
+    return decompose_files_impl(reads_fa, monomers_fa, p, raw_tsv_out, nullptr, errbuf, errlen);
+}
+
+int sd_decompose_files_records(const char* reads_fa, const char* monomers_fa, const sd_params* p,
+                               const char* records_out, char* errbuf, size_t errlen) {
+    if (!records_out) return SD_ERR_PARAM;
+    return decompose_files_impl(reads_fa, monomers_fa, p, nullptr, records_out, errbuf, errlen);
+}
+
+// ---- the binary record stream as a format of its own (host only) ---------------------------------------------
+int sd_write_records(const char* path, const sd_params* p, const char* const* tmpl_names, int32_t n_templates,
+                     const char* const* read_names, const int64_t* read_lens, int32_t n_reads, const sd_rec* rows,
+                     const int64_t* row_off, char* errbuf, size_t errlen) {
+    if (!path || !p || n_templates < 0 || n_reads < 0 || (n_templates && !tmpl_names) || (n_reads && (!read_names || !row_off)))
+        return SD_ERR_PARAM;
+    std::vector<std::string> tn;
+    for (int32_t t = 0; t < n_templates; ++t) tn.emplace_back(tmpl_names[t]);
+    for (int32_t r = 0; r < n_reads; ++r) {
+        if (row_off[r + 1] < row_off[r] || (row_off[r + 1] > row_off[r] && !rows)) { set_err(errbuf, errlen, "row offsets must not decrease"); return SD_ERR_PARAM; }
+        for (int64_t x = row_off[r]; x < row_off[r + 1]; ++x)
+            if (rows[x].tmpl < 0 || rows[x].tmpl >= n_templates) { set_err(errbuf, errlen, "record with a template index outside the template table"); return SD_ERR_PARAM; }
+    }
+    std::string err;
+    sd::RecordsWriter rw;
+    int rc = rw.open(path, *p, tn, err);
+    if (rc == SD_OK) {
+        for (int32_t r = 0; r < n_reads; ++r)
+            rw.add_read(read_names[r], std::strlen(read_names[r]), read_lens ? read_lens[r] : -1, rows + row_off[r], row_off[r + 1] - row_off[r]);
+        rc = rw.close(err, path);
+    }
+    if (rc) set_err(errbuf, errlen, err);
+    return rc;
+}
+
+void sd_records_free(sd_records* r) {
+    if (!r) return;
+    if (r->tmpl_names) for (int32_t t = 0; t < r->n_templates; ++t) std::free(r->tmpl_names[t]);
+    if (r->read_names) for (int32_t i = 0; i < r->n_reads; ++i) std::free(r->read_names[i]);
+    std::free(r->tmpl_names); std::free(r->read_names); std::free(r->read_lens); std::free(r->row_off); std::free(r->rows);
+    std::memset(r, 0, sizeof *r);
+}
+
+int sd_read_records(const char* path, sd_records* out, char* errbuf, size_t errlen) {
+    if (!path || !out) return SD_ERR_PARAM;
+    std::memset(out, 0, sizeof *out);
+    sd::RecordsFile f;
+    std::string err;
+    const int rc = f.load(path, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    auto dup = [](const std::string& x) { char* c = static_cast<char*>(std::malloc(x.size() + 1)); if (c) { std::memcpy(c, x.data(), x.size()); c[x.size()] = 0; } return c; };
+    out->ins = f.score[0]; out->del = f.score[1]; out->mismatch = f.score[2]; out->match = f.score[3];
+    out->part_size = f.part_size; out->overlap = f.overlap; out->ed_thr = f.ed_thr;
+    out->n_templates = (int32_t)f.tnames.size();
+    out->n_reads = (int32_t)f.rnames.size();
+    out->n_rows = (int64_t)f.rows.size();
+    out->tmpl_names = static_cast<char**>(std::calloc(std::max<size_t>(f.tnames.size(), 1), sizeof(char*)));
+    out->read_names = static_cast<char**>(std::calloc(std::max<size_t>(f.rnames.size(), 1), sizeof(char*)));
+    out->read_lens = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * std::max<size_t>(f.rnames.size(), 1)));
+    out->row_off = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * (f.rnames.size() + 1)));
+    out->rows = static_cast<sd_rec*>(std::malloc(sizeof(sd_rec) * std::max<size_t>(f.rows.size(), 1)));
+    bool ok = out->tmpl_names && out->read_names && out->read_lens && out->row_off && out->rows;
+    for (size_t t = 0; ok && t < f.tnames.size(); ++t) ok = (out->tmpl_names[t] = dup(f.tnames[t])) != nullptr;
+    for (size_t r = 0; ok && r < f.rnames.size(); ++r) ok = (out->read_names[r] = dup(f.rnames[r])) != nullptr;
+    if (!ok) { sd_records_free(out); set_err(errbuf, errlen, "out of host memory"); return SD_ERR_INTERNAL; }
+    if (!f.rnames.empty()) std::memcpy(out->read_lens, f.read_lens.data(), sizeof(int64_t) * f.rnames.size());
+    std::memcpy(out->row_off, f.row_off.data(), sizeof(int64_t) * f.row_off.size());
+    if (!f.rows.empty()) std::memcpy(out->rows, f.rows.data(), sizeof(sd_rec) * f.rows.size());
+    return SD_OK;
+}
+
+// record stream -> the raw TSV SaveBatch prints for the same rows (main.cpp:272-285); slices of 32 k rows on all threads
+int sd_records_to_raw_tsv(const char* records_path, const char* raw_tsv_out, int32_t threads, char* errbuf, size_t errlen) {
+    if (!records_path || !raw_tsv_out) return SD_ERR_PARAM;
+    sd::RecordsFile f;
+    std::string err;
+    int rc = f.load(records_path, err);
+    if (rc) { set_err(errbuf, errlen, err); return rc; }
+    struct Slice { size_t r; int64_t a, b; };
+    std::vector<Slice> slices;
+    for (size_t r = 0; r < f.rnames.size(); ++r)
+        for (int64_t a = f.row_off[r]; a < f.row_off[r + 1]; a += 32768)
+            slices.push_back(Slice{r, a, std::min<int64_t>(f.row_off[r + 1], a + 32768)});
+    std::vector<std::string> parts(slices.size());
+    sd::parallel_for((int64_t)slices.size(), std::max(1, (int)threads), 1, [&](int64_t x) {
+        const Slice& sl = slices[(size_t)x];
+        sd::format_rows(parts[(size_t)x], f.rnames[sl.r].data(), f.rnames[sl.r].size(), f.tnames, f.rows.data() + sl.a,
+                        (size_t)(sl.b - sl.a), sl.a > f.row_off[sl.r] ? f.rows[(size_t)sl.a - 1].end : 0);
+    });
+    const int fd = ::open(raw_tsv_out, O_RDWR | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) { set_err(errbuf, errlen, std::string("cannot write ") + raw_tsv_out); return SD_ERR_IO; }
+    int64_t off = 0;
+    const bool ok = sd::write_parts(fd, off, parts, std::max(1, (int)threads));
+    if (::close(fd) != 0 || !ok) { set_err(errbuf, errlen, std::string("short write to ") + raw_tsv_out); return SD_ERR_IO; }
     return SD_OK;
 }
 
@@ -2456,13 +2601,14 @@ static double g_last_run[24] = {0};
 static int run_files_impl(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank, int32_t world,
                           const char* raw_tsv_out, const char* final_tsv_out, const char* alt_tsv_out,
                           int32_t min_identity, int32_t second_best, const double* lr_coef, int64_t* info,
-                          char* errbuf, size_t errlen) {
+                          char* errbuf, size_t errlen, const char* records_out = nullptr) {
     std::string err;
     int rc = validate_params(p, err);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
     if (!reads_fa || !monomers_fa || !raw_tsv_out || !final_tsv_out || !alt_tsv_out || !lr_coef || world < 1 || rank < 0 ||
         rank >= world)
         return SD_ERR_PARAM;
+    if (records_out && world != 1) { set_err(errbuf, errlen, "the record stream is written by a single process"); return SD_ERR_PARAM; }
     const bool timing = getenv("SD_TIMING") != nullptr;
     const double t_begin = now_s();
     double t_prev = t_begin;
@@ -2551,6 +2697,11 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         set_err(errbuf, errlen, std::string("cannot write ") + raw_tsv_out);
         return SD_ERR_IO;
     }
+    sd::RecordsWriter rec_w;   // the rows once more as the binary record stream (sd_records.hpp), written as reads complete
+    if (records_out) {
+        rc = rec_w.open(records_out, *p, ts.tnames, err);
+        if (rc) { close_all(); set_err(errbuf, errlen, err); return rc; }
+    }
     RowJob job;
     job.n_reads = (int32_t)reads.size();
     job.threads = p->threads;
@@ -2571,10 +2722,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         sd_params pe = *p;
         apply_env_overrides(pe);
         stream_ident = !(pe.reserved[1] & SD_FLAG_NO_STREAM_IDENT);
-        pe.threads = 0;   // (host threads do not shape an engine)
-        pkey.assign(reinterpret_cast<const char*>(&pe), sizeof pe);
-        pkey.push_back(second_best ? '2' : '1');
-        for (const sd::Seq& m : monos) { pkey.append(m.seq); pkey.push_back('\n'); }
+        pkey = pipe_cache_key(pe, second_best ? '2' : '1', ts.mseq, ts.mlen);   // (host threads do not shape an engine)
     }
     std::unique_ptr<Pipeline> pipe_h = getenv("SD_PIPE_CACHE_OFF") ? nullptr : pipe_cache_take(pkey);
     const bool reused = pipe_h != nullptr;
@@ -2675,6 +2823,9 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
                     sd::format_rows(parts[(size_t)x], reads[sl.r].name, reads[sl.r].name_len, ts.tnames, w.rows + sl.a,
                                     (size_t)(sl.b - sl.a), sl.a > off[sl.r - w.r0] ? w.rows[sl.a - 1].end : 0);
                 });
+                if (records_out)
+                    for (size_t r = w.r0; r < w.r1; ++r)
+                        rec_w.add_read(reads[r].name, reads[r].name_len, reads[r].len, w.rows + off[r - w.r0], off[r - w.r0 + 1] - off[r - w.r0]);
                 t_fmt += now_s() - t0;
                 t0 = now_s();
                 preads.clear();
@@ -2763,6 +2914,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     sink_thread.join();
     if (rc == SD_OK && sink_rc.load()) { rc = sink_rc.load(); err = sink_err; }
     if (!close_all() && rc == SD_OK) { rc = SD_ERR_IO; err = std::string("short write to ") + raw_tsv_out; }
+    if (records_out && rc == SD_OK) rc = rec_w.close(err, records_out);
     if (timing)
         std::fprintf(stderr, "[sd timing] %zu batches: pack+enqueue %.1f ms, wait %.1f ms, raw text %.1f ms, post-processing %.1f ms, "
                      "file writes %.1f ms, total %.1f ms\n", batches.size(), pipe.pack_s * 1e3, pipe.wait_s * 1e3, t_fmt * 1e3,
@@ -2791,6 +2943,13 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     if (rc == SD_OK && !getenv("SD_PIPE_CACHE_OFF")) pipe_cache_give(pkey, std::move(pipe_h));
     if (rc) { set_err(errbuf, errlen, err); return rc; }
     return SD_OK;
+}
+
+int sd_run_files_records(const char* reads_fa, const char* monomers_fa, const sd_params* p, const char* raw_tsv_out,
+                         const char* final_tsv_out, const char* alt_tsv_out, const char* records_out, int32_t min_identity,
+                         int32_t second_best, const double* lr_coef, char* errbuf, size_t errlen) {
+    return run_files_impl(reads_fa, monomers_fa, p, 0, 1, raw_tsv_out, final_tsv_out, alt_tsv_out, min_identity, second_best,
+                          lr_coef, nullptr, errbuf, errlen, records_out);
 }
 
 void sd_last_run_stats(double out[24]) {

@@ -12,6 +12,12 @@ Three tab-separated text files make up the contract with downstream tools (centr
   <out>_alt.tsv   6 columns (main.py:161-165): read, monomer, start, end, identity, '*' for the
                   monomer reported in <out>.tsv else '-'
 
+A fourth, binary, file is this package's own (the reference has no counterpart; opt-in, `--records`):
+
+  <out>_raw.sdr   the rows of <out>_raw.tsv as 16-byte records per read (read_records / write_records below;
+                  layout in csrc/sd_records.hpp, C-ABI sd_write_records / sd_read_records in include/sd_hip.h).
+                  records_to_raw_tsv(read_records(path)) is the raw TSV byte for byte.
+
 Readers return lists of named tuples with numeric fields converted; writers reproduce the reference's
 text exactly (round trip = identity on files the reference or this package wrote), so a tool can
 filter / merge decompositions without re-deriving the formatting rules.
@@ -137,3 +143,134 @@ def by_read(rows):
             out.append((r.read, []))
         out[-1][1].append(r)
     return out
+
+
+# ---- binary record stream (<out>_raw.sdr) -------------------------------------------------------------
+# Pure Python (struct only): a downstream tool needs neither the HIP library nor numpy to consume it.  The native
+# reader / writer of the same bytes is sd_read_records / sd_write_records (lib.read_records / lib.write_records).
+import struct
+
+RECORDS_MAGIC = b"SDRECS1\n"
+Records = namedtuple("Records", "scoring part_size overlap ed_thr templates reads")
+"""scoring = (ins, del, mismatch, match); templates = names as in column 2 of the raw TSV (monomers, then monomers
++ "'"); reads = [(name, read_len or -1, [(template index, start, end, score), ...])] in file order."""
+
+
+def _pad8(n):
+    return (-n) & 7
+
+
+def write_records(path, rec):
+    """Records -> file.  Layout: csrc/sd_records.hpp."""
+    head = bytearray(RECORDS_MAGIC)
+    head += struct.pack("<II", 0, 0)
+    head += struct.pack("<7i", *(list(rec.scoring) + [rec.part_size, rec.overlap, rec.ed_thr]))
+    head += struct.pack("<I", len(rec.templates))
+    for t in rec.templates:
+        b = t.encode()
+        head += struct.pack("<I", len(b)) + b
+    head += b"\0" * _pad8(len(head))
+    struct.pack_into("<I", head, 8, len(head))
+    nt = len(rec.templates)
+    total = 0
+    with open(path, "wb") as f:
+        f.write(head)
+        for name, rlen, rows in rec.reads:
+            b = name.encode()
+            f.write(struct.pack("<IIqq", len(b), 0, -1 if rlen is None else int(rlen), len(rows)))
+            f.write(b + b"\0" * _pad8(len(b)))
+            for t, s, e, sc in rows:
+                if not 0 <= t < nt:
+                    raise ValueError("template index %d outside the template table" % t)
+                f.write(struct.pack("<4i", t, s, e, int(sc)))
+            total += len(rows)
+        f.write(struct.pack("<IIqq", 0xFFFFFFFF, 0, len(rec.reads), total))
+
+
+def read_records(path):
+    """file -> Records; FormatError for anything that is not a complete, consistent record stream."""
+    with open(path, "rb") as f:
+        d = f.read()
+
+    def bad(msg):
+        return FormatError(str(path), 0, msg)
+
+    if len(d) < 48 or d[:8] != RECORDS_MAGIC:
+        raise bad("not a record stream (bad magic)")
+    hb, _ = struct.unpack_from("<II", d, 8)
+    v = struct.unpack_from("<7i", d, 16)
+    (nt,) = struct.unpack_from("<I", d, 44)
+    at = 48
+    templates = []
+    for _ in range(nt):
+        if at + 4 > len(d):
+            raise bad("truncated template table")
+        (l,) = struct.unpack_from("<I", d, at)
+        at += 4
+        if at + l > len(d):
+            raise bad("truncated template table")
+        templates.append(d[at:at + l].decode())
+        at += l
+    at += _pad8(at)
+    if at != hb or hb > len(d):
+        raise bad("header size does not match the template table")
+    reads, total = [], 0
+    while True:
+        if at + 8 > len(d):
+            raise bad("truncated: no trailer (the writer did not finish)")
+        nl, _ = struct.unpack_from("<II", d, at)
+        at += 8
+        if nl == 0xFFFFFFFF:
+            if at + 16 > len(d):
+                raise bad("truncated trailer")
+            nr, nrow = struct.unpack_from("<qq", d, at)
+            at += 16
+            if nr != len(reads) or nrow != total:
+                raise bad("trailer totals do not match the read blocks")
+            if at != len(d):
+                raise bad("bytes after the trailer")
+            return Records(tuple(v[:4]), v[4], v[5], v[6], templates, reads)
+        if at + 16 > len(d):
+            raise bad("truncated read block")
+        rlen, n = struct.unpack_from("<qq", d, at)
+        at += 16
+        if n < 0 or at + nl > len(d):
+            raise bad("truncated read block")
+        name = d[at:at + nl].decode()
+        at += nl + _pad8(nl)
+        if at + 16 * n > len(d):
+            raise bad("truncated read block")
+        flat = struct.unpack_from("<%di" % (4 * n), d, at)
+        at += 16 * n
+        rows = [tuple(flat[4 * i:4 * i + 4]) for i in range(n)]
+        for r in rows:
+            if not 0 <= r[0] < nt:
+                raise bad("record with a template index outside the template table")
+        reads.append((name, rlen, rows))
+        total += n
+
+
+def records_to_raw_rows(rec):
+    """Records -> [RawRow] exactly as SaveBatch derives them (gap from the previous end of the same read, length)."""
+    out = []
+    for name, _, rows in rec.reads:
+        out.extend(raw_rows(name, [(rec.templates[t], s, e, sc) for t, s, e, sc in rows]))
+    return out
+
+
+def records_to_raw_tsv(rec):
+    """Records -> the text of <out>_raw.tsv (main.cpp:272-285)."""
+    return format_raw(records_to_raw_rows(rec))
+
+
+def raw_to_records(rows, templates, scoring=(-1, -1, -1, 1), part_size=5000, overlap=500, ed_thr=-1, read_lens=None):
+    """[RawRow] (+ the template names in the DP's order: monomers, then monomers + "'") -> Records.  A repeated template
+    name maps to its first index, which is what the raw TSV can tell."""
+    idx = {}
+    for i, t in enumerate(templates):
+        idx.setdefault(t, i)
+    reads = []
+    for name, rr in by_read(rows):
+        reads.append((name, -1 if read_lens is None else read_lens.get(name, -1),
+                      [(idx[r.monomer], r.start, r.end, int(r.score)) for r in rr]))
+    return Records(tuple(scoring), part_size, overlap, ed_thr, list(templates), reads)

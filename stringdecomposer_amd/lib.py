@@ -35,6 +35,8 @@ EXPORTS = [
     "sd_stream_info", "sd_pack_bases", "sd_identity_segments_dev", "sd_nw_release_cache", "sd_last_run_stats", "sd_guard_trips",
     "sd_run_files", "sd_convert_raw_tsv", "sd_decompose_files_range", "sd_assemble_files_tsv",
     "sd_host_stage_rates", "sd_run_files_range", "sd_plan_info", "sd_write_parts_selftest", "sd_convert_raw_tsv_range",
+    "sd_write_records", "sd_read_records", "sd_records_free", "sd_records_to_raw_tsv", "sd_decompose_files_records",
+    "sd_run_files_records",
 ]
 
 
@@ -55,6 +57,16 @@ class Params(C.Structure):
 class Rec(C.Structure):
     _fields_ = [("tmpl", C.c_int32), ("start", C.c_int32), ("end", C.c_int32),
                 ("score", C.c_int32)]
+
+
+class Records(C.Structure):
+    """sd_records (include/sd_hip.h): a parsed binary record stream."""
+    _fields_ = [("ins", C.c_int32), ("del_", C.c_int32), ("mismatch", C.c_int32), ("match", C.c_int32),
+                ("part_size", C.c_int32), ("overlap", C.c_int32), ("ed_thr", C.c_int32),
+                ("n_templates", C.c_int32), ("tmpl_names", C.POINTER(C.c_char_p)),
+                ("n_reads", C.c_int32), ("read_names", C.POINTER(C.c_char_p)),
+                ("read_lens", C.POINTER(C.c_int64)), ("row_off", C.POINTER(C.c_int64)),
+                ("n_rows", C.c_int64), ("rows", C.POINTER(Rec))]
 
 
 class Fasta(C.Structure):
@@ -144,6 +156,15 @@ def load():
     L.sd_stream_info.argtypes = [C.c_void_p, P(C.c_int64)]
     L.sd_pack_bases.restype = C.c_int32
     L.sd_pack_bases.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.sd_write_records.argtypes = [C.c_char_p, P(Params), P(C.c_char_p), C.c_int32, P(C.c_char_p), C.c_void_p, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.sd_read_records.argtypes = [C.c_char_p, P(Records), C.c_char_p, C.c_size_t]
+    L.sd_records_free.argtypes = [P(Records)]
+    L.sd_records_free.restype = None
+    L.sd_records_to_raw_tsv.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_size_t]
+    L.sd_decompose_files_records.argtypes = [C.c_char_p, C.c_char_p, P(Params), C.c_char_p, C.c_char_p, C.c_size_t]
+    L.sd_run_files_records.argtypes = [C.c_char_p, C.c_char_p, P(Params), C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                       C.c_int32, C.c_int32, P(C.c_double), C.c_char_p, C.c_size_t]
     _lib = L
     return L
 
@@ -229,15 +250,81 @@ def decompose_files(reads_fa, monomers_fa, raw_tsv_out, **kw):
 
 
 def run_files(reads_fa, monomers_fa, raw_tsv_out, final_tsv_out, alt_tsv_out, min_identity=0, second_best=False,
-              lr_coef=(-31.48494996, 0.41784018, 0.69186882), **kw):
-    """The whole CLI job natively (sd_run_files): raw, final and _alt TSV files from the two FASTA files."""
+              lr_coef=(-31.48494996, 0.41784018, 0.69186882), records_out=None, **kw):
+    """The whole CLI job natively (sd_run_files): raw, final and _alt TSV files from the two FASTA files; with
+    records_out also the binary record stream of the raw rows (sd_run_files_records)."""
     L = load()
     p = make_params(**kw)
     err = C.create_string_buffer(4096)
     coef = (C.c_double * 3)(*[float(x) for x in lr_coef])
-    rc = L.sd_run_files(os.fsencode(reads_fa), os.fsencode(monomers_fa), C.byref(p), os.fsencode(raw_tsv_out),
-                        os.fsencode(final_tsv_out), os.fsencode(alt_tsv_out), int(min_identity), 1 if second_best else 0,
-                        coef, err, 4096)
+    if records_out is None:
+        rc = L.sd_run_files(os.fsencode(reads_fa), os.fsencode(monomers_fa), C.byref(p), os.fsencode(raw_tsv_out),
+                            os.fsencode(final_tsv_out), os.fsencode(alt_tsv_out), int(min_identity), 1 if second_best else 0,
+                            coef, err, 4096)
+    else:
+        rc = L.sd_run_files_records(os.fsencode(reads_fa), os.fsencode(monomers_fa), C.byref(p), os.fsencode(raw_tsv_out),
+                                    os.fsencode(final_tsv_out), os.fsencode(alt_tsv_out), os.fsencode(records_out),
+                                    int(min_identity), 1 if second_best else 0, coef, err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+
+
+def decompose_files_records(reads_fa, monomers_fa, records_out, **kw):
+    """reads.fa + monomers.fa -> binary record stream (sd_decompose_files_records): the rows of the raw TSV, no text."""
+    L = load()
+    p = make_params(**kw)
+    err = C.create_string_buffer(4096)
+    rc = L.sd_decompose_files_records(os.fsencode(reads_fa), os.fsencode(monomers_fa), C.byref(p),
+                                      os.fsencode(records_out), err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+
+
+def write_records(path, tmpl_names, read_names, read_lens, rows, row_off, **kw):
+    """sd_write_records (host only): rows = structured array / sequence of (tmpl, start, end, score), row_off[n_reads + 1]."""
+    import numpy as np
+    L = load()
+    p = make_params(**kw)
+    r = np.ascontiguousarray(np.asarray(rows, dtype=_rec_dtype()) if not isinstance(rows, np.ndarray) else rows, dtype=_rec_dtype())
+    o = np.ascontiguousarray(row_off, dtype=np.int64)
+    rl = None if read_lens is None else np.ascontiguousarray(read_lens, dtype=np.int64)
+    err = C.create_string_buffer(4096)
+    rc = L.sd_write_records(os.fsencode(path), C.byref(p), _strs([_b(t) for t in tmpl_names]), len(tmpl_names),
+                            _strs([_b(x) for x in read_names]), None if rl is None else rl.ctypes.data, len(read_names),
+                            r.ctypes.data, o.ctypes.data, err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+
+
+def read_records(path):
+    """sd_read_records (host only) -> dict(params, templates, reads, read_lens, row_off, rows[structured array])."""
+    import numpy as np
+    L = load()
+    out = Records()
+    err = C.create_string_buffer(4096)
+    rc = L.sd_read_records(os.fsencode(path), C.byref(out), err, 4096)
+    if rc != SD_OK:
+        raise SdError(rc, err.value.decode(errors="replace"))
+    try:
+        n, nr = out.n_reads, out.n_rows
+        res = {"params": {"scoring": (out.ins, out.del_, out.mismatch, out.match), "part_size": out.part_size,
+                          "overlap": out.overlap, "ed_thr": out.ed_thr},
+               "templates": [out.tmpl_names[t].decode() for t in range(out.n_templates)],
+               "reads": [out.read_names[r].decode() for r in range(n)],
+               "read_lens": [int(out.read_lens[r]) for r in range(n)],
+               "row_off": np.ctypeslib.as_array(out.row_off, shape=(n + 1,)).copy(),
+               "rows": (np.frombuffer(C.string_at(out.rows, nr * C.sizeof(Rec)), dtype=_rec_dtype()).copy() if nr
+                        else np.zeros(0, dtype=_rec_dtype()))}
+    finally:
+        L.sd_records_free(C.byref(out))
+    return res
+
+
+def records_to_raw_tsv(records_path, raw_tsv_out, threads=1):
+    """sd_records_to_raw_tsv (host only): the raw TSV `dp` prints for the rows of a record stream."""
+    L = load()
+    err = C.create_string_buffer(4096)
+    rc = L.sd_records_to_raw_tsv(os.fsencode(records_path), os.fsencode(raw_tsv_out), int(threads), err, 4096)
     if rc != SD_OK:
         raise SdError(rc, err.value.decode(errors="replace"))
 

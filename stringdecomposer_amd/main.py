@@ -355,7 +355,7 @@ def convert_tsv(decomposition, reads, monomers, outfile, identity_th, light, thr
 
 
 def run(sequences, monomers, num_threads, scoring, batch_size, raw_file, ed_thr, overlap, logger,
-        ref_compat=False, device=0, kernel=0, final_file=None, min_identity=0, second_best=False):
+        ref_compat=False, device=0, kernel=0, final_file=None, min_identity=0, second_best=False, records_file=None):
     """main.py:186-197 with the subprocess replaced by libsd_hip.so.
 
     Single process with final_file given: ONE native call (sd_run_files) streams the job through the
@@ -408,7 +408,8 @@ def run(sequences, monomers, num_threads, scoring, batch_size, raw_file, ed_thr,
                       min_identity=min_identity, second_best=second_best, lr_coef=_lr_coef(),
                       scoring=(ins, dels, mm, match), part_size=int(batch_size), overlap=int(overlap),
                       ed_thr=int(ed_thr), threads=int(num_threads), device=device, kernel=kernel,
-                      flags=lib.FLAG_PROGRESS)   # the dp binary's progress lines on stderr (main.cpp:82,115,393)
+                      flags=lib.FLAG_PROGRESS,   # the dp binary's progress lines on stderr (main.cpp:82,115,393)
+                      records_out=records_file)
         return True
     lib.decompose_files(sequences, monomers, raw_file, scoring=(ins, dels, mm, match),
                         part_size=int(batch_size), overlap=int(overlap), ed_thr=int(ed_thr),
@@ -447,6 +448,9 @@ def main(argv=None):
     parser.add_argument("--device", type=int, default=0, help="HIP device ordinal (by default 0)")
     parser.add_argument("--kernel", choices=["auto", "generic", "fast"], default="auto",
                         help="device kernel family (by default auto)")
+    parser.add_argument("--records", action="store_true",
+                        help="also write <out-file>_raw.sdr: the rows of the raw tsv as a binary record stream "
+                             "(stringdecomposer_amd.formats.read_records)")
     args = parser.parse_args(argv)
     pathlib.Path(args.out_dir).mkdir(parents=True, exist_ok=True)
 
@@ -461,13 +465,15 @@ def main(argv=None):
 
     raw_decomp_fn = os.path.join(args.out_dir, args.out_file + "_raw.tsv")
     convert_tsv_fn = os.path.join(args.out_dir, args.out_file + ".tsv")
+    records_fn = os.path.join(args.out_dir, args.out_file + "_raw.sdr") if args.records else None
     kernel = {"auto": 0, "generic": 1, "fast": 2}[args.kernel]
     try:
         raw_decomposition = run(args.sequences, args.monomers, args.threads, args.scoring, args.batch_size,
                                 raw_decomp_fn, args.ed_thr, args.overlap, logger,
                                 ref_compat=args.ref_compat, device=args.device, kernel=kernel,
                                 final_file=convert_tsv_fn, min_identity=int(args.min_identity),
-                                second_best=args.second_best)
+                                second_best=args.second_best,
+                                records_file=records_fn if shard.world()[2] == 1 else None)
     except lib.SdError as e:
         # the reference dies with CalledProcessError after the binary printed its message on stderr
         sys.stderr.write(e.msg + "\n")
@@ -476,6 +482,16 @@ def main(argv=None):
     if raw_decomposition is None:
         return  # not rank 0
     logger.info("Saved raw decomposition to " + raw_decomp_fn)
+    if records_fn and shard.world()[2] > 1:
+        # a multi-GPU launch: the ranks wrote text parts; rank 0 restates the finished raw file as the record stream
+        from . import formats
+        names = lib.fasta_load(args.monomers)[0]
+        sc = (-1, -1, -1, 1) if args.ref_compat else tuple(int(x) for x in args.scoring.split(","))
+        formats.write_records(records_fn, formats.raw_to_records(
+            formats.read_raw(raw_decomp_fn), names + [n + "'" for n in names], scoring=sc,
+            part_size=int(args.batch_size), overlap=int(args.overlap), ed_thr=int(args.ed_thr)))
+    if records_fn:
+        logger.info("Saved the binary record stream to " + records_fn)
     logger.info("Transforming raw alignments...")
     if raw_decomposition is not True:
         # multi-GPU launch: rank 0 holds the raw TSV of the whole job; convert_tsv (main.py:168-184) natively,

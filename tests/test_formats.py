@@ -53,3 +53,75 @@ def test_malformed_lines_are_reported_with_position():
     with pytest.raises(formats.FormatError):
         formats.parse_alt("r\tm\t1\t2\t99.00\tx\n")
     assert formats.parse_final("") == []
+
+
+# ---- binary record stream (<out>_raw.sdr) --------------------------------------------------
+def _templates(case):
+    from stringdecomposer_amd import lib
+    names = lib.fasta_load(case["monomers"])[0]
+    return names + [n + "'" for n in names]     # main.cpp:364-371
+
+
+@pytest.mark.parametrize("name", case_names(include_edthr=True))
+def test_record_stream_round_trip_on_reference_fixtures(name, tmp_path):
+    """raw TSV of the reference binary -> Records -> file -> (Python reader, native reader) -> the same raw TSV,
+    and the native writer produces the Python writer's bytes."""
+    from stringdecomposer_amd import lib
+    c = load_case(name)
+    text = c["raw"].decode()
+    sc = tuple(c.get("scoring") or (-1, -1, -1, 1))
+    rec = formats.raw_to_records(formats.parse_raw(text), _templates(c), scoring=sc,
+                                 part_size=int(c.get("part", 5000)), overlap=int(c.get("overlap", 500)),
+                                 ed_thr=-1 if c.get("ed_thr") is None else int(c["ed_thr"]))
+    p = str(tmp_path / "a.sdr")
+    formats.write_records(p, rec)
+    back = formats.read_records(p)
+    assert back == rec
+    assert formats.records_to_raw_tsv(back) == text
+    n = lib.read_records(p)
+    assert n["templates"] == rec.templates and n["reads"] == [r[0] for r in rec.reads]
+    assert n["params"]["scoring"] == sc
+    flat = [tuple(int(v) for v in row) for row in n["rows"].tolist()]
+    assert flat == [row for _, _, rows in rec.reads for row in rows]
+    out = str(tmp_path / "a.tsv")
+    lib.records_to_raw_tsv(p, out, threads=3)
+    with open(out) as f:
+        assert f.read() == text
+    q = str(tmp_path / "b.sdr")
+    lib.write_records(q, n["templates"], n["reads"], n["read_lens"], n["rows"], n["row_off"], scoring=sc,
+                      part_size=rec.part_size, overlap=rec.overlap, ed_thr=rec.ed_thr)
+    with open(p, "rb") as f, open(q, "rb") as g:
+        assert f.read() == g.read()
+
+
+def test_record_stream_rejects_damaged_files(tmp_path):
+    from stringdecomposer_amd import lib
+    rec = formats.Records((-1, -1, -1, 1), 5000, 500, -1, ["m", "m'"],
+                          [("r0", 300, [(0, 0, 170, 150), (1, 171, 299, 90)]), ("empty", 5, []), ("r1", -1, [(1, 3, 9, 2)])])
+    p = str(tmp_path / "a.sdr")
+    formats.write_records(p, rec)
+    assert formats.read_records(p) == rec
+    assert formats.records_to_raw_tsv(rec) == ("r0\tm\t0\t170\t150.000000\t0\t170\nr0\tm'\t171\t299\t90.000000\t1\t128\n"
+                                               "r1\tm'\t3\t9\t2.000000\t3\t6\n")
+    with open(p, "rb") as f:
+        good = f.read()
+    damaged = {"no trailer": good[:-24], "cut inside a block": good[:len(good) // 2], "bad magic": b"X" + good[1:],
+               "extra bytes": good + b"\0" * 8,
+               # template index 7 in the first record of r0 (its block starts right behind the header)
+               "bad template": None}
+    hb = int.from_bytes(good[8:12], "little")
+    at = hb + 24 + 8           # block head (24) + padded name "r0" (8)
+    damaged["bad template"] = good[:at] + (7).to_bytes(4, "little") + good[at + 4:]
+    for what, data in damaged.items():
+        q = str(tmp_path / "bad.sdr")
+        with open(q, "wb") as f:
+            f.write(data)
+        with pytest.raises(formats.FormatError):
+            formats.read_records(q)
+        with pytest.raises(lib.SdError) as e:
+            lib.read_records(q)
+        assert e.value.code == lib.SD_ERR_FORMAT, what
+        with pytest.raises(lib.SdError):
+            lib.records_to_raw_tsv(q, str(tmp_path / "x.tsv"))
+    with pytest.raises(lib.SdError):   # a writer is given a template index outside its table
+        lib.write_records(str(tmp_path / "c.sdr"), ["m"], ["r"], [10], [(1, 0, 5, 3)], [0, 1])
