@@ -319,8 +319,11 @@ def bench_strong(args):
         job_bp = args.seq_len
         st = None
 
+        last = {}
+
         def step():
             recs, off = lib.decompose_chunk_range(rs, ms, lo, hi, scoring=scoring, device=local_rank, threads=threads)
+            last["recs"], last["off"] = recs, off
             return len(recs)
         workload = "C5: ONE sequence of %d bp, 12 monomers, scoring -2,-3,-4,2, part 5000 / overlap 500 (%d chunks); this " \
                    "rank: chunks [%d, %d)" % (args.seq_len, n_chunks, lo, hi)
@@ -340,6 +343,33 @@ def bench_strong(args):
     shard.barrier(dist, bar_dev)
     dt = shard.max_over_ranks(dist, my_dt, dev)
     rate = shard.job_rate(dist, job_bp * K, my_dt, dev)
+    # What follows the DP in the real multi-process job and is NOT inside the timed steps: the ranks' records meet on rank 0
+    # (host-side gather, no device collective) and rank 0 alone turns them into the raw TSV (chunk offsets, seam merge,
+    # SaveBatch text: main.cpp:104-117, 272-302) -- the serial part of the strong-scaling job, timed once and reported beside it.
+    serial = None
+    if st is None:
+        import numpy as np
+        shard.barrier(dist, bar_dev)
+        s0 = time.perf_counter()
+        if dist is not None and ws > 1:
+            box = [None] * ws if rank == 0 else None
+            dist.gather_object((lo, last["recs"], last["off"]), box, dst=0)
+        else:
+            box = [(lo, last["recs"], last["off"])]
+        s1 = time.perf_counter()
+        if rank == 0:
+            parts = sorted(box, key=lambda t: t[0])
+            all_recs = np.concatenate([q[1] for q in parts])
+            offs, base = [np.zeros(1, dtype=np.int64)], 0
+            for _, r, o in parts:
+                offs.append(o[1:] + base)
+                base += len(r)
+            tsv = lib.assemble_tsv(["seq"], [args.seq_len], mn, all_recs, np.concatenate(offs), scoring=scoring, threads=threads)
+            s2 = time.perf_counter()
+            serial = {"gather_records_ms": (s1 - s0) * 1e3, "rank0_assemble_raw_tsv_ms": (s2 - s1) * 1e3,
+                      "raw_tsv_rows": tsv.count(b"\n"), "raw_tsv_bytes": len(tsv),
+                      "note": "once, after the timed steps: records of all ranks -> rank 0 (gloo / in-process) -> raw TSV text in "
+                              "host memory; not part of ms_per_step"}
     kern = None
     if st:
         b = st.stats()
@@ -352,7 +382,7 @@ def bench_strong(args):
            "config": {"workload": workload, "job_bp": job_bp, "share": [kind, lo, hi], "scoring": list(scoring),
                       "host_threads": threads, "seed": args.seed,
                       "sharding": "contiguous blocks of %s, no collective (shard.strong_share)" % kind},
-           "roofline": None, "cpu_baseline": None,
+           "roofline": None, "cpu_baseline": None, "serial_after_dp": serial,
            "rank0": {"seconds": my_dt, "rows_out_last_step": out_rows, "kernel_ms_per_step": kern,
                      "process_cpu_ms_per_step": ((c1.user - c0.user) + (c1.system - c0.system)) * 1e3 / K},
            "note": "strong-scaling companion of the headline line (which is weak scaling on C2, roofline and cpu_baseline "
@@ -364,6 +394,20 @@ def bench_strong(args):
 
 
 _REAL_STDOUT = None
+
+
+KERNEL_SOURCES = ("sd_fast_fill.hpp", "sd_fast_dev.hpp", "sd_fast_trace2.hip", "sd_fast_wide_fill.hpp")
+
+
+def kernel_source_hashes():
+    """sha256 of the sources that decide the instruction stream of the fill / traceback kernels the committed PMC
+    profile (profiles/fill_traffic.json) was taken on."""
+    import hashlib
+    out = {}
+    for fn in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "stringdecomposer_amd", "csrc", fn), "rb") as f:
+            out[fn] = hashlib.sha256(f.read()).hexdigest()[:16]
+    return out
 
 
 def _claimed_stdout():
@@ -591,11 +635,22 @@ def main():
     res_achieved = alg_bytes / max(einfo["fill_launches"], 1) / res_fill_s / 1e9 if res_fill_s > 0 else 0.0
     traffic = None
     valu = None
+    profile_problems = []
     tf = os.path.join(ROOT, "profiles", "fill_traffic.json")
     if os.path.isfile(tf):
         try:
             with open(tf) as f:
                 tj = json.load(f)
+            # The committed counters belong to ONE build of the kernels: instructions per row and bytes per launch change
+            # with the row loop.  The profile carries the hashes of the kernel sources it was taken on
+            # (tools/collect_traffic.py); a different source -> no instruction count, no traffic, and a note.
+            want = tj.get("kernel_sources_sha256")
+            have = kernel_source_hashes()
+            if want != have:
+                stale = sorted(k for k in have if (want or {}).get(k) != have[k])
+                profile_problems.append("profiles/fill_traffic.json was taken on other kernel sources (%s): valu_issue and traffic "
+                                        "withheld; rerun tools/collect_traffic.py on the GPU box" % ", ".join(stale))
+                raise LookupError("stale profile")
             # the C2 entry at the top level, further workloads (the 64-monomer wide kernel) under "other_workloads"
             for tj in [tj] + list(tj.get("other_workloads", [])):
                 same_kernel = (tj.get("kernel_family") == info["family"] and
@@ -639,6 +694,7 @@ def main():
         v_iso = valu["wave_insts_per_launch"] / res_fill_s / 1e9 if res_steps and res_fill_s > 0 else None
         roofline = {"bound": "valu", "achieved": v_ach, "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s",
                     "frac": v_ach / VALU_PEAK_GINST,
+                    "stream_span_frac": v_ach / VALU_PEAK_GINST,
                     "isolated_frac": None if v_iso is None else v_iso / VALU_PEAK_GINST}
         # `peak` prices the 4.1 cycles at the 2.4-GHz peak clock; under this load the chip holds 2.27-2.33 GHz (the
         # micro-benchmark's wall time per instruction, profiles/r03_ubench_issue.txt: 1.806 ns per SIMD for the fill's
@@ -647,13 +703,20 @@ def main():
         # drain and shares the machine with the previous traceback), so `frac` -- instructions over the fill's own
         # HIP-event span, as the contract asks -- falls when the overlap grows even if the step gets faster.  The figure
         # that cannot be gamed by overlap: the vector instructions of BOTH kernels of a step over the step time.
-        roofline["frac_note"] = ("frac = fill instructions / the fill's in-stream HIP-event span (spans of consecutive batches "
-                                 "overlap in stream mode 2); isolated_frac = the same launch alone; step_frac = (fill + traceback "
-                                 "instructions) / step time, the issue slots the whole path uses")
+        roofline["frac_note"] = ("frac / achieved = work over time: the vector wave-instructions of the fill AND the traceback of the "
+                                 "timed steps over the timed region (step_frac; without a traceback count: the fill alone, "
+                                 "isolated_frac); stream_span_frac = fill instructions / the fill's in-stream HIP-event span -- "
+                                 "spans of consecutive batches overlap in stream mode 2, so it measures occupancy of the stream, "
+                                 "not work; isolated_frac = the fill launched alone on the resident batch")
         if tj.get("traceback_SQ_INSTS_VALU_per_launch") and ws == 1 and args.sub_batches == 1:
             both = valu["wave_insts_per_launch"] + tj["traceback_SQ_INSTS_VALU_per_launch"] * rows / tj["workload_rows"]
             roofline["step_frac"] = both * K / dt / 1e9 / VALU_PEAK_GINST
             valu["traceback_wave_insts_per_launch"] = tj["traceback_SQ_INSTS_VALU_per_launch"] * rows / tj["workload_rows"]
+            roofline["achieved"] = both * K / dt / 1e9
+            roofline["frac"] = roofline["step_frac"]
+        elif v_iso is not None:
+            roofline["achieved"] = v_iso
+            roofline["frac"] = v_iso / VALU_PEAK_GINST
         valu["wall_ceiling_ginst"] = N_SIMDS / VALU_WALL_NS_PER_INST
         valu["isolated_frac_of_wall_ceiling"] = None if v_iso is None else v_iso / valu["wall_ceiling_ginst"]
     else:   # no instruction count for this workload / binary: only the notional figure
@@ -662,6 +725,8 @@ def main():
                     "isolated_frac": res_achieved / HBM_PEAK_GBS if res_steps else None}
     roofline.update({
         "traffic": traffic,
+        # the counters' HBM bytes of a launch over the launch's own time (alone): what the fill really asks of the 8 TB/s
+        "hbm_measured_frac": None if (traffic is None or not res_steps or res_fill_s <= 0) else traffic / res_fill_s / 1e9 / HBM_PEAK_GBS,
         "traffic_source": None if traffic is None else
         "committed profile: profiles/fill_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
         "device-resident single launch), not measured in this run",
@@ -746,6 +811,8 @@ def main():
         problems.append("integer-cell run produced a different number of rows")
     if problems:
         out["invalid"] = problems
+    if profile_problems:   # (the measured value stands; only the figures derived from the committed counters are withheld)
+        out["profile_problems"] = profile_problems
     if rank == 0:
         print(json.dumps(out), file=_claimed_stdout(), flush=True)
     if dist is not None:

@@ -911,7 +911,8 @@ def test_bench_line_contract():
     r = j["roofline"]
     # the fill is VALU bound (measured issue ceiling); the notional HBM figure north_star asks for rides along
     assert r["bound"] == "valu" and r["unit"] == "G wave-inst/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert 0 < r["frac"] < 1 and 0 < r["isolated_frac"] < 1
+    assert 0 < r["frac"] < 1 and 0 < r["isolated_frac"] < 1 and 0 < r["stream_span_frac"] < 1
+    assert r["frac"] == r["step_frac"] and "profile_problems" not in j   # work over time; the committed counters match this build
     h = r["hbm_notional"]
     assert h["unit"] == "GB/s" and h["peak"] == 8000.0 and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-9
     assert h["isolated_frac"] > 0 and h["path_frac"] > 0

@@ -827,3 +827,15 @@ def test_alphabet_check_vector_path_names_the_first_bad_byte(tmp_path):
             p = tmp_path / "n.fa"
             p.write_bytes(b">r1\n" + bytes(b) + b"\n")
             assert lib.fasta_load(str(p))[2] is True
+
+
+def test_committed_pmc_profile_belongs_to_these_kernel_sources():
+    """bench.py derives instructions per row and HBM traffic of the fill from the committed rocprofv3 counters
+    (profiles/fill_traffic.json) and withholds them when the kernel sources have changed since they were taken: a kernel
+    edit without a fresh profile fails HERE, before a bench line goes out without its roofline."""
+    import json
+    import bench
+    with open(os.path.join(ROOT, "profiles", "fill_traffic.json")) as f:
+        tj = json.load(f)
+    assert tj.get("kernel_sources_sha256") == bench.kernel_source_hashes(), \
+        "kernel sources changed: rerun tools/profile_r02.sh + tools/reduce_pmc.py on the GPU box"

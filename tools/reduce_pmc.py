@@ -83,6 +83,10 @@ def main():
             if tr:
                 ft["traceback_SQ_INSTS_VALU_per_launch"] = res["valu"][tr[0]]["SQ_INSTS_VALU_per_launch"]
                 ft["traceback_kernel_instance"] = tr[0].split(":", 1)[1]
+            # the build these counters belong to: bench.py withholds them when the kernel sources have changed since
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            import bench
+            ft["kernel_sources_sha256"] = bench.kernel_source_hashes()
             json.dump(ft, open(sys.argv[3], "w"), indent=1, sort_keys=True)
             print("updated", sys.argv[3])
 
