@@ -153,10 +153,10 @@ int PostProcessor::process(const PostRead* reads, size_t n_reads, const sd_rec* 
 int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd_rec* rows, const int64_t* row_off,
                                  std::vector<std::string>& pf, std::vector<TextBuf>& pa, std::string& err,
                                  const IdentRef* ident) {
-    pf.clear();
-    pa.clear();
+    // (pf / pa may come back from an earlier call: their elements keep their memory -- a fresh 0.5-MB buffer per slice of
+    // blocks is an mmap and a few hundred page faults, 280 MB of them per C4 --second-best job)
     const int64_t nB = row_off[n_reads];
-    if (nB == 0) return SD_OK;
+    if (nB == 0) { pf.clear(); pa.clear(); return SD_OK; }
     const double t_0 = now_seconds();
     const int T = (int)il_seq.size();
     const int nK = (int)keys.size();
@@ -243,8 +243,10 @@ int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd
     // rows -> text, in slices of blocks formatted by all threads
     const int64_t grain = second_best ? 64 : 2048;
     const int64_t n_sl = (nB + grain - 1) / grain;
-    pf.assign((size_t)n_sl, std::string());
-    pa.assign((size_t)n_sl, TextBuf());
+    pf.resize((size_t)n_sl);
+    pa.resize((size_t)n_sl);
+    for (std::string& q : pf) q.clear();
+    for (TextBuf& q : pa) q.clear();
     size_t key_bytes = 0, name_max = 0;
     for (const std::string& k : keys) key_bytes += k.size();
     for (size_t r = 0; r < n_reads; ++r) name_max = std::max(name_max, reads[r].name_len);

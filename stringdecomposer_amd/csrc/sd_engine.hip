@@ -311,6 +311,16 @@ struct sd_engine {
     bool ident_valid = false;                    // the last fetch brought identities for every record
     sd::IdentArgs ia_plain{}, ia_homo{};
     hipEvent_t ev_id0 = nullptr, ev_id1 = nullptr;
+    // Identities in slices: a --second-best batch's identity launches take as long as its DP, and the text of its rows as
+    // long again.  With slice_end set (chunk indices, ascending, the last = number of chunks) the identity kernels run once
+    // per range of chunks -- the ranges' record bounds are read on the device from the record offsets -- with an event
+    // behind each, so that the host fetches, assembles and formats slice s while the device computes slice s + 1: ONE fill
+    // and traceback launch for the whole batch (cutting the job into four batches made four under-filled launches: C4's
+    // fill 47.6 instead of 22.6 ms) and the hand-over still in pieces.
+    std::vector<int> slice_end;
+    std::vector<hipEvent_t> ev_slice;
+    hipEvent_t ev_dp = nullptr;          // DP + compaction done, record offsets and guard flag on the host
+    bool sliced_run = false;             // the last run launched its identities in slices
 
     // run state
     hipStream_t last_stream = nullptr;
@@ -326,8 +336,9 @@ struct sd_engine {
     ~sd_engine() {
         for (hipEvent_t e : ev_fill) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_trace) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {ev_run0, ev_run1, ev_cmp0, ev_cmp1, ev_in, ev_id0, ev_id1})
+        for (hipEvent_t e : {ev_run0, ev_run1, ev_cmp0, ev_cmp1, ev_in, ev_id0, ev_id1, ev_dp})
             if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_slice) (void)hipEventDestroy(e);
         g_pinpool.give(h_ident, h_ident_bytes);
         g_pinpool.give(h_identh, h_identh_bytes);
     }
@@ -1079,23 +1090,51 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                                e->d_dense.p, e->dense_cap, true, e->ident_mode ? e->d_recchunk.p : nullptr,
                                e->d_scanws.p, ++e->scan_epoch);
             SD_HIP(hipEventRecord(e->ev_cmp1, ts));
+            auto copy_offsets = [&]() {
+                // the record offsets travel right behind the compaction: the fetch then knows the record
+                // count as soon as the stream is idle, without a second round trip
+                SD_HIP(hipMemcpyAsync(e->h_roff.p, e->d_roff.p, sizeof(int64_t) * ((size_t)C + 1), hipMemcpyDeviceToHost, ts));
+                if (e->family == 2) {   // and the fp16 range guard of the fills (reset for the next run behind the copy)
+                    e->h_guard.alloc(1);
+                    SD_HIP(hipMemcpyAsync(e->h_guard.p, e->d_guard.p, sizeof(int), hipMemcpyDeviceToHost, ts));
+                    SD_HIP(hipMemsetAsync(e->d_guard.p, 0, sizeof(int), ts));
+                }
+            };
+            e->sliced_run = e->ident_mode != 0 && !e->slice_end.empty() && e->slice_end.back() == C;
+            if (e->sliced_run) {
+                copy_offsets();
+                if (!e->ev_dp) SD_HIP(hipEventCreateWithFlags(&e->ev_dp, hipEventBlockingSync));
+                SD_HIP(hipEventRecord(e->ev_dp, ts));
+            }
             if (e->ident_mode) {   // identities of the final TSV on the batch's compact records (sd_ident.hip)
                 SD_HIP(hipEventRecord(e->ev_id0, ts));
                 e->ia_plain.dense = e->ia_homo.dense = e->d_dense.p;            // (a fetch may have grown them)
                 e->ia_plain.rec_chunk = e->ia_homo.rec_chunk = e->d_recchunk.p;
                 e->ia_plain.dense_cap = e->ia_homo.dense_cap = e->dense_cap;
-                sd::launch_ident(ts, e->ia_plain);
-                if (e->ident_mode == 2) sd::launch_ident(ts, e->ia_homo);
+                if (e->sliced_run) {
+                    while (e->ev_slice.size() < e->slice_end.size()) {
+                        hipEvent_t ev;
+                        SD_HIP(hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming));
+                        e->ev_slice.push_back(ev);
+                    }
+                    int c_lo = 0;
+                    for (size_t sl = 0; sl < e->slice_end.size(); ++sl) {
+                        const int c_hi = e->slice_end[sl];
+                        e->ia_plain.rec_lo = e->ia_homo.rec_lo = e->d_roff.p + c_lo;
+                        e->ia_plain.rec_hi = e->ia_homo.rec_hi = e->d_roff.p + c_hi;
+                        sd::launch_ident(ts, e->ia_plain);
+                        if (e->ident_mode == 2) sd::launch_ident(ts, e->ia_homo);
+                        SD_HIP(hipEventRecord(e->ev_slice[sl], ts));
+                        c_lo = c_hi;
+                    }
+                } else {
+                    e->ia_plain.rec_lo = e->ia_homo.rec_lo = e->ia_plain.rec_hi = e->ia_homo.rec_hi = nullptr;
+                    sd::launch_ident(ts, e->ia_plain);
+                    if (e->ident_mode == 2) sd::launch_ident(ts, e->ia_homo);
+                }
                 SD_HIP(hipEventRecord(e->ev_id1, ts));
             }
-            // the record offsets travel right behind the compaction: the fetch then knows the record
-            // count as soon as the stream is idle, without a second round trip
-            SD_HIP(hipMemcpyAsync(e->h_roff.p, e->d_roff.p, sizeof(int64_t) * ((size_t)C + 1), hipMemcpyDeviceToHost, ts));
-            if (e->family == 2) {   // and the fp16 range guard of the fills (reset for the next run behind the copy)
-                e->h_guard.alloc(1);
-                SD_HIP(hipMemcpyAsync(e->h_guard.p, e->d_guard.p, sizeof(int), hipMemcpyDeviceToHost, ts));
-                SD_HIP(hipMemsetAsync(e->d_guard.p, 0, sizeof(int), ts));
-            }
+            if (!e->sliced_run) copy_offsets();
         }
         SD_HIP(hipEventRecord(e->ev_run1, ts));
         SD_HIP(hipGetLastError());
@@ -1121,15 +1160,17 @@ int sd_engine_run(sd_engine* e, void* hip_stream, char* errbuf, size_t errlen) {
 static std::atomic<long long> g_guard_trips{0};
 extern "C" int64_t sd_guard_trips(void) { return (int64_t)g_guard_trips.load(); }
 
-static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errlen) {
+// First half of a fetch: wait until the DP of the last run is done and its record offsets are on the host (a sliced run:
+// ev_dp, the identity slices may still be running; else the whole run), repeat the batch if a guard tripped, size the
+// host buffer of the records.
+static int fetch_begin(sd_engine* e, int64_t& total, char* errbuf, size_t errlen) {
     total = 0;
     if (!e->ran) { set_err(errbuf, errlen, "sd_engine_fetch before sd_engine_run"); return SD_ERR_PARAM; }
     const size_t C = e->chunks.size();
     try {
         SD_HIP(hipSetDevice(e->device));
-        SD_HIP(hipEventSynchronize(e->ev_run1));
+        SD_HIP(hipEventSynchronize(e->sliced_run ? e->ev_dp : e->ev_run1));
         e->in_pending = false;
-        hipStream_t cs = e->copy_stream ? e->copy_stream : e->last_stream;
         if (C == 0) { e->h_roff.alloc(1); e->h_roff.p[0] = 0; return SD_OK; }
         if (e->family == 2 && e->h_guard.p && e->h_guard.p[0] != 0) {
             // A wave's fp16 cells left the range in which they are exact integers (F16Guard, sd_fast_dev.hpp): the
@@ -1137,6 +1178,7 @@ static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errle
             // the device) is repeated with integer cells, which this engine keeps from now on.
             ++g_guard_trips;
             e->replanned = true;
+            if (e->sliced_run) SD_HIP(hipEventSynchronize(e->ev_run1));   // (the identity slices of the dropped run)
             std::string err2;
             int rc2 = engine_pick_family(e, false, err2);
             if (rc2) { set_err(errbuf, errlen, "fp16 cell range exceeded, and no integer-cell layout: " + err2); return rc2; }
@@ -1154,6 +1196,7 @@ static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errle
         total = e->h_roff.p[C];
         e->ident_valid = e->ident_mode != 0 && total <= e->ident_cap && total <= e->dense_cap;
         if (total > e->dense_cap) {
+            if (e->sliced_run) SD_HIP(hipEventSynchronize(e->ev_run1));
             e->d_dense.alloc((size_t)total);
             e->dense_cap = (int64_t)e->d_dense.cap;
             if (e->ident_mode) e->d_recchunk.alloc((size_t)e->dense_cap);   // a later run of the same load compacts into it
@@ -1162,38 +1205,67 @@ static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errle
             SD_HIP(hipStreamSynchronize(e->last_stream));
         }
         e->h_recs.alloc((size_t)std::max<int64_t>(total, 1));
-        static_assert(sizeof(sd_rec) == sizeof(sd::DevRec), "record layout");
-        if (total > 0) {
-            SD_HIP(hipMemcpyAsync(e->h_recs.p, e->d_dense.p, sizeof(sd_rec) * (size_t)total, hipMemcpyDeviceToHost, cs));
-            if (e->ident_valid) {
-                const size_t per = e->ident_mode == 2 ? (size_t)e->iT : 1;
-                const size_t nb = sizeof(uint32_t) * (size_t)total * per;
-                if (e->h_ident_bytes < nb) {
-                    g_pinpool.give(e->h_ident, e->h_ident_bytes);
-                    e->h_ident = nullptr;
-                    e->h_ident_bytes = 0;   // take() may throw: no stale size beside a null pointer
-                    e->h_ident = static_cast<uint32_t*>(g_pinpool.take(nb, e->h_ident_bytes));
-                }
-                SD_HIP(hipMemcpyAsync(e->h_ident, e->d_ident.p, nb, hipMemcpyDeviceToHost, cs));
-                if (e->ident_mode == 2) {
-                    if (e->h_identh_bytes < nb) {
-                        g_pinpool.give(e->h_identh, e->h_identh_bytes);
-                        e->h_identh = nullptr;
-                        e->h_identh_bytes = 0;
-                        e->h_identh = static_cast<uint32_t*>(g_pinpool.take(nb, e->h_identh_bytes));
-                    }
-                    SD_HIP(hipMemcpyAsync(e->h_identh, e->d_identh.p, nb, hipMemcpyDeviceToHost, cs));
-                }
-            }
-            SD_HIP(hipStreamSynchronize(cs));
-        }
-        if (e->score_scale != 1)
-            for (int64_t x = 0; x < total; ++x) e->h_recs.p[x].score *= e->score_scale;
     } catch (const HipFail& f) {
         set_err(errbuf, errlen, f.msg);
         return SD_ERR_HIP;
     }
     return SD_OK;
+}
+
+// Second half: the records [r_lo, r_hi) into h_recs (at their own indices) and, if the run has them and the caller gives
+// room (pinned, word 0 = record r_lo), their identity words.
+static int fetch_range(sd_engine* e, int64_t r_lo, int64_t r_hi, uint32_t* id_dst, uint32_t* idh_dst, char* errbuf, size_t errlen) {
+    static_assert(sizeof(sd_rec) == sizeof(sd::DevRec), "record layout");
+    const int64_t n = r_hi - r_lo;
+    if (n <= 0) return SD_OK;
+    try {
+        hipStream_t cs = e->copy_stream ? e->copy_stream : e->last_stream;
+        SD_HIP(hipMemcpyAsync(e->h_recs.p + r_lo, e->d_dense.p + r_lo, sizeof(sd_rec) * (size_t)n, hipMemcpyDeviceToHost, cs));
+        if (e->ident_valid && id_dst) {
+            const size_t per = e->ident_mode == 2 ? (size_t)e->iT : 1;
+            const size_t nb = sizeof(uint32_t) * (size_t)n * per;
+            SD_HIP(hipMemcpyAsync(id_dst, e->d_ident.p + (size_t)r_lo * per, nb, hipMemcpyDeviceToHost, cs));
+            if (e->ident_mode == 2 && idh_dst)
+                SD_HIP(hipMemcpyAsync(idh_dst, e->d_identh.p + (size_t)r_lo * per, nb, hipMemcpyDeviceToHost, cs));
+        }
+        SD_HIP(hipStreamSynchronize(cs));
+        if (e->score_scale != 1)
+            for (int64_t x = r_lo; x < r_hi; ++x) e->h_recs.p[x].score *= e->score_scale;
+    } catch (const HipFail& f) {
+        set_err(errbuf, errlen, f.msg);
+        return SD_ERR_HIP;
+    }
+    return SD_OK;
+}
+
+// the engine's own identity blocks, large enough for `total` records (throws HipFail)
+static void engine_grow_ident(sd_engine* e, int64_t total) {
+    if (!e->ident_valid || total <= 0) return;
+    const size_t nb = sizeof(uint32_t) * (size_t)total * (e->ident_mode == 2 ? (size_t)e->iT : 1);
+    auto grow = [&](uint32_t** p, size_t* have) {
+        if (*have >= nb) return;
+        g_pinpool.give(*p, *have);
+        *p = nullptr;
+        *have = 0;   // take() may throw: no stale size beside a null pointer
+        *p = static_cast<uint32_t*>(g_pinpool.take(nb, *have));
+    };
+    grow(&e->h_ident, &e->h_ident_bytes);
+    if (e->ident_mode == 2) grow(&e->h_identh, &e->h_identh_bytes);
+}
+
+// Waits for the last run and brings its compact records (and identities) into the pinned buffers h_roff / h_recs /
+// h_ident (valid until the next load / run of this engine).
+static int fetch_pinned(sd_engine* e, int64_t& total, char* errbuf, size_t errlen) {
+    int rc = fetch_begin(e, total, errbuf, errlen);
+    if (rc || e->chunks.empty()) return rc;
+    if (e->sliced_run && hipEventSynchronize(e->ev_run1) != hipSuccess) { set_err(errbuf, errlen, "device run failed"); return SD_ERR_HIP; }
+    try {
+        engine_grow_ident(e, total);
+    } catch (const HipFail& f) {
+        set_err(errbuf, errlen, f.msg);
+        return SD_ERR_HIP;
+    }
+    return fetch_range(e, 0, total, e->h_ident, e->h_identh, errbuf, errlen);
 }
 
 int sd_engine_fetch(sd_engine* e, sd_rec** recs, int64_t** rec_off, char* errbuf, size_t errlen) {
@@ -1323,7 +1395,9 @@ struct TemplateSet {
 // memory and hands them to that batch's sink.  While the device works on batch b the host packs and
 // enqueues b+1 and then assembles b; kernels of consecutive batches sit on different streams, so the
 // tail of one launch overlaps the head of the next.
-using RecSink = std::function<void(const sd_rec*, const int64_t*, size_t)>;  // recs, rec_off (n+1), n chunks
+// recs of the chunks [first, first + n) of a batch (word 0 = the first record of chunk `first`), their offsets (n + 1,
+// relative to recs); a batch arrives in one call (first = 0) or, with identity slices, in one call per slice
+using RecSink = std::function<void(const sd_rec*, const int64_t*, size_t, size_t)>;
 namespace {
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -1345,8 +1419,12 @@ struct Pipeline {
     // identities that came with the batch a sink is being called for (in-stream, sd_ident.hip); id == nullptr: none
     // a sink may TAKE the blocks (take_ident: they are then its to give back to g_pinpool): the engine fetches its
     // next batch into other blocks
-    struct IdentOut { uint32_t* id = nullptr; uint32_t* idh = nullptr; int per = 0; size_t id_bytes = 0, idh_bytes = 0; } cur_ident;
-    sd_engine* cur_engine = nullptr;
+    // own_*: set when id / idh point INTO shared blocks (identity slices): the holder just drops the references
+    struct IdentOut {
+        uint32_t* id = nullptr; uint32_t* idh = nullptr; int per = 0; size_t id_bytes = 0, idh_bytes = 0;
+        std::shared_ptr<void> own_id, own_idh;
+    } cur_ident;
+    sd_engine* cur_engine = nullptr;   // the engine whose own blocks cur_ident shows (null: blocks of a slice, owned by pop_fetch)
     IdentOut take_ident() {
         IdentOut o = cur_ident;
         if (cur_engine && o.id) {
@@ -1445,7 +1523,9 @@ struct Pipeline {
         if (mode == 2 && fill_st && hipStreamCreateWithPriority(&fill_st2, hipStreamNonBlocking, prio ? hi : 0) != hipSuccess)
             fill_st2 = nullptr;
     }
-    int push(const std::vector<const char*>& cptr, const std::vector<int32_t>& clen, RecSink sink) {
+    // slice_end (may be empty): chunk indices at which the batch's identities are cut into slices (sd_engine::slice_end)
+    int push(const std::vector<const char*>& cptr, const std::vector<int32_t>& clen, RecSink sink,
+             const std::vector<int>& slice_end = std::vector<int>()) {
         int rc = SD_OK;
         // All slots busy: the oldest batch has to leave its engine first.  Only its device work and the copy of its
         // records are waited for here; its sink (per-read assembly, text) runs AFTER the new batch is packed and
@@ -1457,6 +1537,9 @@ struct Pipeline {
         if (inflight() == NS) { rc = pop_fetch(); deferred = rc == SD_OK; }
         if (rc) return rc;
         struct RunSink { Pipeline* p; bool on; ~RunSink() { if (on) p->pop_sink(); } } run_sink{this, deferred};
+        // nothing in flight: start over at slot 0 -- a job of ONE batch then always meets the engine that already holds
+        // buffers of its size (alternating slots made every second single-batch job allocate 17 GB anew: 0.5 s)
+        if (inflight() == 0 && sink_slot < 0) pushed = popped = 0;
         const int k = (int)(pushed % NS);
         if (!eng[k]) {
             rc = sd_engine_create(&eng[k], &p, mseq.data(), mlen.data(), (int32_t)mseq.size(), eb, sizeof eb);
@@ -1469,6 +1552,7 @@ struct Pipeline {
         rc = load_chunks_impl(eng[k], cptr, clen, copy_st[k] ? copy_st[k] : fill_st, eb, sizeof eb);
         hipStream_t fs = (fill_st2 && (pushed & 1)) ? fill_st2 : fill_st;
         eng[k]->lds_gate = fill_st2 != nullptr;
+        eng[k]->slice_end = slice_end;
         if (rc == SD_OK) rc = engine_run2(eng[k], fs, trace_st ? trace_st : fs, eb, sizeof eb);
         pack_s += now_s() - t0;
         if (rc) return rc;
@@ -1485,32 +1569,98 @@ struct Pipeline {
     RecSink sink_fn;             // ... its sink, its record offsets (a copy: the engine's pinned array is the target of the
     std::vector<int64_t> sink_roff;   // next run's copy) and its chunk count
     size_t sink_chunks = 0;
-    // first half of pop(): wait for the oldest batch, copy its records to the host, book its times
+    // first half of pop(): wait for the oldest batch, copy its records to the host, book its times.  A batch whose
+    // identities run in slices is handed to its sink here, slice by slice, as the slices complete on the device.
     int pop_fetch() {
         if (sink_slot >= 0) pop_sink();
         if (inflight() == 0) return SD_OK;
         const int k = (int)(popped % NS);
+        sd_engine* e = eng[k];
         int64_t total = 0;
         double t0 = now_s();
-        int rc = fetch_pinned(eng[k], total, eb, sizeof eb);
+        int rc = fetch_begin(e, total, eb, sizeof eb);
+        const bool sliced = rc == SD_OK && e->sliced_run && e->ident_valid && !e->chunks.empty();
+        if (rc == SD_OK && !sliced && !e->chunks.empty()) {
+            if (e->sliced_run && hipEventSynchronize(e->ev_run1) != hipSuccess) { std::snprintf(eb, sizeof eb, "device run failed"); rc = SD_ERR_HIP; }
+            if (rc == SD_OK) {
+                try {
+                    engine_grow_ident(e, total);
+                } catch (const HipFail& f) {
+                    std::snprintf(eb, sizeof eb, "%s", f.msg.c_str());
+                    rc = SD_ERR_HIP;
+                }
+            }
+            if (rc == SD_OK) rc = fetch_range(e, 0, total, e->h_ident, e->h_identh, eb, sizeof eb);
+        }
         wait_s += now_s() - t0;
         ++popped;
         if (rc) { sinks[k] = nullptr; return rc; }
-        float ms[4];
-        if (sd_engine_timings(eng[k], ms) == SD_OK) { fill_ms += ms[0]; trace_ms += ms[1]; compact_ms += ms[2]; run_ms += ms[3]; }
-        if (eng[k]->ident_mode && !eng[k]->chunks.empty()) {
-            float im = 0.f;
-            if (hipEventElapsedTime(&im, eng[k]->ev_id0, eng[k]->ev_id1) == hipSuccess) ident_ms += im;
-            if (eng[k]->ident_valid) ident_pairs += total * (eng[k]->ident_mode == 2 ? 2 * (int64_t)eng[k]->iT : 1);
-        }
-        launches += eng[k]->fill_launches;
+        launches += e->fill_launches;
         ++batches;
-        rows += eng[k]->rows;
+        rows += e->rows;
+        if (sliced) {
+            RecSink fn = std::move(sinks[k]);
+            sinks[k] = nullptr;
+            // The identity words of the whole batch land in ONE pair of pinned blocks, slice by slice; every slice's sink
+            // gets a reference (IdentOut::own_*) and the blocks go back to the pool when the last one lets go (a block per
+            // slice meant 16 hipHostMalloc / hipHostFree of 19 MB per job: 100 ms).
+            const size_t per = e->ident_mode == 2 ? (size_t)e->iT : 1;
+            const size_t nb = sizeof(uint32_t) * (size_t)std::max<int64_t>(total, 1) * per;
+            std::shared_ptr<void> own_id, own_idh;
+            try {
+                size_t got = 0;
+                void* q = g_pinpool.take(nb, got);
+                own_id.reset(q, [got](void* x) { g_pinpool.give(x, got); });
+                if (e->ident_mode == 2) {
+                    q = g_pinpool.take(nb, got);
+                    own_idh.reset(q, [got](void* x) { g_pinpool.give(x, got); });
+                }
+            } catch (const HipFail& f) {
+                std::snprintf(eb, sizeof eb, "%s", f.msg.c_str());
+                rc = SD_ERR_HIP;
+            }
+            int c_lo = 0;
+            std::vector<int64_t> ro;
+            for (size_t sl = 0; sl < e->slice_end.size() && rc == SD_OK; ++sl) {
+                const int c_hi = e->slice_end[sl];
+                const int64_t r_lo = e->h_roff.p[c_lo], r_hi = e->h_roff.p[c_hi];
+                t0 = now_s();
+                uint32_t* idp = static_cast<uint32_t*>(own_id.get()) + (size_t)r_lo * per;
+                uint32_t* idhp = own_idh ? static_cast<uint32_t*>(own_idh.get()) + (size_t)r_lo * per : nullptr;
+                if (hipEventSynchronize(e->ev_slice[sl]) != hipSuccess) { std::snprintf(eb, sizeof eb, "device run failed"); rc = SD_ERR_HIP; }
+                if (rc == SD_OK) rc = fetch_range(e, r_lo, r_hi, idp, idhp, eb, sizeof eb);
+                wait_s += now_s() - t0;
+                if (rc == SD_OK) {
+                    t0 = now_s();
+                    ro.resize((size_t)(c_hi - c_lo) + 1);
+                    for (int c = c_lo; c <= c_hi; ++c) ro[(size_t)(c - c_lo)] = e->h_roff.p[c] - r_lo;
+                    cur_engine = nullptr;
+                    cur_ident = IdentOut{};
+                    if (r_hi > r_lo) {
+                        cur_ident.id = idp; cur_ident.idh = idhp; cur_ident.per = (int)per;
+                        cur_ident.own_id = own_id; cur_ident.own_idh = own_idh;
+                    }
+                    if (fn) fn(e->h_recs.p + r_lo, ro.data(), (size_t)c_lo, (size_t)(c_hi - c_lo));
+                    cur_ident = IdentOut{};
+                    sink_s += now_s() - t0;
+                }
+                c_lo = c_hi;
+            }
+            (void)hipEventSynchronize(e->ev_run1);
+        }
+        float ms[4];
+        if (sd_engine_timings(e, ms) == SD_OK) { fill_ms += ms[0]; trace_ms += ms[1]; compact_ms += ms[2]; run_ms += ms[3]; }
+        if (e->ident_mode && !e->chunks.empty()) {
+            float im = 0.f;
+            if (hipEventElapsedTime(&im, e->ev_id0, e->ev_id1) == hipSuccess) ident_ms += im;
+            if (e->ident_valid) ident_pairs += total * (e->ident_mode == 2 ? 2 * (int64_t)e->iT : 1);
+        }
+        if (sliced) return rc;
         sink_slot = k;
         sink_fn = std::move(sinks[k]);
         sinks[k] = nullptr;
-        sink_chunks = eng[k]->chunks.size();
-        sink_roff.assign(eng[k]->h_roff.p, eng[k]->h_roff.p + sink_chunks + 1);
+        sink_chunks = e->chunks.size();
+        sink_roff.assign(e->h_roff.p, e->h_roff.p + sink_chunks + 1);
         return SD_OK;
     }
     // second half: hand the fetched records to the batch's sink
@@ -1522,10 +1672,14 @@ struct Pipeline {
         cur_ident = IdentOut{};
         cur_engine = eng[k];
         if (eng[k]->ident_valid)
-            cur_ident = IdentOut{eng[k]->h_ident, eng[k]->ident_mode == 2 ? eng[k]->h_identh : nullptr,
-                                 eng[k]->ident_mode == 2 ? eng[k]->iT : 1, eng[k]->h_ident_bytes,
-                                 eng[k]->ident_mode == 2 ? eng[k]->h_identh_bytes : 0};
-        if (sink_fn) sink_fn(eng[k]->h_recs.p, sink_roff.data(), sink_chunks);
+        {
+            cur_ident.id = eng[k]->h_ident;
+            cur_ident.idh = eng[k]->ident_mode == 2 ? eng[k]->h_identh : nullptr;
+            cur_ident.per = eng[k]->ident_mode == 2 ? eng[k]->iT : 1;
+            cur_ident.id_bytes = eng[k]->h_ident_bytes;
+            cur_ident.idh_bytes = eng[k]->ident_mode == 2 ? eng[k]->h_identh_bytes : 0;
+        }
+        if (sink_fn) sink_fn(eng[k]->h_recs.p, sink_roff.data(), 0, sink_chunks);
         sink_fn = nullptr;
         cur_ident = IdentOut{};
         cur_engine = nullptr;
@@ -1672,7 +1826,7 @@ static int run_chunk_batches(const std::vector<ReadView>& reads, const std::vect
             cptr.push_back(reads[(size_t)table[c].read].seq + table[c].off);
             clen.push_back(table[c].len);
         }
-        rc = pipe.push(cptr, clen, [&sink, c0, c1](const sd_rec* r, const int64_t* ro, size_t) { sink(c0, c1, r, ro); });
+        rc = pipe.push(cptr, clen, [&sink, c0](const sd_rec* r, const int64_t* ro, size_t first, size_t n) { sink(c0 + first, c0 + first + n, r, ro); });
     }
     std::string busy_err;
     const double t_busy0 = now_s();
@@ -1971,7 +2125,8 @@ int sd_records_to_raw_tsv(const char* records_path, const char* raw_tsv_out, int
 // -------------------------------------------------------------------------------------------
 // chunk-range form: multi-GPU sharding of one job, one process per GPU
 // -------------------------------------------------------------------------------------------
-void sd_release_cache(void) { pipe_cache_clear(); g_pool.release_all(); g_pinpool.release_all(); }
+static void text_pool_clear();
+void sd_release_cache(void) { pipe_cache_clear(); g_pool.release_all(); g_pinpool.release_all(); text_pool_clear(); }
 
 int64_t sd_chunk_table_size(const int64_t* read_lens, int32_t n_reads, int32_t part_size, int32_t overlap) {
     if (!read_lens || n_reads < 0 || part_size <= 0 || overlap < 0) return -1;
@@ -2428,9 +2583,9 @@ int sd_stream_submit(sd_stream* s, const char* const* read_seqs, const int64_t* 
             cptr.push_back(read_seqs[jp->table[c].read] + jp->table[c].off);
             clen.push_back(jp->table[c].len);
         }
-        rc = s->pipe.push(cptr, clen, [jp, c0, c1](const sd_rec* r, const int64_t* ro, size_t) {
-            jp->add(c0, c1, r, ro);
-            --jp->batches_left;
+        rc = s->pipe.push(cptr, clen, [jp, c0, c1](const sd_rec* r, const int64_t* ro, size_t first, size_t n) {
+            jp->add(c0 + first, c0 + first + n, r, ro);
+            if (c0 + first + n == c1) --jp->batches_left;
         });
     }
     if (rc) {
@@ -2578,7 +2733,9 @@ int sd_write_parts_selftest(const char* path, int32_t n_parts, int64_t part_byte
     if (fd < 0) return SD_ERR_IO;
     sd::write_parts_hook().store(fail_reserve ? 1 : 0);
     int64_t off = 0;
+    const double t_w0 = now_s();
     bool ok = sd::write_parts(fd, off, parts, threads) && sd::write_parts(fd, off, parts, threads);
+    if (getenv("SD_TIMING")) std::fprintf(stderr, "[sd timing] write_parts: %lld bytes in %.2f ms\n", (long long)off, (now_s() - t_w0) * 1e3);
     sd::write_parts_hook().store(0);
     struct statfs fs;
     const bool ram = ::fstatfs(fd, &fs) == 0 && ((unsigned long)fs.f_type == 0x01021994ul || (unsigned long)fs.f_type == 0x858458f6ul);
@@ -2609,6 +2766,33 @@ int sd_write_parts_selftest(const char* path, int32_t n_parts, int64_t part_byte
 // stage times of the last sd_run_files / sd_run_files_range call of this process (sd_last_run_stats)
 static std::mutex g_last_m;
 static double g_last_run[24] = {0};
+
+// The three texts of one hand-over of sd_run_files (raw / final / _alt parts), and the process-wide pool their buffers
+// return to (at most four; sd_release_cache() frees them).  Never destroyed at exit (as the other pools).
+struct TextJob { std::vector<std::string> raw, fin; std::vector<sd::TextBuf> alt; };
+struct TextPool {
+    std::mutex m;
+    std::deque<TextJob> free_;
+    TextJob take() {
+        std::lock_guard<std::mutex> g(m);
+        TextJob j;
+        if (!free_.empty()) { j = std::move(free_.front()); free_.pop_front(); }
+        return j;
+    }
+    void give(TextJob&& j) {
+        TextJob drop;   // freed outside the lock
+        std::lock_guard<std::mutex> g(m);
+        if (free_.size() < 4) free_.push_back(std::move(j)); else drop = std::move(j);
+    }
+    void clear() {
+        std::deque<TextJob> drop;
+        std::lock_guard<std::mutex> g(m);
+        drop.swap(free_);
+    }
+};
+static TextPool& g_textpool_ref() { static TextPool* p = new TextPool; return *p; }
+#define g_textpool g_textpool_ref()
+static void text_pool_clear() { g_textpool.clear(); }
 
 static int run_files_impl(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank, int32_t world,
                           const char* raw_tsv_out, const char* final_tsv_out, const char* alt_tsv_out,
@@ -2753,10 +2937,14 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     lap(reused ? "pipeline from the cache" : "engine (HIP runtime start, layout plan, tables, identity masks)");
     if (stream_ident) job.per = second_best ? (int)pp.interleaved_seqs().size() : 1;
     std::vector<std::pair<size_t, size_t>> batches;
-    // --second-best makes the host side of a batch (2T identities' worth of text per row) as long as its kernels: a job
-    // that fits ONE batch is cut in up to four, so that the text of a part is written while the next is on the device
+    // --second-best makes the host side of a batch (2T identities' worth of text per row) as long as its kernels.  Round 3
+    // cut a job that fits ONE batch in up to four, so that the text of a part is written while the next is on the
+    // device -- four under-filled fill launches (C4: 47.6 instead of 22.6 ms of fill).  Now the DP of a batch is one
+    // launch and its IDENTITIES run in slices of whole reads (sd_engine::slice_end): the host fetches, assembles and
+    // formats slice s while the device computes slice s + 1.
     int min_batches = 1;
-    if (second_best && rc == SD_OK) {
+    const bool slice_ident = second_best && rc == SD_OK && !getenv("SD_IDENT_SLICES_OFF");
+    if (second_best && rc == SD_OK && !slice_ident) {
         const size_t nc = job.table.size();
         min_batches = nc >= 2048 ? 4 : nc >= 1024 ? 2 : 1;   // C4 shape, 2 560 chunks: 170 / 159 / 149 / 140 / 134+ ms for 1 / 2 / 3 / 4 / 5+
     }
@@ -2764,7 +2952,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     // it hands it out -- the 17 GB a 50-Mbp job takes as ONE batch cost 0.2-1.2 s, more than the job (0.3 s).  Such a
     // job is cut into eight batches (two run side by side, stream mode 2), so that its buffers are an eighth as large;
     // a pipeline that comes from the cache has its buffers, and a job of many batches allocates full-size ones once.
-    if (!reused && rc == SD_OK) {
+    if (!reused && rc == SD_OK && !slice_ident) {
         const size_t nc = job.table.size();
         min_batches = std::max(min_batches, nc >= 4096 ? 8 : nc >= 1024 ? 4 : 1);
     }
@@ -2793,10 +2981,39 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         if (sink_rc.load() == SD_OK) { sink_err = msg; sink_rc.store(code); }
     };
     double t_fmt = 0, t_post = 0, t_io = 0;
+    // The text of a hand-over goes to a third thread that copies it into the files (the page-cache copy of a --second-best
+    // job's _alt rows -- 280 MB at C4 -- takes twice as long as formatting them): formatting hand-over s + 1 and writing
+    // hand-over s run side by side.  Text buffers circulate between the two threads (a fresh 35-MB vector is page faults).
+    // Text buffers circulate between the two threads and stay with the process between jobs (g_textpool: a fresh 35-MB
+    // vector is page faults, and giving 300 MB back to the kernel at the end of every job was 16 ms).
+    using WriteJob = TextJob;
+    std::mutex io_m;
+    std::condition_variable io_cv;
+    std::deque<WriteJob> io_q;
+    bool io_done = false;
+    auto io_loop = [&]() {
+        sd::HostPool::lane() = 2;
+        for (;;) {
+            WriteJob j;
+            {
+                std::unique_lock<std::mutex> lk(io_m);
+                io_cv.wait(lk, [&] { return io_done || !io_q.empty(); });
+                if (io_q.empty()) return;
+                j = std::move(io_q.front());
+                io_q.pop_front();
+            }
+            io_cv.notify_all();
+            const double t0 = now_s();
+            if (sink_rc.load() == SD_OK &&
+                (!sd::write_parts(fr, off_r, j.raw, p->threads) || !sd::write_parts(ff, off_f, j.fin, p->threads) ||
+                 !sd::write_parts(fa, off_a, j.alt, p->threads)))
+                sink_fail(SD_ERR_IO, std::string("short write to ") + raw_tsv_out);
+            t_io += now_s() - t0;
+            g_textpool.give(std::move(j));
+        }
+    };
     auto sink_loop = [&]() {
         sd::HostPool::lane() = 1;   // this thread's parallel loops run on the second pool, beside the driver's
-        std::vector<std::string> fin_parts;
-        std::vector<sd::TextBuf> alt_parts;
         std::vector<sd::PostRead> preads;
         for (;;) {
             Work w;
@@ -2829,7 +3046,12 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
                 for (size_t r = w.r0; r < w.r1; ++r)
                     for (int64_t a = off[r - w.r0]; a < off[r - w.r0 + 1]; a += 32768)
                         slices.push_back(Slice{r, a, std::min<int64_t>(off[r - w.r0 + 1], a + 32768)});
-                std::vector<std::string> parts(slices.size());
+                WriteJob wj = g_textpool.take();
+                std::vector<std::string>& parts = wj.raw;
+                std::vector<std::string>& fin_parts = wj.fin;
+                std::vector<sd::TextBuf>& alt_parts = wj.alt;
+                parts.resize(slices.size());
+                for (std::string& q : parts) q.clear();
                 sd::parallel_for((int64_t)slices.size(), p->threads, 1, [&](int64_t x) {
                     const Slice& sl = slices[(size_t)x];
                     sd::format_rows(parts[(size_t)x], reads[sl.r].name, reads[sl.r].name_len, ts.tnames, w.rows + sl.a,
@@ -2850,22 +3072,26 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
                 const int r2 = pp.process_parts(preads.data(), preads.size(), w.rows, off, fin_parts, alt_parts, e2,
                                                 w.have_ident ? &iref : nullptr);
                 t_post += now_s() - t0;
-                t0 = now_s();
                 if (r2) {
                     sink_fail(r2, e2);
-                } else if (!sd::write_parts(fr, off_r, parts, p->threads) || !sd::write_parts(ff, off_f, fin_parts, p->threads) ||
-                           !sd::write_parts(fa, off_a, alt_parts, p->threads)) {
-                    sink_fail(SD_ERR_IO, std::string("short write to ") + raw_tsv_out);
+                } else {
+                    std::unique_lock<std::mutex> lk(io_m);
+                    io_cv.wait(lk, [&] { return io_q.size() < 2; });
+                    io_q.push_back(std::move(wj));
+                    lk.unlock();
+                    io_cv.notify_all();
                 }
-                t_io += now_s() - t0;
             }
             std::free(w.rows);
             std::free(w.src);
-            g_pinpool.give(w.ident.id, w.ident.id_bytes);
-            g_pinpool.give(w.ident.idh, w.ident.idh_bytes);
+            if (!w.ident.own_id) {   // (blocks of a slice go back when the last slice lets go of them)
+                g_pinpool.give(w.ident.id, w.ident.id_bytes);
+                g_pinpool.give(w.ident.idh, w.ident.idh_bytes);
+            }
         }
     };
     std::thread sink_thread(sink_loop);
+    std::thread io_thread(io_loop);
     auto sink = [&](size_t c0, size_t c1, const sd_rec* recs, const int64_t* roff) {
         if (sink_rc.load()) return;
         const size_t r0 = job.next_read;
@@ -2913,7 +3139,24 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
             cptr.push_back(reads[(size_t)job.table[c].read].seq + job.table[c].off);
             clen.push_back(job.table[c].len);
         }
-        rc = pipe.push(cptr, clen, [&sink, c0, c1](const sd_rec* r, const int64_t* ro, size_t) { sink(c0, c1, r, ro); });
+        std::vector<int> slice_end;
+        if (slice_ident && stream_ident) {
+            // up to eight slices of at least 256 chunks, each ending with a read (a read that ends in a later slice would
+            // only be carried; the last slice ends the batch)
+            const size_t nb = c1 - c0;
+            int n_sl = (int)std::max<size_t>(1, std::min<size_t>(8, nb / 256));
+            if (const char* ev = getenv("SD_IDENT_SLICES")) n_sl = std::max(1, std::min(64, atoi(ev)));   // developer A/B
+            size_t at = 0;
+            for (int sl = 0; sl < n_sl && at < nb; ++sl) {
+                size_t want = sl + 1 == n_sl ? nb : std::max(at + 1, nb * (size_t)(sl + 1) / (size_t)n_sl);
+                while (want < nb && job.table[c0 + want].read == job.table[c0 + want - 1].read) ++want;
+                slice_end.push_back((int)want);
+                at = want;
+            }
+            if (slice_end.empty() || slice_end.back() != (int)nb) slice_end.push_back((int)nb);
+        }
+        rc = pipe.push(cptr, clen, [&sink, c0](const sd_rec* r, const int64_t* ro, size_t first, size_t n) { sink(c0 + first, c0 + first + n, r, ro); },
+                       slice_end);
         if (rc) err = pipe.eb;
     }
     const int rc2 = pipe.drain();
@@ -2924,6 +3167,12 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     }
     wq_cv.notify_all();
     sink_thread.join();
+    {
+        std::lock_guard<std::mutex> lk(io_m);
+        io_done = true;
+    }
+    io_cv.notify_all();
+    io_thread.join();
     if (rc == SD_OK && sink_rc.load()) { rc = sink_rc.load(); err = sink_err; }
     if (!close_all() && rc == SD_OK) { rc = SD_ERR_IO; err = std::string("short write to ") + raw_tsv_out; }
     if (records_out && rc == SD_OK) rc = rec_w.close(err, records_out);

@@ -7,6 +7,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <condition_variable>
@@ -299,8 +300,8 @@ class HostPool {
     // the two took turns -- "one loop at a time" -- and each waited for the other's loops.
     static int& lane() { static thread_local int l = 0; return l; }
     static HostPool& get() {
-        static HostPool* p[2] = {new HostPool, new HostPool};  // never destroyed: workers may outlive static destructors
-        return *p[lane() & 1];
+        static HostPool* p[3] = {new HostPool, new HostPool, new HostPool};  // never destroyed: workers may outlive static destructors
+        return *p[(unsigned)lane() % 3u];   // lane 2: the file writer of sd_run_files
     }
     // runs `work()` on the calling thread and on up to helpers pool threads; returns when all are back
     template <class F>
@@ -420,12 +421,15 @@ inline bool write_parts(int fd, int64_t& off, const std::vector<Part>& parts, in
     // sparse tmpfs mapping that the file system cannot back (full or small /dev/shm) raises SIGBUS and kills the
     // process, where the pwritev loop below reports the same condition as a short write (-> SD_ERR_IO).
     // sd_write_parts_test_hook() != 0 makes fallocate "fail" (CPU test of the fall-back).
-    if (ram && total >= (4 << 20) && write_parts_fallocate_ok() &&
+    static const int wmode = [] { const char* e = getenv("SD_WRITE_PATH"); return e ? atoi(e) : 0; }();   // developer A/B: 1 = pwritev only
+    if (ram && wmode != 1 && total >= (4 << 20) && write_parts_fallocate_ok() &&
         ::fallocate(fd, 0, (off_t)off, (off_t)total) == 0) {
         // pages allocated in one call: the copies below then take minor faults only (300 MB on the GPU box: 52-63 ms
         // against 83-104 ms with every page allocated by the fault of a copying thread; tools/scratch/tmpfs_write.cpp)
         const long pg = ::sysconf(_SC_PAGESIZE);
         const int64_t m0 = off / pg * pg;
+        // (MAP_POPULATE -- the page tables filled by one call instead of a minor fault per page in the copying threads --
+        // was measured at C4: 66-69 ms of writes per 280 MB against 36-37: the populate is single-threaded)
         void* mp = ::mmap(nullptr, (size_t)(off + total - m0), PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)m0);
         if (mp != MAP_FAILED) {
             char* base = static_cast<char*>(mp) - m0;   // base + file offset

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256, 3) void sd_ident_pairs(IdentArgs a, int use_li
     // not fit -- and must not be touched.
     const int64_t n_tot = *a.total;
     if (n_tot > a.rec_cap || n_tot > a.dense_cap) return;
-    const int64_t n_all = n_tot;
+    const int64_t r_lo = a.rec_lo ? *a.rec_lo : 0;
+    const int64_t n_all = (a.rec_hi ? *a.rec_hi : n_tot) - r_lo;
     const int64_t n_rec = use_list ? (int64_t)min(*a.long_cnt, (int)min(a.rec_cap, (int64_t)0x7fffffff)) : n_all;
     const int64_t n_pairs = n_rec * a.T;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256, 3) void sd_ident_pairs(IdentArgs a, int use_li
     for (int64_t p = gid; p < n_pairs; p += stride) {
         const int64_t xl = p / a.T;
         const int tq = (int)(p - xl * a.T);
-        const int64_t x = use_list ? (int64_t)a.long_list[xl] : xl;
+        const int64_t x = use_list ? (int64_t)a.long_list[xl] : r_lo + xl;
         const DevRec rec = a.dense[x];
         const int t = a.own ? a.own[rec.tmpl] : tq;
         const int ql = rec.end - rec.start + 1;

@@ -17,6 +17,8 @@ struct IdentArgs {
     const DevRec* dense;            // compact records (chunk-local coordinates)
     const int32_t* rec_chunk;       // chunk of every compact record
     const int64_t* total;           // device: number of compact records (roff[C])
+    const int64_t* rec_lo = nullptr;   // device (may be null = 0 / *total): this launch covers the records [*rec_lo, *rec_hi) --
+    const int64_t* rec_hi = nullptr;   // the records of a range of chunks (entries of the batch's record offsets)
     int64_t rec_cap;                // records the outputs have room for
     int64_t dense_cap;              // records the compaction had room for (beyond it `dense` is not written)
     int T;                          // templates per record: 1 (own template, `own` maps the DP's template index) or all

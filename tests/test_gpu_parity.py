@@ -1004,25 +1004,36 @@ def test_in_stream_identities_equal_the_text_based_path_across_batches(tmp_path,
 
 @pytest.mark.gpu
 def test_second_best_job_is_cut_into_device_batches_with_the_same_files(tmp_path, monkeypatch):
-    """A --second-best job that fits one device batch is cut in up to four, so that the text of a part is written while
-    the next part is on the device (run_files_impl); the three files do not depend on the cut."""
+    """A --second-best job that fits one device batch: ONE fill / traceback launch, the identities in slices of whole
+    reads that the host fetches and formats while the next slice is on the device (run_files_impl; round 3 cut the job
+    into four device batches instead, SD_IDENT_SLICES_OFF).  The three files depend neither on the number of slices nor
+    on the number of device batches."""
     mn, ms = synth.make_monomers(12, seed=3)
     rn, rs = synth.make_reads(ms, 230, read_len=50000, seed=4)
     rs[5] = rs[5][:20000] + b"N" * 30 + rs[5][20030:]
+    rs[7] = rs[7][:300]
     rfa, mfa = str(tmp_path / "r.fa"), str(tmp_path / "m.fa")
     synth.write_fasta(rfa, rn, rs, width=80)
     synth.write_fasta(mfa, mn, ms)
     outs = {}
-    for tag, mb in (("default", None), ("one", "1"), ("seven", "7")):
-        if mb is None:
-            monkeypatch.delenv("SD_MIN_BATCHES", raising=False)
-        else:
-            monkeypatch.setenv("SD_MIN_BATCHES", mb)
+    cases = (("default", {}, 1), ("one_slice", {"SD_IDENT_SLICES": "1"}, 1), ("three", {"SD_IDENT_SLICES": "3"}, 1),
+             ("many", {"SD_IDENT_SLICES": "40"}, 1), ("batches", {"SD_IDENT_SLICES_OFF": "1"}, 4),
+             ("seven_batches_sliced", {"SD_MIN_BATCHES": "7"}, 7), ("seven_batches", {"SD_MIN_BATCHES": "7", "SD_IDENT_SLICES_OFF": "1"}, 7))
+    for tag, env, batches in cases:
+        for k in ("SD_MIN_BATCHES", "SD_IDENT_SLICES", "SD_IDENT_SLICES_OFF"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         o = [str(tmp_path / ("%s_%s.tsv" % (tag, x))) for x in ("raw", "final", "alt")]
         lib.run_files(rfa, mfa, o[0], o[1], o[2], second_best=True, threads=8)
-        assert lib.last_run_stats()["batches"] == {"default": 4, "one": 1, "seven": 7}[tag]
+        st = lib.last_run_stats()
+        assert st["batches"] == batches and st["text_identity_ms"] < 0.01   # every identity came from the device
         outs[tag] = [hashlib.sha256(open(x, "rb").read()).hexdigest() for x in o]
-    assert outs["default"] == outs["one"] == outs["seven"]
+    assert len({tuple(v) for v in outs.values()}) == 1
+    # ... and they are the text-based path's files
+    o = [str(tmp_path / ("text_%s.tsv" % x)) for x in ("raw", "final", "alt")]
+    lib.run_files(rfa, mfa, o[0], o[1], o[2], second_best=True, threads=8, flags=lib.FLAG_NO_STREAM_IDENT)
+    assert [hashlib.sha256(open(x, "rb").read()).hexdigest() for x in o] == outs["default"]
 
 
 @pytest.mark.gpu
