@@ -264,7 +264,7 @@ int sd_engine_timings(sd_engine* e, float ms[4]);
  *     of a lane whose diagonal input needs the maximum with the start term (0 = every slot takes it)
  * [6] bytes of HBM workspace allocated [7] bits 0..15: number of fill launches per run; bits 16..: traceback of the
  *     fast family: 1 = one block per step, int32 cells (sd_fast_trace), 2 = two blocks per step, packed 16-bit cells
- *     (sd_fast_trace_pk; narrow layouts with templates <= 248 bp unless SD_FLAG_TRACE_V1) */
+ *     (sd_fast_trace_pk: layouts with one wave per chunk, templates <= 256 bp, unless SD_FLAG_TRACE_V1) */
 int sd_engine_info(sd_engine* e, int64_t info[8]);
 
 /* Host only (no device needed): the layout sd_engine_create would choose for this monomer set and scoring.

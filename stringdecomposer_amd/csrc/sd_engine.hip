@@ -247,7 +247,7 @@ struct sd_engine {
     DevBuf<uint8_t> d_ftcodes;       // base code of template cell (j,k)
     DevBuf<uint32_t> d_ftr2;         // tables of the packed two-block traceback (FastPlan::tr2_tab)
     DevBuf<long long> d_scanws;      // sd_scan_compact: per-range counts and launch stamps (persist between launches)
-    long long scan_epoch = 0;
+    long long scan_epoch = 0, scan_tickets = 0;
     DevBuf<uint32_t> d_fckpt;        // checkpoints
     DevBuf<int32_t> d_fckbase;       // per-checkpoint rebase values
     // --ed_thr prefilter (fast family only)
@@ -1083,12 +1083,13 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
             }
             SD_HIP(hipEventRecord(e->ev_cmp0, ts));
             if (!e->d_scanws.p) {
-                e->d_scanws.alloc(512);
-                SD_HIP(hipMemsetAsync(e->d_scanws.p, 0, 512 * sizeof(long long), ts));
+                e->d_scanws.alloc(520);
+                SD_HIP(hipMemsetAsync(e->d_scanws.p, 0, 520 * sizeof(long long), ts));
+                e->scan_tickets = 0;
             }
             sd::launch_compact(ts, e->dp_chunks, C, e->d_cnt.p, e->d_roff.p, e->d_recs.p,
                                e->d_dense.p, e->dense_cap, true, e->ident_mode ? e->d_recchunk.p : nullptr,
-                               e->d_scanws.p, ++e->scan_epoch);
+                               e->d_scanws.p, ++e->scan_epoch, &e->scan_tickets);
             SD_HIP(hipEventRecord(e->ev_cmp1, ts));
             auto copy_offsets = [&]() {
                 // the record offsets travel right behind the compaction: the fetch then knows the record

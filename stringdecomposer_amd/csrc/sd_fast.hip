@@ -849,7 +849,7 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
                        const uint32_t* ckpt, const int32_t* ckbase, DevRec* recs,
                        int32_t* rec_cnt, int* queue, const int* order, int n_cu, const uint16_t* klist,
                        const uint16_t* kpos, const int32_t* nkept, const uint32_t* tr2_tab, const uint32_t* lane_t) {
-    // the packed two-block form where the plan has it (narrow layout, templates <= 248 bp, 16-bit tagged range)
+    // the packed two-block form where the plan has it (one wave per chunk in the fill, templates <= 256 bp, 16-bit tagged range)
     if (klist == nullptr && launch_fast_trace2(plan, st, chunks, n_chunks, bases2, nmask, lane_consts, tcodes, toff, tlen, sc,
                                                B, ckpt, ckbase, tr2_tab, recs, rec_cnt, queue, order, n_cu))
         return;

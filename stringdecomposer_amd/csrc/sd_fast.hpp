@@ -68,8 +68,8 @@ struct FastPlan {
     std::vector<int32_t> end_vlane;      // virtual lane holding the end of template j
     std::vector<int32_t> end_off;        // (L_j - 1) * del
     // traceback, second form (sd_fast_trace2.hip): packed 16-bit recomputation, two blocks per wave
-    bool tr2_ok = false;                 // the narrow layout, templates <= 248 bp, scores inside the 16-bit tagged range
-    int tr2_qm = 0;                      // ceil(Lmax / 62): registers per lane at the widest level
+    bool tr2_ok = false;                 // one wave per chunk in the fill (narrow layout, wide / tiled layouts of one wave), templates <= 256 bp, scores inside the 16-bit tagged range
+    int tr2_qm = 0;                      // ceil(Lmax / 64): registers per lane at the widest level
     int tr2_xlim = 0;                    // |E' - base| a checkpoint cell may have (run-time check of the range proof)
     int tr2_bound = 0;                   // the proven bound on |E' - base| for this template set and scoring (<= tr2_xlim)
     std::vector<uint32_t> tr2_tab;       // per template and level: table [5][QQ][32] + checkpoint map [QQ][2][32]
@@ -190,8 +190,8 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
                        const uint32_t* ckpt, const int32_t* ckbase, DevRec* recs,
                        int32_t* rec_cnt, int* queue, const int* order, int n_cu,
                        const uint16_t* klist = nullptr, const uint16_t* kpos = nullptr, const int32_t* nkept = nullptr,
-                       const uint32_t* tr2_tab = nullptr,
-                       const uint32_t* lane_t = nullptr);   // compacted tiled chunks: the lane table (kpos = first lanes then)
-                                                            // (FastPlan::filter_only: every chunk is one, or skipped)   // device copy of FastPlan::tr2_tab: the second form where it applies
+                       const uint32_t* tr2_tab = nullptr,   // device copy of FastPlan::tr2_tab: the packed two-block form where it applies
+                       const uint32_t* lane_t = nullptr);   // compacted tiled chunks: the lane table (kpos = first lanes then;
+                                                            // FastPlan::filter_only: every chunk is one, or skipped)
 
 }  // namespace sd

@@ -456,22 +456,28 @@ __global__ void sd_compact(const ChunkDesc* __restrict__ chunks, const int32_t* 
         for (int a = threadIdx.x; a < k; a += blockDim.x) out_chunk[roff[c] + a] = c;
 }
 
-// Offsets and compaction in ONE launch: workgroup b owns a contiguous range of chunks, publishes the record count of its
-// range, adds up the counts of the ranges before it as they appear (every workgroup's first step depends on nothing, and
-// workgroups are dispatched in order, so the wait is for work that is already running), scans its own chunks and copies
-// their records.  `ws`: 2 * SC_NB words that persist between launches -- [b] the count of range b, [SC_NB + b] the launch
-// (`epoch`) it belongs to -- so nothing has to be cleared.  Replaces the one-workgroup sd_scan_counts, which sat behind the
+// Offsets and compaction in ONE launch: a workgroup owns a contiguous range of chunks, publishes the record count of its
+// range, adds up the counts of the ranges before it as they appear, scans its own chunks and copies their records.
+// WHICH range a workgroup owns is decided by a ticket it draws when it starts (ws[2 * SC_NB], a counter that only grows;
+// `ticket0` = its value before this launch), not by blockIdx: a workgroup then only ever waits for workgroups that have
+// started -- on a multi-XCD part workgroups are dealt round-robin to XCDs that dispatch on their own, and this kernel
+// shares the machine with the next batch's persistent fill, so "lower blockIdx runs first" is not a guarantee (rocPRIM's
+// decoupled look-back orders its blocks the same way).  `ws`: words that persist between launches -- [b] the count of
+// range b, [SC_NB + b] the launch (`epoch`) it belongs to -- so nothing has to be cleared.  Replaces the one-workgroup sd_scan_counts, which sat behind the
 // next batch's fill on the lower-priority stream for milliseconds before its 16 us of work (round 3: 4 ms on average).
 constexpr int SC_NB = 256, SC_T = 256;
 __global__ __launch_bounds__(SC_T) void sd_scan_compact(const ChunkDesc* __restrict__ chunks, const int32_t* __restrict__ cnt,
                                                         int n, int64_t* __restrict__ roff, const DevRec* __restrict__ recs,
                                                         DevRec* __restrict__ out, int64_t out_cap,
                                                         int32_t* __restrict__ out_chunk, long long* __restrict__ ws,
-                                                        long long epoch) {
+                                                        long long epoch, long long ticket0) {
     __shared__ long long red[SC_T / 64];
     __shared__ long long run_s;
+    __shared__ int b_s;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+    if (t == 0) b_s = (int)((long long)atomicAdd(reinterpret_cast<unsigned long long*>(ws + 2 * SC_NB), 1ull) - ticket0);
+    __syncthreads();
+    const int nb = (int)gridDim.x, b = b_s;
     const int per = (n + nb - 1) / nb;
     const int c0 = min(n, b * per), c1 = min(n, c0 + per);
     auto block_sum = [&](long long v) {   // valid in every thread
@@ -533,11 +539,12 @@ __global__ __launch_bounds__(SC_T) void sd_scan_compact(const ChunkDesc* __restr
 
 void launch_compact(hipStream_t st, const ChunkDesc* chunks, int n_chunks, const int32_t* cnt,
                     int64_t* roff, const DevRec* recs, DevRec* out, int64_t out_cap, bool scan, int32_t* out_chunk,
-                    long long* scan_ws, long long epoch) {
-    if (scan && scan_ws != nullptr && n_chunks > 0) {
+                    long long* scan_ws, long long epoch, long long* tickets) {
+    if (scan && scan_ws != nullptr && tickets != nullptr && n_chunks > 0) {
         const int nb = std::max(1, std::min(SC_NB, (n_chunks + 31) / 32));
         hipLaunchKernelGGL(sd_scan_compact, dim3(nb), dim3(SC_T), 0, st, chunks, cnt, n_chunks, roff, recs, out, out_cap,
-                           out_chunk, scan_ws, epoch);
+                           out_chunk, scan_ws, epoch, *tickets);
+        *tickets += nb;
         return;
     }
     if (scan) hipLaunchKernelGGL(sd_scan_counts, dim3(1), dim3(1024), 0, st, cnt, n_chunks, roff);

@@ -21,7 +21,8 @@ void launch_generic_trace(int n_sub, hipStream_t st, const ChunkDesc* chunks, in
 void launch_compact(hipStream_t st, const ChunkDesc* chunks, int n_chunks, const int32_t* cnt,
                     int64_t* roff, const DevRec* recs, DevRec* out, int64_t out_cap, bool scan,
                     int32_t* out_chunk = nullptr,
-                    long long* scan_ws = nullptr,   // 512 words that persist between launches: offsets + compaction in one
-                    long long epoch = 0);           // launch (sd_scan_compact); a value no earlier launch on scan_ws has used
+                    long long* scan_ws = nullptr,   // 520 zeroed words that persist between launches: offsets + compaction in
+                    long long epoch = 0,            // one launch (sd_scan_compact); a value no earlier launch on scan_ws has used
+                    long long* tickets = nullptr);  // host: tickets drawn from scan_ws so far (advanced by the launch)
 
 }  // namespace sd

@@ -839,3 +839,14 @@ def test_committed_pmc_profile_belongs_to_these_kernel_sources():
         tj = json.load(f)
     assert tj.get("kernel_sources_sha256") == bench.kernel_source_hashes(), \
         "kernel sources changed: rerun tools/profile_r02.sh + tools/reduce_pmc.py on the GPU box"
+
+
+def test_packed_traceback_applies_up_to_256_bp_templates():
+    """sd_plan_info's public trace_regs: the packed two-block traceback takes templates of up to 64 * 4 = 256 bp
+    (ceil(L / 64) registers per lane); one base more and the one-block int32 form runs (trace_regs == 0)."""
+    import random
+    rnd = random.Random(5)
+    for L, regs in ((255, 4), (256, 4), (257, 0), (128, 2), (129, 3)):
+        ms = ["".join(rnd.choice("ACGT") for _ in range(L)) for _ in range(3)]
+        info = lib.plan_info(ms)
+        assert info["family"] == "fast" and info["trace_regs"] == regs, (L, info)
