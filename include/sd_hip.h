@@ -259,7 +259,8 @@ int sd_engine_timings(sd_engine* e, float ms[4]);
  *     (0 int32, 1 packed int16, 2 packed fp16 [exact small integers], 3 wide: int16 cells / int8 table,
  *      4 wide: fp16 cells / bf8 table, 5 multi-wave wide: fp16 cells / template codes in LDS, > 128 templates,
  *      6 tiled multi-wave: as 5 with a template over several virtual lanes -- templates longer than 224 bp in sets
- *      beyond one wave of the narrow layout)
+ *      beyond one wave of the narrow layout, 7 / 8: as 5 / 6 with int16 cells and int8 table bytes -- scorings beyond
+ *      the fp16 range, or after a tripped fp16 guard)
  * [5] generic: cells-per-thread parameter Q; fast: slots per lane P in bits 0..15, bits 16..: the last slot
  *     of a lane whose diagonal input needs the maximum with the start term (0 = every slot takes it)
  * [6] bytes of HBM workspace allocated [7] bits 0..15: number of fill launches per run; bits 16..: traceback of the

@@ -536,7 +536,7 @@ int sd_plan_info(const sd_params* p, const char* const* mono_seqs, const int32_t
     info[0] = ok ? 2 : 1;                       // kernel family "auto" would take: 2 fast, 1 generic
     if (!ok) { set_err(errbuf, errlen, why); return SD_OK; }
     info[1] = plan.P;
-    info[2] = plan.tiled ? 6 : plan.waves > 1 ? 5 : plan.wide ? (plan.f16 ? 4 : 3) : plan.f16 ? 2 : 1;   // as sd_engine_info [4] >> 8
+    info[2] = plan.tiled ? (plan.f16 ? 6 : 8) : plan.waves > 1 ? (plan.f16 ? 5 : 7) : plan.wide ? (plan.f16 ? 4 : 3) : plan.f16 ? 2 : 1;   // as sd_engine_info [4] >> 8
     info[3] = plan.floor_slots;
     info[4] = plan.waves | ((int64_t)plan.range_bound << 8) | ((int64_t)plan.rebase << 40);
     // narrow layout: cells in the shortest first lane of a template and in the fullest lane (from slot_of)
@@ -827,7 +827,7 @@ static void engine_alloc_batch(sd_engine* e, int64_t nck) {
             e->d_crank.alloc(C * 64 * (size_t)e->fplan.waves);
             // SD_FLAG_NO_EDTHR_COMPACT (SD_EDTHR_COMPACT=0 arrives as that flag through apply_env_overrides):
             // every chunk on the W-wave ranked kernel (A/B, tests)
-            e->compact_edthr = e->fplan.wide && e->fplan.waves > 1 && !(e->p.reserved[1] & SD_FLAG_NO_EDTHR_COMPACT);
+            e->compact_edthr = e->fplan.wide && e->fplan.waves > 1 && e->fplan.f16 && !(e->p.reserved[1] & SD_FLAG_NO_EDTHR_COMPACT);
             if (e->compact_edthr && e->fplan.tiled) e->d_lanet.alloc(C * (size_t)e->fplan.waves * 128);
             if (e->compact_edthr) {
                 e->d_klist.alloc(C * (size_t)e->T + 2);
@@ -1343,7 +1343,7 @@ int sd_engine_info(sd_engine* e, int64_t info[8]) {
     info[1] = e->sumL;
     info[2] = (int64_t)e->chunks.size();
     info[3] = e->rows;
-    info[4] = e->family | ((e->family == 1 ? 0 : e->fplan.tiled ? 6 : e->fplan.waves > 1 ? 5 : e->fplan.wide ? (e->fplan.f16 ? 4 : 3) : e->fplan.f16 ? 2 : 1) << 8);
+    info[4] = e->family | ((e->family == 1 ? 0 : e->fplan.tiled ? (e->fplan.f16 ? 6 : 8) : e->fplan.waves > 1 ? (e->fplan.f16 ? 5 : 7) : e->fplan.wide ? (e->fplan.f16 ? 4 : 3) : e->fplan.f16 ? 2 : 1) << 8);
     info[5] = e->family == 1 ? e->Q : (e->fplan.P | ((int64_t)e->fplan.floor_slots << 16));
     info[6] = (int64_t)e->workspace_bytes();
     info[7] = (e->family == 1 ? (int64_t)e->subs.size() : 1) |

@@ -395,7 +395,9 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
             for (int p : FAST_WIDE_P_LIST)
                 if (p >= Lmax) { P = p; break; }
         if (P != 0) {
-            if ((int64_t)(3 * Lmax + 2 * FAST_REBASE + 4) * maxabs > 8000) { why = "scores too large for the wide layout"; return false; }
+            // (rounds 1-4 also refused (3 Lmax + 2 REBASE + 4) * max|score| > 8000 here, a bound from before the range proof
+            // above: `ub` <= 12 000 covers the wide layouts' stored cells as it covers the narrow ones -- same recurrence, same
+            // stored domain -- and the int8 table values are checked below)
             split = std::min(T, 64);
             if (T > 128) plan.waves = (T + 127) / 128;   // multi-wave wide layout: wave w holds templates [128 w, 128 w + 128)
         } else {
@@ -667,10 +669,12 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         if (W > 1 || plan.tiled) {
             // multi-wave wide layout (sd_fast_wn.hip): LDS holds the template base codes, [wave][G][2 halves][64
             // lanes][4 dwords], bytes as above; code 7 = padding; the two bf8 table bytes travel as kernel arguments
-            if (!plan.f16) { why = plan.tiled ? "the tiled layout needs bf8-exact table values and the fp16 score range"
-                                               : "more than 128 templates need bf8-exact table values and the fp16 score range"; return false; }
-            plan.bf8_match = (uint32_t)mb & 0xffu;
-            plan.bf8_mismatch = (uint32_t)xb & 0xffu;
+            // fp16 cells / bf8 bytes where the set and scoring allow; else int16 cells / int8 bytes (sd_fast_wn_i16.hip, round
+            // 5: 5.5 instead of 4.5 ops per slot -- until then such sets fell to the generic family).  The compacted
+            // --ed_thr forms exist for fp16 cells only: a set that has no layout of its own needs them.
+            if (!plan.f16 && plan.filter_only) { why = "a set beyond eight waves needs bf8-exact table values and the fp16 score range"; return false; }
+            plan.bf8_match = (uint32_t)(plan.f16 ? mb : md) & 0xffu;
+            plan.bf8_mismatch = (uint32_t)(plan.f16 ? xb : xd) & 0xffu;
             plan.table.assign((size_t)W * G * 512, 0x07070707u);
             int64_t sumLw = 0;
             for (const std::string& s : tseq) sumLw += (int64_t)s.size();

@@ -58,7 +58,7 @@ struct FastPlan {
     int range_bound = 0;       // proven bound on |stored cell| between two rebases (fp16 formats need <= 2040)
     bool full_floor = false;   // launch the fills that take the start-term maximum in every slot (SD_FLAG_FULL_FLOOR: A/B, parity test)
     int floor_slots = 0;  // last slot of a lane whose diagonal input needs the max with the start term (see sd_fast_fill)
-    uint32_t bf8_match = 0, bf8_mismatch = 0;   // multi-wave wide layout: bf8 bytes of the two table values
+    uint32_t bf8_match = 0, bf8_mismatch = 0;   // multi-wave wide layout: the two table values as bf8 bytes (f16) or int8 bytes (integer cells)
     std::vector<int32_t> vlane0;         // first virtual lane of template j
     std::vector<uint32_t> table;         // narrow: [5][P4/4][64][4] packed int16 (mm - del - ins), NEG on padding
                                          // wide:   [5][P/16][2][64][4] dwords of int8 {lo,hi} pairs, -128 on padding
@@ -176,6 +176,16 @@ void launch_fast_fill_wn_compact(const FastPlan& plan, hipStream_t st, const Chu
                                  uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order_w, const int* n_ptr,
                                  int n_cu, const uint16_t* klist, const uint8_t* tcodes, const int32_t* toff,
                                  const int32_t* tlen, int wb);   // wb: waves per chunk of this class
+
+// the same two layouts with int16 cells / int8 table bytes (sd_fast_wn_i16.hip): plan.f16 == false
+bool launch_fast_fill_wn_i16(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks, int n_chunks,
+                             const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table, const uint32_t* lane_consts,
+                             ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order,
+                             const uint32_t* cendoff, const uint32_t* crank, const int* n_ptr);
+bool launch_fast_fill_wt_i16(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks, int n_chunks,
+                             const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table, const uint32_t* lane_consts,
+                             ScoreArgs sc, int32_t* B, uint32_t* ckpt, int32_t* ckbase, int* queue, const int* order,
+                             const uint32_t* cendoff, const uint32_t* crank, const int* n_ptr);
 
 bool launch_fast_fill_wn_fl(const FastPlan& plan, hipStream_t st, int grid, size_t lds, const ChunkDesc* chunks,
                             int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,

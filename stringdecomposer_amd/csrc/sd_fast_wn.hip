@@ -31,6 +31,11 @@ void launch_fast_fill_wn(const FastPlan& plan, hipStream_t st, const ChunkDesc* 
     const int grid = std::min(n_chunks, per_cu * n_cu);
     const size_t lds = ((size_t)W * (plan.P / 16) * 512 + 64) * sizeof(uint32_t);
     const bool ranked = cendoff != nullptr;
+    if (!plan.f16) {   // integer cells (sd_fast_wn_i16.hip)
+        (void)launch_fast_fill_wn_i16(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt, ckbase,
+                                      queue, order, cendoff, crank, n_ptr);
+        return;
+    }
     if (!plan.full_floor &&
         launch_fast_fill_wn_fl(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt,
                                ckbase, queue, order, cendoff, crank, n_ptr))

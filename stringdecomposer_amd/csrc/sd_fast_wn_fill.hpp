@@ -19,8 +19,27 @@ __device__ __forceinline__ uint32_t cvt_bf8_pair(uint32_t tb, int pair, uint32_t
     else asm("v_cvt_scalef32_pk_f16_bf8 %0, %1, %2 op_sel:[1,0,0]" : "=v"(v) : "v"(tb), "s"(one_s));
     return v;
 }
+// integer cells: the table byte pair of a slot is int8; two SDWA adds sign-extend the bytes onto the 16-bit halves (the sums
+// never start from the -32768 padding value: u is at least the row's finite start term, see the slot loop)
+__device__ __forceinline__ uint32_t wn_add_b8(uint32_t u, uint32_t tb, int pair) {
+    uint32_t v;
+    if (pair == 0) {
+        asm("v_add_u16_sdwa %0, %1, sext(%2) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_0" : "=v"(v) : "v"(u), "v"(tb));
+        asm("v_add_u16_sdwa %0, %1, sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_1" : "+v"(v) : "v"(u), "v"(tb));
+    } else {
+        asm("v_add_u16_sdwa %0, %1, sext(%2) dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_2" : "=v"(v) : "v"(u), "v"(tb));
+        asm("v_add_u16_sdwa %0, %1, sext(%2) dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:BYTE_3" : "+v"(v) : "v"(u), "v"(tb));
+    }
+    return v;
+}
 }  // namespace
 
+// F16 = false (sd_fast_wn_i16.hip, round 5): packed int16 cells and int8 table bytes instead of fp16 cells and bf8 bytes --
+// 5.5 instead of 4.5 operations per slot (no packed three-input maximum for int16, two byte adds instead of convert + add)
+// -- for scorings whose stored values leave the exact-integer range of fp16 (|S| up to 12 000 instead of 2 040) and as the
+// form an engine repeats a batch in after its fp16 range guard tripped; until round 5 both cases fell to the generic
+// family (50x slower per cell).  Same lane layout, checkpoints (int16 pairs) and B words; no --ed_thr compaction.
+//
 // COMPACT (--ed_thr with more than 128 templates, sd_fast_wn_ck.hip): a chunk is filled by as many waves as its
 // KEPT templates need (blockDim.x / 64 = ceil(kept / 128), chosen per chunk class by the launcher), whose virtual
 // lanes hold the kept templates in their filtered order (klist, written by sd_rank_keep) -- the reference's
@@ -36,7 +55,7 @@ __device__ __forceinline__ uint32_t cvt_bf8_pair(uint32_t tb, int pair, uint32_t
 // template-segmented prefix maximum of the lane totals, Vmax - 1 DPP hops) is applied lazily exactly as there -- it
 // joins the chain at slot 0 of the next row, it is the diagonal input of slot 0, and checkpoints / ends take
 // max(value, K).
-template <int P, bool RANKED, int FL = P, bool COMPACT = false, bool TILED = false>
+template <int P, bool RANKED, int FL = P, bool COMPACT = false, bool TILED = false, bool F16 = true>
 __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ codes,
@@ -49,6 +68,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     const uint32_t* __restrict__ lane_t = nullptr) {   // COMPACT && TILED: [chunk][W * 128] template | part << 16 of every virtual lane
     static_assert(P % 16 == 0, "the code table is streamed 16 slots at a time");
     static_assert(!(COMPACT && RANKED), "the compacted form needs no ranks");
+    static_assert(F16 || (!COMPACT && FL == P), "integer cells: the plain W-wave kernels only");
     constexpr int G = P / 16;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [W][G][2 halves][64 lanes][4 dwords] codes, then the exchange area
     if (n_ptr) n_chunks = *n_ptr;      // the size of a chunk class is known on the device only
@@ -63,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
     int32_t* xc = xr + 16;                                 // [1] chunk of the workgroup
     __syncthreads();
 
-    using CO = CellOps<true>;
+    using CO = CellOps<F16>;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     uint32_t* myc = lds + wave * (G * 512);
@@ -173,9 +193,10 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
         };
         // the eight table bytes of a row symbol r: code 0..4 -> match / mismatch, 5..7 -> -inf (padding = 7)
         auto pool_of = [&](int r, uint32_t& plo, uint32_t& phi) {
-            uint32_t lo = xb * 0x01010101u, hi = 0xFCFCFC00u | xb;
+            constexpr uint32_t PADS = F16 ? 0xFCFCFC00u : 0x80808000u;   // bf8 -inf / int8 -128
+            uint32_t lo = xb * 0x01010101u, hi = PADS | xb;
             if (r < 4) lo = (lo & ~(0xffu << (8 * r))) | (mb << (8 * r));
-            else hi = 0xFCFCFC00u | mb;
+            else hi = PADS | mb;
             plo = lo;
             phi = hi;
         };
@@ -239,7 +260,9 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
                 for (int s = 0; s < 16; ++s) {
                     const int q = 16 * g + s;
                     const uint32_t tb = __builtin_amdgcn_perm(phi, plo, cg[0][s >> 1]);
-                    const uint32_t t16 = CO::add(q == 0 ? row0adj : ins2, cvt_bf8_pair(tb, s & 1, 0x3f800000u));
+                    uint32_t t16;
+                    if constexpr (F16) t16 = CO::add(q == 0 ? row0adj : ins2, cvt_bf8_pair(tb, s & 1, 0x3f800000u));
+                    else t16 = wn_add_b8(q == 0 ? row0adj : ins2, tb, s & 1);
                     run = q == 0 ? t16 : CO::mx(run, t16);
                     L[q] = run;
                 }
@@ -253,8 +276,10 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
             }
         }
         F16Guard<P> guard;   // run-time check of the fp16 exact-integer range (sd_fast_dev.hpp)
-        guard.start(L[P - 1], sc.guard_lim);
-        guard.check_low(L);
+        if constexpr (F16) {
+            guard.start(L[P - 1], sc.guard_lim);
+            guard.check_low(L);
+        }
         int rnext = rs.code(1);
         rs.advance(1);
         load_group(0, 0, L[P - 1]);
@@ -266,11 +291,11 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
                     base += Brel;
                     Brel = 0;
                     tp = 0;
-                    guard.check_high(L);
+                    if constexpr (F16) guard.check_high(L);
 #pragma unroll
                     for (int s = 0; s < P; ++s) L[s] = CO::sub(L[s], d2);
                     if constexpr (TILED) K = bfi(startMask, NEGC, CO::sub(K, d2));
-                    guard.check_low(L);
+                    if constexpr (F16) guard.check_low(L);
                 }
                 const int q = (i / FAST_R) - 1;
                 uint32_t* ckq = ck + (uint64_t)q * (uint64_t)W * (uint64_t)(P * 64);
@@ -281,6 +306,42 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
             const uint32_t KB = CO::splat(Brel + sc.del - tp * sc.ins);
             uint32_t plo, phi;
             pool_of(rcur, plo, phi);
+            if constexpr (!F16) {
+                // integer cells, 5.5 ops per slot: [perm per 2 slots]; u = max(S[x-1], KB); v = u + int8 pair (2 SDWA adds);
+                // c = max(v, S[x]); S'[x] = max(S'[x-1], c) -- software-pipelined over the slots
+                uint32_t u_[P], v_[P], c_[P];
+                uint32_t run = 0, tbw = 0;
+                uint32_t KBx = KB, w0 = 0;
+                if constexpr (TILED) {
+                    KBx = CO::mx(K, KB);               // the carry is the diagonal input of slot 0 and joins the later floors
+                    w0 = bfi(startMask, NEGC, L[0]);   // no insertion move at k = 0
+                }
+#pragma unroll
+                for (int s = 0; s < P + 3; ++s) {
+                    if (s >= 3) {
+                        const int q = s - 3;
+                        run = q == 0 ? c_[0] : pk_max(run, c_[q]);
+                        L[q] = run;
+                    }
+                    if (s >= 2 && s - 2 < P) {
+                        const int q = s - 2;
+                        if (q == 0) c_[0] = TILED ? pk_max(pk_max(v_[0], w0), K) : v_[0];   // k == 0: start term only
+                        else c_[q] = pk_max(v_[q], L[q]);
+                    }
+                    if (s >= 1 && s - 1 < P) {
+                        const int q = s - 1;
+                        if ((q & 1) == 0) tbw = __builtin_amdgcn_perm(phi, plo, cg[(q >> 4) & 1][(q & 15) >> 1]);
+                        v_[q] = wn_add_b8(u_[q], tbw, q & 1);
+                        if ((q & 15) == 2 && (q >> 4) + 1 < G) load_group((q >> 4) + 1, ((q >> 4) + 1) & 1, v_[q]);   // one group ahead
+                    }
+                    if (s < P) {
+                        const int q = s;
+                        u_[q] = q == 0 ? KBx : pk_max(L[q - 1], KBx);
+                    }
+                    asm volatile("" : "+v"(KBx), "+v"(run));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
             uint32_t u_[P], v_[P], t_[P];
             uint32_t KBs = (uint32_t)__builtin_amdgcn_readfirstlane((int)KB);
             // TILED: slot 0's diagonal input is the true last slot of the lane below = the carry; KBv >= K serves the
@@ -323,6 +384,7 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
                 asm volatile("" : "+s"(KBs), "+s"(one_s) : "v"(pinL));
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }
             rnext = rs.code(i + 1);
             rs.advance(i + 1);
             load_group(0, 0, L[P - 1]);
@@ -336,8 +398,10 @@ __global__ __launch_bounds__(512, 2) void sd_fast_fill_wn(
                 reduce_ends(L[P - 1], i + 1);
             }
         }
-        guard.check_high(L);
-        guard.finish(sc.guard_flag);
+        if constexpr (F16) {
+            guard.check_high(L);
+            guard.finish(sc.guard_flag);
+        }
         __syncthreads();   // the exchange area and xc are rewritten for the next chunk
     }
 }

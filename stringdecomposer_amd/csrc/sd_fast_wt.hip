@@ -29,6 +29,11 @@ void launch_fast_fill_wt(const FastPlan& plan, hipStream_t st, const ChunkDesc* 
     const int per_cu = std::max(1, std::min(8 / W, (int)((size_t)160 * 1024 / lds)));
     const int grid = std::min(n_chunks, per_cu * n_cu);
     const bool ranked = cendoff != nullptr;
+    if (!plan.f16) {   // integer cells (sd_fast_wn_i16.hip)
+        (void)launch_fast_fill_wt_i16(plan, st, grid, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, ckpt, ckbase,
+                                      queue, order, cendoff, crank, n_ptr);
+        return;
+    }
     const bool fl48 = !plan.full_floor && plan.floor_slots >= 1 && plan.floor_slots <= 48;
 #define SD_FILLWT_K(PP, RK, FLV)                                                                                   \
     {                                                                                                              \

@@ -222,7 +222,8 @@ def plan_info(mono_seqs, **kw):
     rc = L.sd_plan_info(C.byref(p), _strs(ms), ml, len(ms), v, err, 4096)
     if rc != SD_OK:
         raise SdError(rc, err.value.decode(errors="replace"))
-    cells = {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table", 4: "f16/bf8-table", 5: "f16/bf8-codes x waves", 6: "f16/bf8-codes tiled x waves"}
+    cells = {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table", 4: "f16/bf8-table", 5: "f16/bf8-codes x waves", 6: "f16/bf8-codes tiled x waves",
+             7: "int16/int8-codes x waves", 8: "int16/int8-codes tiled x waves"}
     return {"family": {1: "generic", 2: "fast"}[v[0]], "cells_per_lane": v[1], "cells": cells.get(v[2], "?") if v[0] == 2 else "int32",
             "floor_slots": v[3], "waves": v[4] & 0xff, "range_bound": (v[4] >> 8) & 0xffffffff, "rebase": v[4] >> 40, "min_first_lane_cells": v[5], "max_lane_cells": v[6],
             "score_factor": v[7] & 0xffff, "trace_regs": (v[7] >> 16) & 0xff, "trace_bound": (v[7] >> 24) & 0xffffffff,
@@ -504,7 +505,8 @@ def _info_dict(v):
     return {"n_templates": v[0], "sum_template_len": v[1], "n_chunks": v[2], "rows": v[3],
             "family": {1: "generic", 2: "fast"}.get(v[4] & 0xff, "?"),
             "cells": {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table", 4: "f16/bf8-table",
-                      5: "f16/bf8-codes x waves", 6: "f16/bf8-codes tiled x waves"}.get(v[4] >> 8, "?"),
+                      5: "f16/bf8-codes x waves", 6: "f16/bf8-codes tiled x waves", 7: "int16/int8-codes x waves",
+                      8: "int16/int8-codes tiled x waves"}.get(v[4] >> 8, "?"),
             "cells_per_lane": v[5] if (v[4] & 0xff) == 1 else v[5] & 0xffff,
             "floor_slots": 0 if (v[4] & 0xff) == 1 else v[5] >> 16,
             "workspace_bytes": v[6], "fill_launches": v[7] & 0xffff,

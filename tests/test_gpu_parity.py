@@ -1192,3 +1192,64 @@ def test_one_bp_templates_on_the_fast_family_vs_oracle(oracle, k, sc):
         v1 = lib.decompose(rn, reads, mn, ms, kernel=lib.KERNEL_FAST, scoring=sc, part_size=part, overlap=ov, ed_thr=ed,
                            flags=lib.FLAG_TRACE_V1)
         assert v1 == exp, (k, sc, part, ed, "one-block traceback")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nm,lo,hi,sc,cells", [
+    (150, 150, 180, (-2, -2, -3, 40), "int16/int8-codes x waves"),          # 44 is not exact in bf8, G = 42 leaves fp16
+    (100, 165, 178, (-3, -5, -4, 7), "int16/int8-codes x waves"),           # range bound 2 040 < . <= 12 000
+    (40, 230, 700, (-2, -3, -4, 9), "int16/int8-codes tiled x waves"),      # tiled, 2+ waves
+    (5, 950, 1000, (-1, -2, -1, 3), "int16/int8-codes tiled x waves"),      # tiled, one wave, a dozen lanes per template
+    (200, 100, 224, (-1, -1, -1, 1), "forced")])                            # default scoring, SD_FLAG_NO_F16
+def test_multi_wave_layouts_with_integer_cells_vs_oracle(oracle, nm, lo, hi, sc, cells):
+    """Template sets beyond one wave whose scoring leaves the exact-integer range of fp16 (or is not exact in bf8): the
+    multi-wave fills with int16 cells and int8 table bytes (sd_fast_wn_i16.hip) instead of the generic family -- with and
+    without --ed_thr (ranked form: no compaction for integer cells), N in reads and templates, small chunks."""
+    st = synth.Stream(977 + nm, nm)
+    ms = _random_monomers(st, nm, lo, hi)
+    ms[1] = ms[1][:7] + b"N" + ms[1][8:]
+    mn = ["m%d" % j for j in range(nm)]
+    reads = []
+    for r in range(3):
+        parts = []
+        while sum(len(x) for x in parts) < 1500 + 900 * r:
+            j = int(st.below(1, nm)[0])
+            codes = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), np.frombuffer(ms[j].replace(b"N", b"A"), dtype=np.uint8))
+            x = synth._to_ascii(synth.mutate(codes, st, 0.05, 0.03, 0.03))
+            parts.append(synth.revcomp_bytes(x) if st.below(1, 2)[0] else x)
+        b = bytearray(b"".join(parts))
+        b[len(b) // 3] = ord("N")
+        reads.append(bytes(b))
+    rn = ["r%d" % i for i in range(len(reads))]
+    flags = lib.FLAG_NO_F16 if cells == "forced" else 0
+    e = lib.Engine(ms, scoring=sc, flags=flags)
+    info = e.info()
+    e.close()
+    assert info["family"] == "fast" and info["cells"] == ("int16/int8-codes x waves" if cells == "forced" else cells), info
+    for part, ov, ed in [(5000, 500, -1), (600, 90, -1), (5000, 500, 45), (700, 100, 0)]:
+        scc = (-1, -1, -1, 1) if ed > -1 else sc   # (the reference's 10-argument form ignores the scores)
+        if ed > -1 and cells != "forced":
+            continue
+        exp = oracle.decompose(rn, reads, mn, ms, threads=min(32, os.cpu_count() or 1), sc=scc, part=part, overlap=ov, ed_thr=ed)
+        got = lib.decompose(rn, reads, mn, ms, scoring=scc, part_size=part, overlap=ov, ed_thr=ed, flags=flags)
+        assert got == exp, (nm, sc, part, ed)
+
+
+@pytest.mark.gpu
+def test_fp16_guard_trip_on_a_multi_wave_set_repeats_on_the_fast_family(oracle):
+    """A tripped fp16 range guard on more than 128 templates: the batch is repeated with the int16 multi-wave kernels
+    (until round 5: on the generic family)."""
+    mn, ms = synth.make_monomers(140, seed=3)
+    rn, rs = synth.make_reads(ms, 4, read_len=3000, seed=5)
+    want = oracle.decompose(rn, rs, mn, ms, threads=8)
+    t0 = lib.guard_trips()
+    e = lib.Engine(ms, f16_guard=40)
+    e.load_reads(rs)
+    e.run()
+    rows = e.rows()
+    info = e.info()
+    e.close()
+    assert lib.guard_trips() > t0
+    assert info["family"] == "fast" and info["cells"] == "int16/int8-codes x waves", info
+    tn = mn + [m + "'" for m in mn]
+    assert b"".join(lib.format_rows(n, tn, r) for n, r in zip(rn, rows)) == want

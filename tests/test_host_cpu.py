@@ -607,7 +607,11 @@ def test_plan_layouts_of_the_baseline_sets_and_fuzz_fixtures():
     assert (t2["cells"], t2["cells_per_lane"], t2["waves"]) == ("f16/bf8-codes tiled x waves", 224, 4), t2
     t3 = lib.plan_info([rnd(1000)] * 5)                                        # ten templates of eleven lanes: one wave of 96 slots
     assert (t3["cells"], t3["cells_per_lane"], t3["waves"]) == ("f16/bf8-codes tiled x waves", 96, 1), t3
-    assert lib.plan_info([rnd(1000)] * 5, scoring=(-1, -2, -1, 1))["family"] == "generic"   # beyond the fp16 range: no tiled form
+    t4 = lib.plan_info([rnd(1000)] * 5, scoring=(-1, -2, -1, 1))               # beyond the fp16 range: the tiled form with integer cells (round 5)
+    assert (t4["family"], t4["cells"], t4["waves"]) == ("fast", "int16/int8-codes tiled x waves", 1), t4
+    t5 = lib.plan_info([rnd(150 + j % 30) for j in range(150)], scoring=(-2, -2, -3, 40))   # 44 is not exact in bf8, B grows by 42 a row
+    assert (t5["family"], t5["cells"], t5["waves"]) == ("fast", "int16/int8-codes x waves", 3), t5
+    assert lib.plan_info([rnd(150 + j % 30) for j in range(150)], scoring=(-2, -2, -3, 90))["family"] == "generic"   # beyond int16 cells
     huge = [rnd(100 + j % 150) for j in range(600)]
     assert lib.plan_info(huge)["family"] == "generic"                           # more lanes than eight waves hold ...
     h2 = lib.plan_info(huge, ed_thr=30)                                         # ... but with --ed_thr a chunk's kept templates mostly fit:
