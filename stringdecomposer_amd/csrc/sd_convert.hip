@@ -219,8 +219,10 @@ int PostProcessor::process_parts(const PostRead* reads, size_t n_reads, const sd
         for (const std::string& t : il_seq) tmax = std::max(tmax, t.size());
         int64_t worst = 0;
         for (int64_t b = 0; b < nB; ++b) worst = std::max<int64_t>(worst, seg_len[(size_t)b]);
-        host_only = edlib_splits(worst, (int64_t)tmax);   // (conservative: longest block x longest template)
-        if (host_only) have = false;
+        // (conservative: longest block x longest template.  Monomers beyond 512 bp: the device path deals the pairs one by
+        // one -- block traceback on the device, the split on host threads, sd_nw.hip -- so the batch is not held back)
+        host_only = edlib_splits(worst, (int64_t)tmax) && tmax <= 512;
+        if (edlib_splits(worst, (int64_t)tmax)) have = false;
     }
     const bool id = have;   // identities came with the rows
     const double t_a = now_seconds();

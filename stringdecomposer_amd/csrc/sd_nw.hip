@@ -214,10 +214,14 @@ int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans
         }
         tmax = std::max(tmax, (int)o.size());
     }
-    if (tmax > 512) return SD_ERR_UNSUPPORTED;
+    if (tmax > 2048) return SD_ERR_UNSUPPORTED;
+    const bool long_t = tmax > 512;   // monomers of a kilobase: a pair across lanes (sd_nw_long.hip)
+    if (long_t && getenv("SD_NW_LONG_OFF")) return SD_ERR_UNSUPPORTED;   // developer A/B: the host threads, as until round 4
     int K = (tmax + 63) / 64;
-    if (K == 5) K = 6;
-    if (K == 7) K = 8;
+    if (!long_t) {
+        if (K == 5) K = 6;
+        if (K == 7) K = 8;
+    }
     std::vector<unsigned long long> peq;
     std::vector<int32_t> tl;
     sd::nw_build_masks(ts, K, peq, tl);
@@ -234,10 +238,26 @@ int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans
     if (pair_tmpl)
         for (int64_t s = 0; s < n_seg; ++s)
             if (pair_tmpl[s] < 0 || pair_tmpl[s] >= T) return SD_ERR_PARAM;
-    {   // a pair edlib would align by Hirschberg's split (edlib.cpp:1186): the host identities follow it, this kernel does not
+    if (!long_t) {   // a pair edlib would align by Hirschberg's split (edlib.cpp:1186): the host identities follow it, this kernel does not
         size_t traw = 1;
         for (const std::string& t : tmpl) traw = std::max(traw, t.size());
         if (sd::edlib_splits(qmax, (int64_t)traw)) return SD_ERR_UNSUPPORTED;
+    }
+    // Long templates: edlib takes Hirschberg's split for ~1.7 kb x 1.7 kb and beyond (20 * ceil(q / 64) * t + 8 t >= 1 MB),
+    // which is the common case at 2 kb and rare at 1 kb -- so the pairs are dealt one by one: those edlib walks by its
+    // block traceback go to the device, the others (and segments beyond the kernel's LDS room) to the host
+    // implementation, which restates the split (sd_post.hip).  (Lengths before compression: a conservative test.)
+    constexpr int NWL_QCAP = 8192;
+    std::vector<int64_t> dev_pairs, host_pairs;
+    int qcap_dev = 1;
+    if (long_t) {
+        for (int64_t s = 0; s < n_seg; ++s)
+            for (int t = pair_tmpl ? pair_tmpl[s] : 0, te = pair_tmpl ? t + 1 : T; t < te; ++t) {
+                const int64_t id = pair_tmpl ? s : s * T + t;
+                if (seg_len[s] <= 0 || tmpl[(size_t)t].empty()) { dist[id] = -1; matches[id] = 0; continue; }   // main.py:30-33
+                if (seg_len[s] > NWL_QCAP || sd::edlib_splits(seg_len[s], (int64_t)tmpl[(size_t)t].size())) host_pairs.push_back(id);
+                else { dev_pairs.push_back(id); qcap_dev = std::max(qcap_dev, (int)seg_len[s]); }
+            }
     }
 
     std::lock_guard<std::mutex> g(g_nw.m);
@@ -274,6 +294,77 @@ int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans
         });
         for (uint8_t b : bad)
             if (b) return SD_ERR_UNSUPPORTED;
+    }
+    if (long_t) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return SD_ERR_HIP;
+        const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        const int lpp = K <= 16 ? 16 : 32, bt = 128, slots = (bt / 64) * (64 / lpp);
+        const size_t lds = sd::nw_long_lds_bytes(lpp, qcap_dev, bt);
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, ((size_t)160 * 1024) / std::max<size_t>(lds, 1)));
+        const int64_t nd = (int64_t)dev_pairs.size();
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nd + slots - 1) / slots, (int64_t)n_cu * per_cu));
+        const int cap = sd::nw_long_slots(qcap_dev, K);
+        const size_t ck_bytes = (size_t)grid * slots * (size_t)cap * 5 * lpp * 4;
+        bool ok = lds <= (size_t)160 * 1024 && g_nw.seq.need((size_t)text + 8) && g_nw.starts.need(sizeof(int64_t) * (size_t)n_seg) &&
+                  g_nw.lens.need(sizeof(int32_t) * (size_t)n_seg) && g_nw.peq.need(sizeof(unsigned long long) * peq.size()) &&
+                  g_nw.tlen.need(sizeof(int32_t) * (size_t)std::max(T, 1)) && g_nw.ck.need(ck_bytes) &&
+                  g_nw.idx.need(sizeof(int64_t) * (size_t)std::max<int64_t>(nd, 1)) && g_nw.dist.need(sizeof(int32_t) * (size_t)n_pairs) &&
+                  g_nw.matches.need(sizeof(int32_t) * (size_t)n_pairs) && (!pair_tmpl || g_nw.pair.need(sizeof(int32_t) * (size_t)n_seg));
+        if (!ok) return SD_ERR_UNSUPPORTED;
+        lap.to(0);
+        if (nd > 0) {
+            auto up = [](void* d, const void* h, size_t n) { return n == 0 || hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; };
+            ok = up(g_nw.seq.p, g_nw.stage, (size_t)text) && up(g_nw.starts.p, seg_start, sizeof(int64_t) * (size_t)n_seg) &&
+                 up(g_nw.lens.p, seg_len, sizeof(int32_t) * (size_t)n_seg) && up(g_nw.peq.p, peq.data(), sizeof(unsigned long long) * peq.size()) &&
+                 up(g_nw.tlen.p, tl.data(), sizeof(int32_t) * (size_t)T) && up(g_nw.idx.p, dev_pairs.data(), sizeof(int64_t) * (size_t)nd) &&
+                 (!pair_tmpl || up(g_nw.pair.p, pair_tmpl, sizeof(int32_t) * (size_t)n_seg));
+            if (!ok) return SD_ERR_HIP;
+            lap.to(1);
+            sd::launch_nw_long(K, nullptr, grid, bt, static_cast<const uint8_t*>(g_nw.seq.p), static_cast<const int64_t*>(g_nw.starts.p),
+                               static_cast<const int32_t*>(g_nw.lens.p), static_cast<const int64_t*>(g_nw.idx.p), nd, T,
+                               pair_tmpl ? static_cast<const int32_t*>(g_nw.pair.p) : nullptr,
+                               static_cast<const unsigned long long*>(g_nw.peq.p), static_cast<const int32_t*>(g_nw.tlen.p),
+                               homo ? 1 : 0, qcap_dev, cap, g_nw.ck.p, static_cast<int32_t*>(g_nw.dist.p), static_cast<int32_t*>(g_nw.matches.p));
+            if (hipGetLastError() != hipSuccess) return SD_ERR_HIP;
+        }
+        // the pairs edlib splits: host threads, under the kernel
+        int hrc = SD_OK;
+        if (!host_pairs.empty()) {
+            const size_t nh = host_pairs.size();
+            std::vector<std::string> qs(homo ? nh : 0);
+            std::vector<const char*> qp(nh), tp(nh);
+            std::vector<int32_t> qn(nh), tn(nh), hd(nh), hm(nh), hc(nh);
+            for (size_t x = 0; x < nh; ++x) {
+                const int64_t id = host_pairs[x], sg = pair_tmpl ? id : id / T;
+                const int t = pair_tmpl ? pair_tmpl[sg] : (int)(id - sg * T);
+                const char* q = g_nw.stage + seg_start[sg];
+                if (homo) {
+                    std::string& o = qs[x];
+                    for (int32_t i = 0; i < seg_len[sg]; ++i) if (i == 0 || q[i] != q[i - 1]) o.push_back(q[i]);
+                    qp[x] = o.data(); qn[x] = (int32_t)o.size();
+                } else {
+                    qp[x] = q; qn[x] = seg_len[sg];
+                }
+                tp[x] = ts[(size_t)t].data(); tn[x] = (int32_t)ts[(size_t)t].size();
+            }
+            hrc = sd_nw_identity_batch(qp.data(), qn.data(), tp.data(), tn.data(), (int64_t)nh, threads, hd.data(), hm.data(), hc.data());
+            if (hrc == SD_OK)
+                for (size_t x = 0; x < nh; ++x) { dist[host_pairs[x]] = hd[x]; matches[host_pairs[x]] = hm[x]; }
+        }
+        if (nd > 0) {
+            std::vector<int32_t> dd((size_t)n_pairs), dm((size_t)n_pairs);
+            if (hipMemcpy(dd.data(), g_nw.dist.p, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(dm.data(), g_nw.matches.p, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost) != hipSuccess)
+                return SD_ERR_HIP;
+            for (int64_t id : dev_pairs) {
+                if (dd[(size_t)id] == -2) return SD_ERR_INTERNAL;
+                dist[id] = dd[(size_t)id];
+                matches[id] = dm[(size_t)id];
+            }
+        }
+        lap.to(2);
+        return hrc == SD_OK ? SD_OK : (hrc == SD_ERR_UNSUPPORTED ? SD_ERR_UNSUPPORTED : hrc);
     }
     // Two launches: the segments of up to NW_SHORT symbols -- practically all of them, a block is about a monomer long --
     // with NW_SHORT / S checkpoint slots per lane and 12 waves per CU, and the few long ones (a non-satellite flank can

@@ -21,6 +21,14 @@ void launch_nw_pairs(int K, hipStream_t st, int grid, const uint8_t* seq, const 
                      const int32_t* seg_len, const int32_t* seg_idx, int64_t n_seg, int T, const int32_t* pair_tmpl,
                      const unsigned long long* peq, const int32_t* tlen, int homo, int cap, void* ck, int* ckpos,
                      int32_t* dist, int32_t* matches);
+// templates of 513 .. 2048 bp (sd_nw_long.hip): a pair across K lanes, systolic over the columns.  plist: the pair ids of
+// the launch; ck: grid * (block_threads / 64) * (64 / lpp) pair slots x cap x 5 x lpp dwords, lpp = 16 (K <= 16) or 32
+void launch_nw_long(int K, hipStream_t st, int grid, int block_threads, const uint8_t* seq, const int64_t* seg_start,
+                    const int32_t* seg_len, const int64_t* plist, int64_t n_pairs, int T, const int32_t* pair_tmpl,
+                    const unsigned long long* peq, const int32_t* tlen, int homo, int qcap, int cap, void* ck,
+                    int32_t* dist, int32_t* matches);
+size_t nw_long_lds_bytes(int lpp, int qcap, int block_threads);
+int nw_long_slots(int qmax, int K);
 void nw_build_masks(const std::vector<std::string>& ts, int K, std::vector<unsigned long long>& peq,
                     std::vector<int32_t>& tl);
 

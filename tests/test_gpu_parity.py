@@ -529,7 +529,10 @@ def test_stream_rows_equal_oracle(oracle, sub, cap):
         lib.Stream(ms).collect()
 
 
-@pytest.mark.parametrize("shape", [(12, 160, 180), (64, 165, 178), (5, 20, 70), (3, 300, 500), (2, 1, 5), (7, 120, 260)])
+# (4, 520, 1000) / (3, 700, 2000): monomers beyond 512 bp -- a pair across 16 / 32 lanes (sd_nw_long.hip); the pairs edlib
+# aligns by Hirschberg's split (~1.7 kb x 1.7 kb and beyond) go to host threads inside the same call
+@pytest.mark.parametrize("shape", [(12, 160, 180), (64, 165, 178), (5, 20, 70), (3, 300, 500), (2, 1, 5), (7, 120, 260),
+                                   (4, 520, 1000), (3, 700, 2000), (5, 600, 1500)])
 def test_nw_identity_kernel_equals_host_and_edlib(shape):
     """K3 (main.py:29-60,107-150): the device identity kernel (one lane per (segment, template) pair) against
     the host implementation -- itself pinned against the reference's vendored edlib on CPU -- for every pair,
