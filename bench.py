@@ -539,12 +539,18 @@ def main():
         nrows = 0
         depth = int(os.environ.get("SD_BENCH_DEPTH", "1"))   # developer A/B: steps kept outstanding before collecting
         out = 0
+        step_t = [] if os.environ.get("SD_BENCH_STEP_TIMES") else None   # developer: wall time of every step on stderr
         for k in range(steps):
+            if step_t is not None:
+                step_t.append(time.perf_counter())
             st.submit(readset)
             out += 1
             if out > depth:
                 nrows = st.collect()     # rows of an earlier step are in host memory
                 out -= 1
+        if step_t:
+            step_t.append(time.perf_counter())
+            print("[bench] step ms:", " ".join("%.1f" % ((b - a) * 1e3) for a, b in zip(step_t, step_t[1:])), file=sys.stderr)
         while out > 0:
             nrows = st.collect()
             out -= 1

@@ -1443,6 +1443,7 @@ struct Pipeline {
     double pack_s = 0, wait_s = 0, sink_s = 0;
     int64_t launches = 0, batches = 0, rows = 0;
 
+    bool restart_idle = false;   // an idle pipeline starts over at slot 0 (see push)
     bool ident_ok = false;   // a cached pipeline's engines carry the identity tables of their job (run_files_impl)
     // a pipeline kept from an earlier job with the same parameters and monomers: new borrowed arrays, fresh counters
     void begin_job(const sd_params* pp, const char* const* mono_seqs, const int32_t* mono_lens, int32_t n_mono) {
@@ -1540,7 +1541,9 @@ struct Pipeline {
         struct RunSink { Pipeline* p; bool on; ~RunSink() { if (on) p->pop_sink(); } } run_sink{this, deferred};
         // nothing in flight: start over at slot 0 -- a job of ONE batch then always meets the engine that already holds
         // buffers of its size (alternating slots made every second single-batch job allocate 17 GB anew: 0.5 s)
-        if (inflight() == 0 && sink_slot < 0) pushed = popped = 0;
+        // (jobs from files / chunk ranges only: a stream's caller overlaps its jobs, and its second engine should come to
+        // life during the caller's warm-up, not when two jobs first overlap)
+        if (restart_idle && inflight() == 0 && sink_slot < 0) pushed = popped = 0;
         const int k = (int)(pushed % NS);
         if (!eng[k]) {
             rc = sd_engine_create(&eng[k], &p, mseq.data(), mlen.data(), (int32_t)mseq.size(), eb, sizeof eb);
@@ -1815,6 +1818,7 @@ static int run_chunk_batches(const std::vector<ReadView>& reads, const std::vect
     }
     Pipeline& pipe = *pipe_h;
     if (rc) { err = pipe.eb; return rc; }
+    pipe.restart_idle = true;
     std::vector<std::pair<size_t, size_t>> batches;
     plan_batches(table, c_lo, c_hi, pipe.row_budget(), 1, batches);
     std::vector<const char*> cptr;
@@ -2925,6 +2929,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     const bool reused = pipe_h != nullptr;
     if (!pipe_h) pipe_h.reset(new Pipeline);
     Pipeline& pipe = *pipe_h;
+    pipe.restart_idle = true;
     pipe.on_engine = [&](sd_engine* e) {
         if (stream_ident && !engine_set_identity(e, pp.interleaved_seqs(), pp.own_interleaved(), second_best != 0)) stream_ident = false;
     };
