@@ -1865,6 +1865,7 @@ struct ReadAssembler {
     size_t next_read = 0;         // first read not yet written
     int32_t chunks_seen = 0;
     sd::RecordsWriter* rec_out = nullptr;   // set: completed reads go to the binary record stream and no text is made
+    std::vector<std::string>* part_sink = nullptr;   // set: the text stays in pieces (in order) instead of being appended to tsv
     ReadAssembler(const std::vector<ReadView>& r, const std::vector<CRef>& t, const std::vector<int32_t>& n,
                   const std::vector<std::string>& tn, int th, std::string& out)
         : reads(r), table(t), nch(n), tnames(tn), threads(th), tsv(out) {}
@@ -1912,6 +1913,10 @@ struct ReadAssembler {
             sd::format_rows(parts[(size_t)x], rd.name, rd.name_len, tnames, rows.data() + sl.r0, sl.r1 - sl.r0,
                             sl.r0 ? rows[sl.r0 - 1].end : 0);
         });
+        if (part_sink) {   // the caller gathers (or writes) the pieces itself, in parallel
+            for (std::string& part : parts) part_sink->push_back(std::move(part));
+            return;
+        }
         size_t total = tsv.size();
         for (const std::string& part : parts) total += part.size();
         tsv.reserve(std::max(total, tsv.capacity()));
@@ -2347,7 +2352,9 @@ int sd_assemble_tsv(const char* const* read_names, const int64_t* read_lens, int
             return SD_ERR_PARAM;
         }
     std::string out;
+    std::vector<std::string> parts;
     ReadAssembler as(reads, table, nch, tnames, p->threads, out);
+    as.part_sink = &parts;
     // in slices, so that the formatting threads always have a few hundred reads to share
     const size_t step = 4096;
     for (size_t c0 = 0; c0 < table.size(); c0 += step) {
@@ -2356,11 +2363,19 @@ int sd_assemble_tsv(const char* const* read_names, const int64_t* read_lens, int
         for (size_t c = c0; c <= c1; ++c) ro[c - c0] = rec_off[c] - rec_off[c0];
         as.add(c0, c1, recs + rec_off[c0], ro.data());
     }
-    char* o = static_cast<char*>(std::malloc(out.size() + 1));
-    std::memcpy(o, out.data(), out.size());
-    o[out.size()] = 0;
+    // one copy, by all threads, straight into the buffer the caller gets (a 200-Mb sequence is 52 MB of rows: appending
+    // the pieces to a string and copying that once more was two thirds of this call)
+    std::vector<size_t> at(parts.size() + 1, 0);
+    for (size_t i = 0; i < parts.size(); ++i) at[i + 1] = at[i] + parts[i].size();
+    const size_t total = at[parts.size()];
+    char* o = static_cast<char*>(std::malloc(total + 1));
+    if (!o) { set_err(errbuf, errlen, "out of host memory"); return SD_ERR_INTERNAL; }
+    sd::parallel_for((int64_t)parts.size(), p->threads, 1, [&](int64_t i) {
+        if (!parts[(size_t)i].empty()) std::memcpy(o + at[(size_t)i], parts[(size_t)i].data(), parts[(size_t)i].size());
+    });
+    o[total] = 0;
     *tsv = o;
-    *tsv_len = out.size();
+    *tsv_len = total;
     return SD_OK;
 }
 
