@@ -1866,21 +1866,36 @@ struct ReadAssembler {
     int32_t chunks_seen = 0;
     sd::RecordsWriter* rec_out = nullptr;   // set: completed reads go to the binary record stream and no text is made
     std::vector<std::string>* part_sink = nullptr;   // set: the text stays in pieces (in order) instead of being appended to tsv
+    double t_merge = 0, t_text = 0;
     ReadAssembler(const std::vector<ReadView>& r, const std::vector<CRef>& t, const std::vector<int32_t>& n,
                   const std::vector<std::string>& tn, int th, std::string& out)
         : reads(r), table(t), nch(n), tnames(tn), threads(th), tsv(out) {}
     void add(size_t c0, size_t c1, const sd_rec* recs, const int64_t* roff) {
         std::vector<std::vector<sd_rec>> done_rows;
         std::vector<size_t> done_ids;
-        for (size_t c = c0; c < c1; ++c) {
-            const int32_t add = (int32_t)table[c].off;  // main.cpp:109-111
-            for (int64_t x = roff[c - c0]; x < roff[c - c0 + 1]; ++x) {
-                sd_rec t = recs[x];
-                t.start += add;
-                t.end += add;
-                cur.push_back(t);
-            }
-            if (++chunks_seen == nch[next_read]) {
+        for (size_t c = c0; c < c1;) {
+            // the chunks of this call that belong to the read being assembled: their records are one contiguous range,
+            // moved (chunk offsets added, main.cpp:109-111) by all threads when there are many -- a 200-Mb sequence is
+            // 40 000 chunks of one read
+            const size_t ce = std::min(c1, c + (size_t)(nch[next_read] - chunks_seen));
+            const int64_t x0 = roff[c - c0], x1 = roff[ce - c0];
+            const size_t base = cur.size();
+            cur.resize(base + (size_t)(x1 - x0));
+            auto move_chunk = [&](int64_t k) {
+                const size_t ck = c + (size_t)k;
+                const int32_t add = (int32_t)table[ck].off;
+                for (int64_t x = roff[ck - c0]; x < roff[ck - c0 + 1]; ++x) {
+                    sd_rec t = recs[x];
+                    t.start += add;
+                    t.end += add;
+                    cur[base + (size_t)(x - x0)] = t;
+                }
+            };
+            if (ce - c >= 512) sd::parallel_for((int64_t)(ce - c), threads, 64, move_chunk);
+            else for (size_t k = 0; k < ce - c; ++k) move_chunk((int64_t)k);
+            chunks_seen += (int32_t)(ce - c);
+            c = ce;
+            if (chunks_seen == nch[next_read]) {
                 done_rows.emplace_back();
                 done_rows.back().swap(cur);
                 done_ids.push_back(next_read);
@@ -1888,8 +1903,10 @@ struct ReadAssembler {
                 chunks_seen = 0;
             }
         }
+        const double t_m0 = now_s();
         sd::parallel_for((int64_t)done_ids.size(), threads, 4,
                          [&](int64_t q) { sd::seam_merge(done_rows[(size_t)q]); });
+        t_merge += now_s() - t_m0;
         if (rec_out) {
             for (size_t q = 0; q < done_ids.size(); ++q) {
                 const ReadView& rd = reads[done_ids[q]];
@@ -1906,6 +1923,7 @@ struct ReadAssembler {
             for (size_t r0 = 0; r0 < done_rows[q].size(); r0 += step)
                 slices.push_back(Slice{q, r0, std::min(done_rows[q].size(), r0 + step)});
         std::vector<std::string> parts(slices.size());
+        const double t_t0 = now_s();
         sd::parallel_for((int64_t)slices.size(), threads, 1, [&](int64_t x) {
             const Slice& sl = slices[(size_t)x];
             const ReadView& rd = reads[done_ids[sl.q]];
@@ -1913,6 +1931,7 @@ struct ReadAssembler {
             sd::format_rows(parts[(size_t)x], rd.name, rd.name_len, tnames, rows.data() + sl.r0, sl.r1 - sl.r0,
                             sl.r0 ? rows[sl.r0 - 1].end : 0);
         });
+        t_text += now_s() - t_t0;
         if (part_sink) {   // the caller gathers (or writes) the pieces itself, in parallel
             for (std::string& part : parts) part_sink->push_back(std::move(part));
             return;
@@ -1926,7 +1945,8 @@ struct ReadAssembler {
 }  // namespace
 
 static int decompose_impl(const std::vector<ReadView>& reads, const std::vector<sd::Seq>& monos,
-                          const sd_params* p, std::string& tsv, std::string& err, const char* records_out = nullptr) {
+                          const sd_params* p, std::string& tsv, std::string& err, const char* records_out = nullptr,
+                          std::vector<std::string>* parts_out = nullptr) {   // parts_out: the text in pieces instead of `tsv`
     if (monos.empty()) { err = "no monomers"; return SD_ERR_PARAM; }
     for (const ReadView& r : reads)
         if (r.len <= 0) { err = "ERROR: Sequence " + std::string(r.name, r.name_len) + " is empty"; return SD_ERR_EMPTY; }
@@ -1935,6 +1955,7 @@ static int decompose_impl(const std::vector<ReadView>& reads, const std::vector<
     std::vector<int32_t> nch;
     build_chunk_table(reads, p, table, nch);
     ReadAssembler as(reads, table, nch, ts.tnames, p->threads, tsv);
+    as.part_sink = parts_out;
     sd::RecordsWriter rw;
     if (records_out) {
         const int orc = rw.open(records_out, *p, ts.tnames, err);
@@ -2020,13 +2041,15 @@ static int decompose_files_impl(const char* reads_fa, const char* monomers_fa, c
     std::vector<ReadView> views;
     views.reserve(rf.recs.size());
     for (const auto& r : rf.recs) views.push_back(ReadView{r.name, r.name_len, r.seq, r.len});
-    rc = decompose_impl(views, monos, p, out, err, records_out);
+    std::vector<std::string> parts;   // the text stays in the pieces the threads formatted: written by write_parts, no gather
+    rc = decompose_impl(views, monos, p, out, err, records_out, &parts);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
     if (!raw_tsv_out) return SD_OK;
-    FILE* fp = std::fopen(raw_tsv_out, "wb");
-    if (!fp) { set_err(errbuf, errlen, std::string("cannot write ") + raw_tsv_out); return SD_ERR_IO; }
-    const size_t w = std::fwrite(out.data(), 1, out.size(), fp);
-    if (std::fclose(fp) != 0 || w != out.size()) {
+    const int fd = ::open(raw_tsv_out, O_RDWR | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) { set_err(errbuf, errlen, std::string("cannot write ") + raw_tsv_out); return SD_ERR_IO; }
+    int64_t off = 0;
+    const bool ok = sd::write_parts(fd, off, parts, p->threads);
+    if (::close(fd) != 0 || !ok) {
         set_err(errbuf, errlen, std::string("short write to ") + raw_tsv_out);
         return SD_ERR_IO;
     }
@@ -2353,6 +2376,7 @@ int sd_assemble_tsv(const char* const* read_names, const int64_t* read_lens, int
         }
     std::string out;
     std::vector<std::string> parts;
+    const double t_a0 = now_s();
     ReadAssembler as(reads, table, nch, tnames, p->threads, out);
     as.part_sink = &parts;
     // in slices, so that the formatting threads always have a few hundred reads to share
@@ -2363,6 +2387,7 @@ int sd_assemble_tsv(const char* const* read_names, const int64_t* read_lens, int
         for (size_t c = c0; c <= c1; ++c) ro[c - c0] = rec_off[c] - rec_off[c0];
         as.add(c0, c1, recs + rec_off[c0], ro.data());
     }
+    const double t_g0 = now_s();
     // one copy, by all threads, straight into the buffer the caller gets (a 200-Mb sequence is 52 MB of rows: appending
     // the pieces to a string and copying that once more was two thirds of this call)
     std::vector<size_t> at(parts.size() + 1, 0);
@@ -2376,6 +2401,9 @@ int sd_assemble_tsv(const char* const* read_names, const int64_t* read_lens, int
     o[total] = 0;
     *tsv = o;
     *tsv_len = total;
+    if (getenv("SD_TIMING"))
+        std::fprintf(stderr, "[sd timing] assemble: %.1f ms to the pieces (seam merge %.1f, text %.1f), gather %.1f ms\n",
+                     (t_g0 - t_a0) * 1e3, as.t_merge * 1e3, as.t_text * 1e3, (now_s() - t_g0) * 1e3);
     return SD_OK;
 }
 

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -266,27 +267,49 @@ inline char* put_fixed2_at(char* w, double v) {
 // SaveBatch (main.cpp:272-285).  The reference prints to_string(float identity) == "%f"; the
 // identity is an integer-valued float (|v| < 1e6 < 2^24 by the range check in the engine), so
 // "%f" is exactly "<int>.000000".
+// decimal text of an int written at w, returns the end (room for 12 bytes)
+inline char* put_int_at(char* w, int64_t v) {
+    char buf[24];
+    int p = 24;
+    const bool neg = v < 0;
+    uint64_t u = neg ? (uint64_t)(-(v + 1)) + 1u : (uint64_t)v;
+    do { buf[--p] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (neg) buf[--p] = '-';
+    std::memcpy(w, buf + p, (size_t)(24 - p));
+    return w + (24 - p);
+}
+
 inline void format_rows(std::string& o, const char* read_name, size_t read_name_len,
                         const std::vector<std::string>& tnames, const sd_rec* rows, size_t n,
                         int prev_end = 0) {  // prev_end: end of the row before rows[0] (0 at a read's start)
+    // Written through a pointer into room reserved for the worst case (a std::string that grows field by field spent
+    // 580 ns per row on appends and reallocations: 61 ms for the 1.17 M rows of a 200-Mb sequence on 16 threads).
+    size_t tmax = 0;
+    for (const std::string& t : tnames) tmax = std::max(tmax, t.size());
+    const size_t row_max = read_name_len + tmax + 5 * 12 + 8 + 7;   // two names, five ints, ".000000", separators
+    const size_t at0 = o.size();
+    o.resize(at0 + n * row_max);
+    char* w = &o[at0];
     for (size_t x = 0; x < n; ++x) {
         const sd_rec& r = rows[x];
-        o.append(read_name, read_name_len);
-        o.push_back('\t');
-        o.append(tnames[(size_t)r.tmpl]);
-        o.push_back('\t');
-        put_int(o, r.start);
-        o.push_back('\t');
-        put_int(o, r.end);
-        o.push_back('\t');
-        put_int(o, r.score);
-        o.append(".000000\t", 8);
-        put_int(o, (int64_t)r.start - prev_end);
-        o.push_back('\t');
-        put_int(o, (int64_t)r.end - r.start);
-        o.push_back('\n');
+        std::memcpy(w, read_name, read_name_len); w += read_name_len;
+        *w++ = '\t';
+        const std::string& tn = tnames[(size_t)r.tmpl];
+        std::memcpy(w, tn.data(), tn.size()); w += tn.size();
+        *w++ = '\t';
+        w = put_int_at(w, r.start);
+        *w++ = '\t';
+        w = put_int_at(w, r.end);
+        *w++ = '\t';
+        w = put_int_at(w, r.score);
+        std::memcpy(w, ".000000\t", 8); w += 8;
+        w = put_int_at(w, (int64_t)r.start - prev_end);
+        *w++ = '\t';
+        w = put_int_at(w, (int64_t)r.end - r.start);
+        *w++ = '\n';
         prev_end = r.end;
     }
+    o.resize((size_t)(w - o.data()));
 }
 
 // Process-wide pool of host worker threads.  The packer, the assembler and the formatter run many
