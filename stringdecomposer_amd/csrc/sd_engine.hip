@@ -1867,12 +1867,89 @@ struct ReadAssembler {
     sd::RecordsWriter* rec_out = nullptr;   // set: completed reads go to the binary record stream and no text is made
     std::vector<std::string>* part_sink = nullptr;   // set: the text stays in pieces (in order) instead of being appended to tsv
     double t_merge = 0, t_text = 0;
+    // A read of many chunks (a chromosome: 40 000) is merged and formatted AS ITS CHUNKS ARRIVE, so that the text of a
+    // device batch is made (and, by sd_decompose_files, written) while the next batch is on the device instead of all at
+    // the end.  The seam merge (main.cpp:287-302) is a scan whose state is one index: at decision index i it looks at the
+    // six records behind i, keeps b[i], and either goes on at i + 1 or -- b[i] overlaps b[j] by more than half of b[j] --
+    // also keeps b[j + 1] unchecked and goes on at j + 2.  A decision needs the records up to i + 7, so with more chunks
+    // to come the scan stops eight records before the end of what has arrived; `cur` then holds that undecided tail.
+    static constexpr int32_t kStreamChunks = 256;   // reads of more chunks than this take the streaming form
+    std::vector<sd_rec> s_rows;   // kept rows not yet formatted
+    int s_prev_end = 0;           // end of the last kept row (SaveBatch's prev_end)
+    void stream_advance(bool final, std::vector<std::string>& parts) {
+        const double t_m0 = now_s();
+        const size_t N = cur.size();
+        size_t i = 0;
+        while (i < N && (final || i + 8 <= N)) {
+            const size_t lim = i + 7 < N ? i + 7 : N;
+            for (size_t j = i + 1; j < lim; ++j)
+                if ((cur[i].end - cur[j].start) * 2 > (cur[j].end - cur[j].start)) {
+                    s_rows.push_back(cur[i]);
+                    i = j + 1;
+                    break;
+                }
+            if (i < N) s_rows.push_back(cur[i]);
+            ++i;
+        }
+        cur.erase(cur.begin(), cur.begin() + (long)std::min(i, N));   // (what stays is at most eight records)
+        t_merge += now_s() - t_m0;
+        if (s_rows.empty()) return;
+        const double t_t0 = now_s();
+        const ReadView& rd = reads[next_read];
+        const size_t step = 32768, n_sl = (s_rows.size() + step - 1) / step, at = parts.size();
+        parts.resize(at + n_sl);
+        sd::parallel_for((int64_t)n_sl, threads, 1, [&](int64_t x) {
+            const size_t r0 = (size_t)x * step, r1 = std::min(s_rows.size(), r0 + step);
+            sd::format_rows(parts[at + (size_t)x], rd.name, rd.name_len, tnames, s_rows.data() + r0, r1 - r0,
+                            r0 ? s_rows[r0 - 1].end : s_prev_end);
+        });
+        s_prev_end = s_rows.back().end;
+        s_rows.clear();
+        t_text += now_s() - t_t0;
+    }
     ReadAssembler(const std::vector<ReadView>& r, const std::vector<CRef>& t, const std::vector<int32_t>& n,
                   const std::vector<std::string>& tn, int th, std::string& out)
         : reads(r), table(t), nch(n), tnames(tn), threads(th), tsv(out) {}
     void add(size_t c0, size_t c1, const sd_rec* recs, const int64_t* roff) {
-        std::vector<std::vector<sd_rec>> done_rows;
+        std::vector<std::vector<sd_rec>> done_rows;   // reads completed by this call, not yet merged / formatted
         std::vector<size_t> done_ids;
+        std::vector<std::string> out_parts;           // the text of this call, in read order
+        // merge + text (or record stream) of the completed reads gathered so far
+        auto flush_done = [&]() {
+            if (done_ids.empty()) return;
+            const double t_m0 = now_s();
+            sd::parallel_for((int64_t)done_ids.size(), threads, 4,
+                             [&](int64_t q) { sd::seam_merge(done_rows[(size_t)q]); });
+            t_merge += now_s() - t_m0;
+            if (rec_out) {
+                for (size_t q = 0; q < done_ids.size(); ++q) {
+                    const ReadView& rd = reads[done_ids[q]];
+                    rec_out->add_read(rd.name, rd.name_len, rd.len, done_rows[q].data(), (int64_t)done_rows[q].size());
+                }
+            } else {
+                // text in slices of 32 k rows, so that a long read is formatted by all host threads as well; a slice only
+                // needs the end of the row before it (SaveBatch's prev_end)
+                struct Slice { size_t q, r0, r1; };
+                std::vector<Slice> slices;
+                const size_t step = 32768;
+                for (size_t q = 0; q < done_ids.size(); ++q)
+                    for (size_t r0 = 0; r0 < done_rows[q].size(); r0 += step)
+                        slices.push_back(Slice{q, r0, std::min(done_rows[q].size(), r0 + step)});
+                const size_t at = out_parts.size();
+                out_parts.resize(at + slices.size());
+                const double t_t0 = now_s();
+                sd::parallel_for((int64_t)slices.size(), threads, 1, [&](int64_t x) {
+                    const Slice& sl = slices[(size_t)x];
+                    const ReadView& rd = reads[done_ids[sl.q]];
+                    const std::vector<sd_rec>& rows = done_rows[sl.q];
+                    sd::format_rows(out_parts[at + (size_t)x], rd.name, rd.name_len, tnames, rows.data() + sl.r0, sl.r1 - sl.r0,
+                                    sl.r0 ? rows[sl.r0 - 1].end : 0);
+                });
+                t_text += now_s() - t_t0;
+            }
+            done_rows.clear();
+            done_ids.clear();
+        };
         for (size_t c = c0; c < c1;) {
             // the chunks of this call that belong to the read being assembled: their records are one contiguous range,
             // moved (chunk offsets added, main.cpp:109-111) by all threads when there are many -- a 200-Mb sequence is
@@ -1895,6 +1972,13 @@ struct ReadAssembler {
             else for (size_t k = 0; k < ce - c; ++k) move_chunk((int64_t)k);
             chunks_seen += (int32_t)(ce - c);
             c = ce;
+            if (nch[next_read] > kStreamChunks && !rec_out) {   // a huge read: merged and formatted as it arrives
+                flush_done();                                   // (the reads before it come first in the text)
+                const bool fin = chunks_seen == nch[next_read];
+                stream_advance(fin, out_parts);
+                if (fin) { ++next_read; chunks_seen = 0; s_prev_end = 0; cur.clear(); }
+                continue;
+            }
             if (chunks_seen == nch[next_read]) {
                 done_rows.emplace_back();
                 done_rows.back().swap(cur);
@@ -1903,50 +1987,23 @@ struct ReadAssembler {
                 chunks_seen = 0;
             }
         }
-        const double t_m0 = now_s();
-        sd::parallel_for((int64_t)done_ids.size(), threads, 4,
-                         [&](int64_t q) { sd::seam_merge(done_rows[(size_t)q]); });
-        t_merge += now_s() - t_m0;
-        if (rec_out) {
-            for (size_t q = 0; q < done_ids.size(); ++q) {
-                const ReadView& rd = reads[done_ids[q]];
-                rec_out->add_read(rd.name, rd.name_len, rd.len, done_rows[q].data(), (int64_t)done_rows[q].size());
-            }
-            return;
-        }
-        // text in slices of 32 k rows, so that one huge read (a whole chromosome) is formatted by all
-        // host threads as well; a slice only needs the end of the row before it (SaveBatch's prev_end)
-        struct Slice { size_t q, r0, r1; };
-        std::vector<Slice> slices;
-        const size_t step = 32768;
-        for (size_t q = 0; q < done_ids.size(); ++q)
-            for (size_t r0 = 0; r0 < done_rows[q].size(); r0 += step)
-                slices.push_back(Slice{q, r0, std::min(done_rows[q].size(), r0 + step)});
-        std::vector<std::string> parts(slices.size());
-        const double t_t0 = now_s();
-        sd::parallel_for((int64_t)slices.size(), threads, 1, [&](int64_t x) {
-            const Slice& sl = slices[(size_t)x];
-            const ReadView& rd = reads[done_ids[sl.q]];
-            const std::vector<sd_rec>& rows = done_rows[sl.q];
-            sd::format_rows(parts[(size_t)x], rd.name, rd.name_len, tnames, rows.data() + sl.r0, sl.r1 - sl.r0,
-                            sl.r0 ? rows[sl.r0 - 1].end : 0);
-        });
-        t_text += now_s() - t_t0;
+        flush_done();
         if (part_sink) {   // the caller gathers (or writes) the pieces itself, in parallel
-            for (std::string& part : parts) part_sink->push_back(std::move(part));
+            for (std::string& part : out_parts) part_sink->push_back(std::move(part));
             return;
         }
         size_t total = tsv.size();
-        for (const std::string& part : parts) total += part.size();
+        for (const std::string& part : out_parts) total += part.size();
         tsv.reserve(std::max(total, tsv.capacity()));
-        for (const std::string& part : parts) tsv += part;
+        for (const std::string& part : out_parts) tsv += part;
     }
 };
 }  // namespace
 
 static int decompose_impl(const std::vector<ReadView>& reads, const std::vector<sd::Seq>& monos,
                           const sd_params* p, std::string& tsv, std::string& err, const char* records_out = nullptr,
-                          std::vector<std::string>* parts_out = nullptr) {   // parts_out: the text in pieces instead of `tsv`
+                          std::vector<std::string>* parts_out = nullptr,   // parts_out: the text in pieces instead of `tsv`
+                          const std::function<bool(std::vector<std::string>&)>& flush_parts = nullptr) {   // ... handed over after every batch
     if (monos.empty()) { err = "no monomers"; return SD_ERR_PARAM; }
     for (const ReadView& r : reads)
         if (r.len <= 0) { err = "ERROR: Sequence " + std::string(r.name, r.name_len) + " is empty"; return SD_ERR_EMPTY; }
@@ -1962,10 +2019,13 @@ static int decompose_impl(const std::vector<ReadView>& reads, const std::vector<
         if (orc) return orc;
         as.rec_out = &rw;
     }
+    bool flush_ok = true;
     int rc = run_chunk_batches(reads, table, 0, table.size(), ts, p, err,
                                [&](size_t c0, size_t c1, const sd_rec* recs, const int64_t* roff) {
                                    as.add(c0, c1, recs, roff);
+                                   if (flush_parts && parts_out && flush_ok) flush_ok = flush_parts(*parts_out);
                                });
+    if (rc == SD_OK && !flush_ok) { rc = SD_ERR_IO; err = "short write"; }
     if (records_out && rc == SD_OK) rc = rw.close(err, records_out);
     return rc;
 }
@@ -2041,18 +2101,25 @@ static int decompose_files_impl(const char* reads_fa, const char* monomers_fa, c
     std::vector<ReadView> views;
     views.reserve(rf.recs.size());
     for (const auto& r : rf.recs) views.push_back(ReadView{r.name, r.name_len, r.seq, r.len});
-    std::vector<std::string> parts;   // the text stays in the pieces the threads formatted: written by write_parts, no gather
-    rc = decompose_impl(views, monos, p, out, err, records_out, &parts);
-    if (rc) { set_err(errbuf, errlen, err); return rc; }
-    if (!raw_tsv_out) return SD_OK;
-    const int fd = ::open(raw_tsv_out, O_RDWR | O_CREAT | O_TRUNC, 0666);
-    if (fd < 0) { set_err(errbuf, errlen, std::string("cannot write ") + raw_tsv_out); return SD_ERR_IO; }
-    int64_t off = 0;
-    const bool ok = sd::write_parts(fd, off, parts, p->threads);
-    if (::close(fd) != 0 || !ok) {
-        set_err(errbuf, errlen, std::string("short write to ") + raw_tsv_out);
-        return SD_ERR_IO;
+    // The text stays in the pieces the threads formatted and goes to the file after every device batch (write_parts: no
+    // gather), i.e. while the next batch is on the device -- for a chromosome-sized read too, whose rows are merged and
+    // formatted as its chunks arrive (ReadAssembler::stream_advance).
+    std::vector<std::string> parts;
+    int fd = -1;
+    if (raw_tsv_out) {
+        fd = ::open(raw_tsv_out, O_RDWR | O_CREAT | O_TRUNC, 0666);
+        if (fd < 0) { set_err(errbuf, errlen, std::string("cannot write ") + raw_tsv_out); return SD_ERR_IO; }
     }
+    int64_t off = 0;
+    auto flush = [&](std::vector<std::string>& ps) {
+        const bool ok = fd < 0 || sd::write_parts(fd, off, ps, p->threads);
+        ps.clear();
+        return ok;
+    };
+    rc = decompose_impl(views, monos, p, out, err, records_out, &parts, flush);
+    const bool closed = fd < 0 || ::close(fd) == 0;
+    if (rc) { set_err(errbuf, errlen, err == "short write" ? std::string("short write to ") + raw_tsv_out : err); return rc; }
+    if (!closed) { set_err(errbuf, errlen, std::string("short write to ") + raw_tsv_out); return SD_ERR_IO; }
     return SD_OK;
 }
 

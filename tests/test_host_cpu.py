@@ -854,3 +854,61 @@ def test_packed_traceback_applies_up_to_256_bp_templates():
         ms = ["".join(rnd.choice("ACGT") for _ in range(L)) for _ in range(3)]
         info = lib.plan_info(ms)
         assert info["family"] == "fast" and info["trace_regs"] == regs, (L, info)
+
+
+def test_streamed_seam_merge_of_a_huge_read_equals_the_literal_scan():
+    """A read of many chunks is merged and formatted as its chunks arrive (ReadAssembler::stream_advance: the scan of
+    main.cpp:287-302 stopped eight records before the end of what has arrived); rows must equal the literal scan over the
+    whole read -- records built so that every branch of the scan fires (overlaps of more than half a record at distances
+    1..6, runs of them, the unchecked record behind a drop), small reads before and after the huge one."""
+    import random
+    import numpy as np
+    rnd = random.Random(11)
+    part, ov = 100, 30
+    read_lens = [900, 700_000, 1300, 950_000, 40]          # 9 + 7 000 + 13 + 9 500 + 1 chunks: the huge reads arrive in several calls
+    rec_dt = lib._rec_dtype()
+    recs, off, per_read = [], [0], []
+    for rl in read_lens:
+        rows = []
+        for (o, ln) in lib.chunk_plan(rl, part, ov):
+            pos, k = 0, 0
+            chunk = []
+            while pos < ln - 5:
+                w = rnd.randint(3, 40)
+                e = min(ln - 1, pos + w)
+                chunk.append((rnd.randrange(6), pos, e, rnd.randint(-5, 30)))
+                # the next record often starts INSIDE this one (a seam-like overlap), sometimes far behind it
+                pos = max(0, e - rnd.randint(0, w)) if rnd.random() < 0.45 else e + 1 + rnd.randint(0, 3)
+                k += 1
+                if k > 60:
+                    break
+            recs.extend(chunk)
+            off.append(len(recs))
+            rows.extend((t, s + o, e + o, sc) for t, s, e, sc in chunk)
+        per_read.append(rows)
+
+    def literal(b):   # main.cpp:287-302
+        res, i = [], 0
+        while i < len(b):
+            for j in range(i + 1, min(i + 7, len(b))):
+                if (b[i][2] - b[j][1]) * 2 > (b[j][2] - b[j][1]):
+                    res.append(b[i])
+                    i = j + 1
+                    break
+            if i < len(b):
+                res.append(b[i])
+            i += 1
+        return res
+    names = ["r%d" % i for i in range(len(read_lens))]
+    mono = ["m0", "m1", "m2"]
+    tn = mono + [m + "'" for m in mono]
+    want = []
+    for nm, rows in zip(names, per_read):
+        prev = 0
+        for t, s, e, sc in literal(rows):
+            want.append("%s\t%s\t%d\t%d\t%d.000000\t%d\t%d\n" % (nm, tn[t], s, e, sc, s - prev, e - s))
+            prev = e
+    arr = np.array(recs, dtype=rec_dt)
+    for threads in (1, 4):
+        got = lib.assemble_tsv(names, read_lens, mono, arr, np.array(off, dtype=np.int64), part_size=part, overlap=ov, threads=threads)
+        assert got.decode() == "".join(want)
