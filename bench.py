@@ -343,33 +343,61 @@ def bench_strong(args):
     shard.barrier(dist, bar_dev)
     dt = shard.max_over_ranks(dist, my_dt, dev)
     rate = shard.job_rate(dist, job_bp * K, my_dt, dev)
-    # What follows the DP in the real multi-process job and is NOT inside the timed steps: the ranks' records meet on rank 0
-    # (host-side gather, no device collective) and rank 0 alone turns them into the raw TSV (chunk offsets, seam merge,
-    # SaveBatch text: main.cpp:104-117, 272-302) -- the serial part of the strong-scaling job, timed once and reported beside it.
+    # What follows the DP in the real multi-process job and is NOT inside the timed steps: records -> raw TSV (chunk offsets,
+    # seam merge, SaveBatch text: main.cpp:104-117, 272-302).  Since round 5 every rank does that for its own chunk range
+    # (shard._assemble_by_ranks: two exchanges of a few hundred bytes, csrc/sd_seam.hpp) instead of rank 0 for everybody;
+    # timed once and reported beside the DP.  One process: the whole-job assembly a single GPU pays, and the same job cut
+    # into eight ranges assembled one after the other with the threads a rank of eight gets (what each of eight GPUs' hosts
+    # would pay: the slowest range counts).
     serial = None
     if st is None:
         import numpy as np
         shard.barrier(dist, bar_dev)
-        s0 = time.perf_counter()
         if dist is not None and ws > 1:
-            box = [None] * ws if rank == 0 else None
-            dist.gather_object((lo, last["recs"], last["off"]), box, dst=0)
+            stats = {}
+            s0 = time.perf_counter()
+            done = shard._assemble_by_ranks(dist, rank, ws, lambda: lib.RangeAssembler.from_lists(
+                ["seq"], [args.seq_len], mn, lo, hi, last["recs"], last["off"], scoring=scoring, threads=threads), stats=stats)
+            s1 = time.perf_counter()
+            worst = shard.max_over_ranks(dist, s1 - s0, dev)
+            if done is not None:
+                serial = {"mode": "every rank assembles its own chunk range", "wall_ms_max_over_ranks": worst * 1e3,
+                          "rank0": stats, "raw_tsv_bytes": len(done[1]) if done[1] is not None else None,
+                          "note": "once, after the timed steps; includes the gather of the finished TEXT on rank 0 that stands in "
+                                  "for the file writes of the command line; not part of ms_per_step"}
+            else:
+                serial = {"mode": "not shareable (a share is empty or a crossing piece is shorter than 32 records)"}
         else:
-            box = [(lo, last["recs"], last["off"])]
-        s1 = time.perf_counter()
-        if rank == 0:
-            parts = sorted(box, key=lambda t: t[0])
-            all_recs = np.concatenate([q[1] for q in parts])
-            offs, base = [np.zeros(1, dtype=np.int64)], 0
-            for _, r, o in parts:
-                offs.append(o[1:] + base)
-                base += len(r)
-            tsv = lib.assemble_tsv(["seq"], [args.seq_len], mn, all_recs, np.concatenate(offs), scoring=scoring, threads=threads)
+            s1 = time.perf_counter()
+            tsv = lib.assemble_tsv(["seq"], [args.seq_len], mn, last["recs"], last["off"], scoring=scoring, threads=threads)
             s2 = time.perf_counter()
-            serial = {"gather_records_ms": (s1 - s0) * 1e3, "rank0_assemble_raw_tsv_ms": (s2 - s1) * 1e3,
-                      "raw_tsv_rows": tsv.count(b"\n"), "raw_tsv_bytes": len(tsv),
-                      "note": "once, after the timed steps: records of all ranks -> rank 0 (gloo / in-process) -> raw TSV text in "
-                              "host memory; not part of ms_per_step"}
+            serial = {"mode": "one process", "assemble_raw_tsv_ms": (s2 - s1) * 1e3, "raw_tsv_rows": tsv.count(b"\n"),
+                      "raw_tsv_bytes": len(tsv),
+                      "note": "once, after the timed steps: this rank's records -> raw TSV text in host memory; not part of ms_per_step"}
+            if kind == "chunks" and lo == 0 and hi - lo >= 64:
+                t8 = max(1, threads // 8)
+                asm, per = [], []
+                for g in range(8):
+                    glo, ghi = shard.block_range(hi, g, 8)
+                    g0 = time.perf_counter()
+                    asm.append(lib.RangeAssembler.from_lists(["seq"], [args.seq_len], mn, glo, ghi, last["recs"][last["off"][glo]:last["off"][ghi]],
+                                                             last["off"][glo:ghi + 1] - last["off"][glo], scoring=scoring, threads=t8))
+                    per.append(time.perf_counter() - g0)
+                edges = [x.edge for x in asm]
+                texts = []
+                for g, x in enumerate(asm):
+                    g0 = time.perf_counter()
+                    x.text(edges, g)
+                    per[g] += time.perf_counter() - g0
+                    texts.append(x.bytes())
+                st8 = [x.stats() for x in asm]
+                for x in asm:
+                    x.close()
+                serial["eight_ranges_one_after_the_other"] = {
+                    "threads_per_range": t8, "ms_per_range": [round(v * 1e3, 2) for v in per], "slowest_ms": max(per) * 1e3,
+                    "after_the_exchange_ms": [round(q["text_ms"], 3) for q in st8],
+                    "rows_printed_after_the_exchange": [q["rows_printed_after_exchange"] for q in st8],
+                    "edge_bytes_per_rank": len(edges[0]), "same_bytes_as_one_process": b"".join(texts) == tsv}
     kern = None
     if st:
         b = st.stats()

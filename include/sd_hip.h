@@ -221,6 +221,52 @@ int sd_assemble_tsv(const char* const* read_names, const int64_t* read_lens, int
                     const sd_rec* recs, const int64_t* rec_off, int64_t n_chunks, char** tsv,
                     size_t* tsv_len, char* errbuf, size_t errlen);
 
+/* ---- one read over several ranks: every rank makes the text of its own chunk range --------------------
+ * The gather above leaves the seam merge and the text of a whole chromosome to rank 0 (46 ms for 200 Mb, whatever
+ * the number of GPUs).  The merge (main.cpp:287-302) is a scan whose state is one index, so a rank can run it on its
+ * own records once it knows where the scan enters them -- which follows from a few records either side of every
+ * range boundary (csrc/sd_seam.hpp).  Protocol, host only, no record leaves its rank:
+ *   1. sd_range_assemble_begin[_files]: chunk offsets, the merge and text of the reads that lie completely inside
+ *      [chunk_lo, chunk_hi), the scan of the crossing pieces from an assumed entry, the text of their middle part;
+ *      fills `edge` (POD, 176 bytes) for the exchange;
+ *   2. the caller all-gathers the edges (torch.distributed all_gather_object in shard.py);
+ *   3. sd_range_assemble_text(h, edges, world, rank, &bytes): the real entry from the chain of edges, the first
+ *      and last rows of the crossing pieces; SD_ERR_UNSUPPORTED when some rank's edge has ok == 0 (an empty share or
+ *      a crossing piece of fewer than 32 rows): gather on rank 0 instead;
+ *   4. the caller all-gathers `bytes`, rank 0 creates the file at its final size, and every rank calls
+ *      sd_range_assemble_write(h, path, offset of its text).
+ * The concatenation of the ranks' texts is byte for byte what sd_assemble_tsv makes of all records. */
+typedef struct sd_seam_edge {
+    int32_t ok;          /* 0: this share cannot take part */
+    int32_t has_front;   /* the share begins inside a read (its first records continue the previous rank's last read) */
+    int32_t has_back;    /* the share ends inside a read */
+    int32_t through;     /* both, and it is the same read: the share lies inside one read */
+    int32_t head[8][2];  /* start, end (read coordinates) of the first eight records of the front piece */
+    int32_t tail[8][2];  /* ... of the last eight records of the back piece */
+    int8_t exit_of[8];   /* position 0..7 at which the scan reaches the last eight records, by entry position 0..7 */
+    int64_t reserved;
+} sd_seam_edge;
+typedef struct sd_range_asm sd_range_asm;
+int sd_range_assemble_begin(const char* const* read_names, const int64_t* read_lens, int32_t n_reads,
+                            const char* const* mono_names, int32_t n_mono, const sd_params* p, int64_t chunk_lo,
+                            int64_t chunk_hi, const sd_rec* recs, const int64_t* rec_off, sd_seam_edge* edge,
+                            sd_range_asm** h, char* errbuf, size_t errlen);
+/* names and lengths from the FASTA index; the range is block_range(n_chunks, rank, world) as in
+ * sd_decompose_files_range */
+int sd_range_assemble_begin_files(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank,
+                                  int32_t world, const sd_rec* recs, const int64_t* rec_off, sd_seam_edge* edge,
+                                  sd_range_asm** h, char* errbuf, size_t errlen);
+int sd_range_assemble_text(sd_range_asm* h, const sd_seam_edge* edges, int32_t world, int32_t rank, int64_t* text_bytes,
+                           char* errbuf, size_t errlen);
+/* the text into the existing file `path` at byte `offset` (no truncation), or into `buf` (text_bytes of room) */
+int sd_range_assemble_write(sd_range_asm* h, const char* path, int64_t offset, char* errbuf, size_t errlen);
+int sd_range_assemble_copy(sd_range_asm* h, char* buf, int64_t room);
+/* stage times of this handle in ms: [0] begin, [1] of it merge + text of complete reads, [2] assumed scans + text
+ * made ahead, [3] sd_range_assemble_text, [4] rows printed by it (repaired head + tail), [5] 1 if the real scan joined
+ * the assumed one too late and the piece was formatted again, [6] write */
+void sd_range_assemble_stats(sd_range_asm* h, double out[8]);
+void sd_range_assemble_free(sd_range_asm* h);
+
 /* ---- engine: device-resident batches (what bench.py and the parity tests drive) ------------ */
 typedef struct sd_engine sd_engine;
 

@@ -37,6 +37,8 @@ EXPORTS = [
     "sd_host_stage_rates", "sd_run_files_range", "sd_plan_info", "sd_write_parts_selftest", "sd_convert_raw_tsv_range",
     "sd_write_records", "sd_read_records", "sd_records_free", "sd_records_to_raw_tsv", "sd_decompose_files_records",
     "sd_run_files_records",
+    "sd_range_assemble_begin", "sd_range_assemble_begin_files", "sd_range_assemble_text", "sd_range_assemble_write",
+    "sd_range_assemble_copy", "sd_range_assemble_stats", "sd_range_assemble_free",
 ]
 
 
@@ -810,6 +812,130 @@ def assemble_files_tsv(reads_fa, monomers_fa, recs, rec_off, raw_tsv_out, **kw):
                                  o.ctypes.data, len(o) - 1, os.fsencode(raw_tsv_out), err, 4096)
     if rc != SD_OK:
         raise SdError(rc, err.value.decode(errors="replace"))
+
+
+class SeamEdge(C.Structure):
+    """sd_seam_edge (include/sd_hip.h): what a rank publishes about the records either side of its range boundaries."""
+    _fields_ = [("ok", C.c_int32), ("has_front", C.c_int32), ("has_back", C.c_int32), ("through", C.c_int32),
+                ("head", (C.c_int32 * 2) * 8), ("tail", (C.c_int32 * 2) * 8), ("exit_of", C.c_int8 * 8),
+                ("reserved", C.c_int64)]
+
+
+class RangeAssembler:
+    """One rank's part of the raw TSV of a job sharded by chunk range (sd_range_assemble_*, include/sd_hip.h):
+         a = RangeAssembler.from_files(reads_fa, monomers_fa, rank, world, recs, rec_off, **params)   # or .from_lists
+         edges = <all-gather of a.edge (bytes)>
+         nbytes = a.text(edges)            # SdError(SD_ERR_UNSUPPORTED): gather on rank 0 instead
+         a.write(path, offset) / a.bytes()
+    Host only; the concatenation of the ranks' texts equals assemble_tsv of all records."""
+
+    def __init__(self, handle, edge, keep):
+        self._h = handle
+        self._keep = keep
+        self.edge = bytes(edge)
+        self.nbytes = None
+
+    @staticmethod
+    def _bind(L):
+        L.sd_range_assemble_begin.restype = C.c_int
+        L.sd_range_assemble_begin_files.restype = C.c_int
+        L.sd_range_assemble_text.restype = C.c_int
+        L.sd_range_assemble_write.restype = C.c_int
+        L.sd_range_assemble_copy.restype = C.c_int
+        L.sd_range_assemble_stats.restype = None
+        L.sd_range_assemble_free.restype = None
+        L.sd_range_assemble_free.argtypes = [C.c_void_p]
+        L.sd_range_assemble_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.sd_range_assemble_text.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_char_p, C.c_size_t]
+        L.sd_range_assemble_write.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_size_t]
+        L.sd_range_assemble_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+
+    @classmethod
+    def from_files(cls, reads_fa, monomers_fa, rank, world, recs, rec_off, **kw):
+        import numpy as np
+        L = load()
+        cls._bind(L)
+        p = make_params(**kw)
+        r = np.ascontiguousarray(recs, dtype=_rec_dtype())
+        o = np.ascontiguousarray(rec_off, dtype=np.int64)
+        edge, h = SeamEdge(), C.c_void_p()
+        err = C.create_string_buffer(4096)
+        rc = L.sd_range_assemble_begin_files(os.fsencode(reads_fa), os.fsencode(monomers_fa), C.byref(p), C.c_int32(rank),
+                                             C.c_int32(world), C.c_void_p(r.ctypes.data), C.c_void_p(o.ctypes.data),
+                                             C.byref(edge), C.byref(h), err, C.c_size_t(4096))
+        if rc != SD_OK:
+            raise SdError(rc, err.value.decode(errors="replace"))
+        return cls(h, edge, (r, o))
+
+    @classmethod
+    def from_lists(cls, read_names, read_lens, mono_names, chunk_lo, chunk_hi, recs, rec_off, **kw):
+        import numpy as np
+        L = load()
+        cls._bind(L)
+        p = make_params(**kw)
+        rn = [_b(s) for s in read_names]
+        mn = [_b(s) for s in mono_names]
+        rl = (C.c_int64 * max(len(rn), 1))(*[int(x) for x in read_lens])
+        r = np.ascontiguousarray(recs, dtype=_rec_dtype())
+        o = np.ascontiguousarray(rec_off, dtype=np.int64)
+        edge, h = SeamEdge(), C.c_void_p()
+        err = C.create_string_buffer(4096)
+        rc = L.sd_range_assemble_begin(_strs(rn), rl, C.c_int32(len(rn)), _strs(mn), C.c_int32(len(mn)), C.byref(p),
+                                       C.c_int64(chunk_lo), C.c_int64(chunk_hi), C.c_void_p(r.ctypes.data),
+                                       C.c_void_p(o.ctypes.data), C.byref(edge), C.byref(h), err, C.c_size_t(4096))
+        if rc != SD_OK:
+            raise SdError(rc, err.value.decode(errors="replace"))
+        return cls(h, edge, (r, o))
+
+    def text(self, edges, rank):
+        """edges: the edges of all ranks in rank order (bytes each).  Returns the bytes of this rank's text."""
+        L = load()
+        arr = (SeamEdge * len(edges))()
+        for k, e in enumerate(edges):
+            if e is None or len(e) != C.sizeof(SeamEdge):
+                raise SdError(SD_ERR_UNSUPPORTED, "a rank published no edge")
+            C.memmove(C.byref(arr[k]), e, C.sizeof(SeamEdge))
+        n = C.c_int64()
+        err = C.create_string_buffer(4096)
+        rc = L.sd_range_assemble_text(self._h, arr, len(edges), int(rank), C.byref(n), err, 4096)
+        if rc != SD_OK:
+            raise SdError(rc, err.value.decode(errors="replace"))
+        self.nbytes = n.value
+        return n.value
+
+    def write(self, path, offset):
+        L = load()
+        err = C.create_string_buffer(4096)
+        rc = L.sd_range_assemble_write(self._h, os.fsencode(path), int(offset), err, 4096)
+        if rc != SD_OK:
+            raise SdError(rc, err.value.decode(errors="replace"))
+
+    def bytes(self):
+        L = load()
+        buf = C.create_string_buffer(max(self.nbytes, 1))
+        rc = L.sd_range_assemble_copy(self._h, buf, self.nbytes)
+        if rc != SD_OK:
+            raise SdError(rc, "sd_range_assemble_copy")
+        return buf.raw[:self.nbytes]
+
+    def stats(self):
+        L = load()
+        out = (C.c_double * 8)()
+        L.sd_range_assemble_stats(self._h, out)
+        return {"begin_ms": out[0], "complete_reads_ms": out[1], "assumed_scan_and_text_ahead_ms": out[2],
+                "text_ms": out[3], "rows_printed_after_exchange": int(out[4]), "formatted_again": bool(out[5]),
+                "write_ms": out[6]}
+
+    def close(self):
+        if self._h:
+            load().sd_range_assemble_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def assemble_tsv(read_names, read_lens, mono_names, recs, rec_off, **kw):

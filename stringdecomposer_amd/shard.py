@@ -6,11 +6,14 @@ A chunk's DP depends only on its <= part+overlap bases and the (replicated) temp
     single-GPU engine on its block;
   * decompose_sharded (one job, strong scaling): the chunks of ALL reads form one global table and
     rank g takes the contiguous chunk range block_range(n_chunks, g, G) -- a single 200-Mb sequence
-    (BASELINE config 5) spreads over the GPUs exactly like a million reads.  The compact
-    records (24 B per ~171 bp) are gathered on rank 0, which applies the chunk offsets, the seam merge
-    and the TSV formatting (host only).
+    (BASELINE config 5) spreads over the GPUs exactly like a million reads.  Every rank
+    then turns ITS records into ITS part of the raw TSV -- chunk offsets, seam merge, text (host only): the
+    merge of a read that crosses range boundaries needs eight records from either side of a boundary, which
+    the ranks exchange as 160-byte edges (_assemble_by_ranks, csrc/sd_seam.hpp), and the ranks write their
+    texts into the output file at their offsets.  Only when a share is empty or a crossing piece is
+    shorter than 32 records are the compact records (24 B per ~171 bp) gathered on rank 0 instead.
 torch.distributed (RCCL on GPUs, gloo in the CPU tests) is used only for the barrier / max-over-ranks
-timing and for that gather; there is no collective on the data path.
+timing and for those small exchanges; there is no collective on the data path.
 """
 import os
 
@@ -113,6 +116,83 @@ def _name_reads(msg, read_names):
     return re.sub(r"Sequence #(\d+)", sub, msg)
 
 
+def _edges_ok(edges):
+    from . import lib
+    return all(e is not None and lib.SeamEdge.from_buffer_copy(e).ok for e in edges)
+
+
+def _assemble_by_ranks(dist, rank, ws, make, raw_tsv_out=None, stats=None):
+    """Every rank makes the raw TSV text of its own chunk range (lib.RangeAssembler: `make()` builds this rank's).
+    Two small exchanges -- the 160-byte edges, then the text sizes -- and, with `raw_tsv_out`, all ranks write into
+    the file (created at its final size by rank 0) at their offsets; without it the texts are gathered on rank 0.
+    Returns None when the job cannot be shared this way (decided identically on all ranks from the edges: gather
+    the records instead), else (True, text-or-None).  A failure on any rank is raised on every rank."""
+    import os as _os
+    import time
+    from . import lib
+    if _os.environ.get("SD_SHARD_GATHER"):      # developer knob: the rank-0 assembly of rounds 1-4
+        return None
+    failure, a, edge = None, None, None
+    t0 = time.perf_counter()
+    try:
+        a = make()
+        edge = a.edge
+    except Exception as e:
+        failure = _status_of(e)
+    t1 = time.perf_counter()
+    box = [None] * ws
+    dist.all_gather_object(box, (failure, edge))
+    t2 = time.perf_counter()
+    first = next((b[0] for b in box if b[0] is not None), None)
+    try:
+        if first is not None:
+            raise lib.SdError(*first)
+        edges = [b[1] for b in box]
+        if not _edges_ok(edges):
+            return None
+        n = None
+        try:
+            n = a.text(edges, rank)
+        except Exception as e:
+            failure = _status_of(e)
+        t3 = time.perf_counter()
+        sizes = [None] * ws
+        dist.all_gather_object(sizes, (failure, n))
+        first = next((b[0] for b in sizes if b[0] is not None), None)
+        if first is not None:
+            raise lib.SdError(*first)
+        sizes = [b[1] for b in sizes]
+        t4 = time.perf_counter()
+        text = None
+        if raw_tsv_out is not None:
+            if rank == 0:
+                try:
+                    with open(raw_tsv_out, "wb") as f:
+                        f.truncate(sum(sizes))
+                except Exception as e:
+                    failure = _status_of(e)
+            _raise_first(dist, ws, failure)     # also the barrier in front of the writes
+            try:
+                a.write(raw_tsv_out, sum(sizes[:rank]))
+            except Exception as e:
+                failure = _status_of(e)
+            _raise_first(dist, ws, failure)
+        else:
+            mine = a.bytes()
+            got = [None] * ws if rank == 0 else None
+            dist.gather_object(mine, got, dst=0)
+            text = b"".join(got) if rank == 0 else None
+        if stats is not None:
+            stats.update(a.stats())
+            stats.update({"begin_wall_ms": (t1 - t0) * 1e3, "edge_exchange_ms": (t2 - t1) * 1e3,
+                          "text_wall_ms": (t3 - t2) * 1e3, "size_exchange_ms": (t4 - t3) * 1e3,
+                          "write_or_gather_ms": (time.perf_counter() - t4) * 1e3, "text_bytes": sizes[rank]})
+        return (True, text)
+    finally:
+        if a is not None:
+            a.close()
+
+
 def decompose_sharded(read_names, read_seqs, mono_names, mono_seqs, dist=None, range_fn=None, **params):
     """Raw TSV (bytes) of the whole job on rank 0, None on the other ranks.
 
@@ -123,6 +203,7 @@ def decompose_sharded(read_names, read_seqs, mono_names, mono_seqs, dist=None, r
     import numpy as np
     from . import lib
     rank, local_rank, ws = world() if dist is not None else (0, 0, 1)
+    asm_stats = params.pop("assemble_stats", None)   # a dict that receives the stage times of the rank-local assembly
     part = int(params.get("part_size", 5000))
     overlap = int(params.get("overlap", 500))
     read_lens = [len(s) for s in read_seqs]
@@ -149,6 +230,12 @@ def decompose_sharded(read_names, read_seqs, mono_names, mono_seqs, dist=None, r
         raise lib.SdError(*failure)
     recs = np.ascontiguousarray(recs)
     off = np.ascontiguousarray(off, dtype=np.int64)
+    keep = {k: v for k, v in params.items() if k in ("scoring", "part_size", "overlap", "threads")}
+    if dist is not None and ws > 1:
+        done = _assemble_by_ranks(dist, rank, ws, lambda: lib.RangeAssembler.from_lists(
+            read_names, read_lens, mono_names, lo, hi, recs, off, **keep), stats=asm_stats)
+        if done is not None:
+            return done[1]
     if dist is None or ws == 1:
         parts = [(lo, recs, off)]
     else:
@@ -165,7 +252,6 @@ def decompose_sharded(read_names, read_seqs, mono_names, mono_seqs, dist=None, r
         base += len(r)
     all_off = np.concatenate(offs)
     assert len(all_off) == n_chunks + 1
-    keep = {k: v for k, v in params.items() if k in ("scoring", "part_size", "overlap", "threads")}
     return lib.assemble_tsv(read_names, read_lens, mono_names, all_recs, all_off, **keep)
 
 
@@ -178,6 +264,7 @@ def decompose_files_sharded(reads_fa, monomers_fa, raw_tsv_out, dist, range_fn=N
     import numpy as np
     from . import lib
     rank, local_rank, ws = world()
+    asm_stats = params.pop("assemble_stats", None)
     params = dict(params, device=params.get("device", local_rank))
     fn = range_fn or lib.decompose_files_range
     failure, res = None, None
@@ -187,6 +274,11 @@ def decompose_files_sharded(reads_fa, monomers_fa, raw_tsv_out, dist, range_fn=N
         failure = _status_of(e)
     _raise_first(dist, ws, failure)
     recs, off, lo, hi, n_chunks = res
+    keep = {k: v for k, v in params.items() if k in ("scoring", "part_size", "overlap", "threads")}
+    done = _assemble_by_ranks(dist, rank, ws, lambda: lib.RangeAssembler.from_files(
+        reads_fa, monomers_fa, rank, ws, recs, off, **keep), raw_tsv_out=raw_tsv_out, stats=asm_stats)
+    if done is not None:
+        return True if rank == 0 else None
     box = [None] * ws if rank == 0 else None
     dist.gather_object((lo, recs, off), box, dst=0)
     failure = None
@@ -200,7 +292,6 @@ def decompose_files_sharded(reads_fa, monomers_fa, raw_tsv_out, dist, range_fn=N
                 base += len(r)
             all_off = np.concatenate(offs)
             assert len(all_off) == n_chunks + 1
-            keep = {k: v for k, v in params.items() if k in ("scoring", "part_size", "overlap", "threads")}
             lib.assemble_files_tsv(reads_fa, monomers_fa, all_recs, all_off, raw_tsv_out, **keep)
         except Exception as e:
             failure = _status_of(e)

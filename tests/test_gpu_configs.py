@@ -109,6 +109,22 @@ def test_c5_200mb_single_sequence_chunk_ranges_and_oracle(oracle):
     got = lib.assemble_tsv(["chr"], [len(seq)], mn, recs, off, scoring=sc, threads=th)
     assert hashlib.sha256(got).hexdigest() == hashlib.sha256(one).hexdigest()
     assert one.count(b"\n") > 1_100_000
+    # the multi-GPU form: eight ranks, each makes the text of its own 25-Mb share from its records and the exchanged
+    # edges (csrc/sd_seam.hpp); their texts in rank order are the file
+    asm = []
+    for g in range(8):
+        lo, hi = shard.block_range(n, g, 8)
+        asm.append(lib.RangeAssembler.from_lists(["chr"], [len(seq)], mn, lo, hi, recs[off[lo]:off[hi]], off[lo:hi + 1] - off[lo],
+                                                 scoring=sc, threads=2))
+    edges = [a.edge for a in asm]
+    texts = []
+    for g, a in enumerate(asm):
+        a.text(edges, g)
+        texts.append(a.bytes())
+        st = a.stats()
+        assert not st["formatted_again"] and st["rows_printed_after_exchange"] < 200, st
+        a.close()
+    assert hashlib.sha256(b"".join(texts)).hexdigest() == hashlib.sha256(one).hexdigest()
     # sampled chunks against AlignPartClassicDP (oracle), both sides of every range seam included
     pick = {0, n - 1}
     for lo, hi in ranges:

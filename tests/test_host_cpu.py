@@ -912,3 +912,125 @@ def test_streamed_seam_merge_of_a_huge_read_equals_the_literal_scan():
     for threads in (1, 4):
         got = lib.assemble_tsv(names, read_lens, mono, arr, np.array(off, dtype=np.int64), part_size=part, overlap=ov, threads=threads)
         assert got.decode() == "".join(want)
+
+
+def _seam_records(rnd, read_lens, part, ov, p_overlap, wmax=40):
+    """Per-chunk records whose neighbours overlap with probability p_overlap (every branch of main.cpp:287-302 fires)."""
+    recs, off = [], [0]
+    for rl in read_lens:
+        for (_o, ln) in lib.chunk_plan(rl, part, ov):
+            pos, k = 0, 0
+            while pos < ln - 5 and k <= 60:
+                w = rnd.randint(3, wmax)
+                e = min(ln - 1, pos + w)
+                recs.append((rnd.randrange(6), pos, e, rnd.randint(-5, 30)))
+                pos = max(0, e - rnd.randint(0, w)) if rnd.random() < p_overlap else e + 1 + rnd.randint(0, 3)
+                k += 1
+            off.append(len(recs))
+    return recs, off
+
+
+@pytest.mark.parametrize("p_overlap", [0.05, 0.45, 0.9])
+def test_every_rank_assembles_its_own_chunk_range(p_overlap):
+    """sd_range_assemble_* (csrc/sd_seam.hpp): the seam merge of a read whose chunks are spread over several ranks, made
+    by every rank on its own records from the exchanged edges -- the texts of the ranks in rank order must be the bytes
+    sd_assemble_tsv makes of all records.  Shares inside one read, shares that end / begin inside a read, reads that lie
+    completely inside a share; records that overlap seldom (the real case: the scans join at once), often, and nearly
+    always (the assumed scan and the real one stay apart for long: the piece is formatted again)."""
+    import random
+    import numpy as np
+    from stringdecomposer_amd import shard
+    rnd = random.Random(int(p_overlap * 100) + 5)
+    part, ov = 100, 30
+    rec_dt = lib._rec_dtype()
+    mono = ["m0", "m1", "m2"]
+    again = 0
+    for case in range(12):
+        read_lens = [rnd.choice([40, 900, 2500, 30_000, 120_000]) for _ in range(rnd.randint(1, 6))]
+        if case % 3 == 0:
+            read_lens = [rnd.randint(150_000, 400_000)]          # one chromosome: every share lies inside it
+        names = ["r%d" % i for i in range(len(read_lens))]
+        recs, off = _seam_records(rnd, read_lens, part, ov, p_overlap)
+        arr = np.array(recs, dtype=rec_dt)
+        off = np.array(off, dtype=np.int64)
+        n_chunks = len(off) - 1
+        want = lib.assemble_tsv(names, read_lens, mono, arr, off, part_size=part, overlap=ov, threads=2)
+        for world in (1, 2, 3, 5, 8):
+            asm = []
+            for rank in range(world):
+                lo, hi = shard.block_range(n_chunks, rank, world)
+                asm.append(lib.RangeAssembler.from_lists(names, read_lens, mono, lo, hi, arr[off[lo]:off[hi]], off[lo:hi + 1] - off[lo],
+                                                         part_size=part, overlap=ov, threads=1 + rank % 3))
+            edges = [a.edge for a in asm]
+            shareable = all(lib.SeamEdge.from_buffer_copy(e).ok for e in edges)
+            if not shareable:
+                with pytest.raises(lib.SdError) as ei:
+                    asm[0].text(edges, 0)
+                assert ei.value.code == lib.SD_ERR_UNSUPPORTED
+                # refused only when a share is empty or a crossing piece has fewer than 32 records
+                cs = np.cumsum([0] + [len(lib.chunk_plan(rl, part, ov)) for rl in read_lens])
+                short = False
+                for rank in range(world):
+                    lo, hi = shard.block_range(n_chunks, rank, world)
+                    if hi == lo:
+                        short = True
+                        continue
+                    ra = int(np.searchsorted(cs, lo, side="right")) - 1
+                    rb = int(np.searchsorted(cs, hi - 1, side="right")) - 1
+                    of, ob = lo > cs[ra], hi < cs[rb + 1]
+                    if of and ob and ra == rb:
+                        short |= off[hi] - off[lo] < 32
+                    else:
+                        short |= of and off[min(hi, cs[ra + 1])] - off[lo] < 32
+                        short |= ob and off[hi] - off[max(lo, cs[rb])] < 32
+                assert short, (read_lens, world)
+                continue
+            got = b""
+            for rank, a in enumerate(asm):
+                n = a.text(edges, rank)
+                t = a.bytes()
+                assert len(t) == n
+                got += t
+                again += a.stats()["formatted_again"]
+            assert got == want, (case, world, read_lens)
+            for a in asm:
+                a.close()
+    if p_overlap <= 0.05:
+        assert again == 0
+
+
+def test_rank_local_assembly_when_the_real_scan_never_meets_the_assumed_one():
+    """Records built so that every position of the merge scan jumps three ahead (each record covers the next): scans
+    that enter at positions of different residues never share a position, the text a rank made ahead from the assumed
+    entry is wrong and sd_range_assemble_text formats the piece again -- same bytes as the serial merge."""
+    import numpy as np
+    from stringdecomposer_amd import shard
+    part, ov = 100, 30
+    rec_dt = lib._rec_dtype()
+    mono = ["m0", "m1", "m2"]
+    read_lens = [3000]
+    names = ["chr"]
+    again = 0
+    for per_chunk in (299, 300, 301, 302):
+        recs, off = [], [0]
+        for k, (_o, ln) in enumerate(lib.chunk_plan(read_lens[0], part, ov)):
+            recs.extend([(k % 6, 5, min(95, ln - 1), 7)] * (per_chunk + k % 2))
+            off.append(len(recs))
+        arr = np.array(recs, dtype=rec_dt)
+        off = np.array(off, dtype=np.int64)
+        n_chunks = len(off) - 1
+        want = lib.assemble_tsv(names, read_lens, mono, arr, off, part_size=part, overlap=ov, threads=2)
+        for world in (2, 3, 4, 7):
+            asm = []
+            for rank in range(world):
+                lo, hi = shard.block_range(n_chunks, rank, world)
+                asm.append(lib.RangeAssembler.from_lists(names, read_lens, mono, lo, hi, arr[off[lo]:off[hi]], off[lo:hi + 1] - off[lo],
+                                                         part_size=part, overlap=ov, threads=2))
+            edges = [a.edge for a in asm]
+            got = b""
+            for rank, a in enumerate(asm):
+                a.text(edges, rank)
+                got += a.bytes()
+                again += a.stats()["formatted_again"]
+            assert got == want, (per_chunk, world)
+    assert again > 0

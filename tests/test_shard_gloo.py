@@ -450,3 +450,95 @@ def test_convert_tsv_shared_by_three_ranks_equals_one_process(tmp_path, second_b
                                       second_best=second_best, device=-1)
             got += open(os.path.join(d, "p_final.tsv"), "rb").read()
         assert got == want, w
+
+
+# ---- every rank assembles its own range (csrc/sd_seam.hpp) --------------------------------------------
+_SEAM_READS = [2500, 260_000, 40, 30_000]      # a chromosome over all ranks, small reads either side of it
+_SEAM_PART, _SEAM_OV = 100, 30
+
+
+def _seam_job():
+    """Synthetic per-chunk records (no DP): neighbours overlap often enough for every branch of main.cpp:287-302."""
+    import random
+    import numpy as np
+    from stringdecomposer_amd import lib
+    rnd = random.Random(77)
+    recs, off = [], [0]
+    for rl in _SEAM_READS:
+        for (_o, ln) in lib.chunk_plan(rl, _SEAM_PART, _SEAM_OV):
+            pos, k = 0, 0
+            while pos < ln - 5 and k <= 60:
+                w = rnd.randint(3, 40)
+                e = min(ln - 1, pos + w)
+                recs.append((rnd.randrange(6), pos, e, rnd.randint(-5, 30)))
+                pos = max(0, e - rnd.randint(0, w)) if rnd.random() < 0.3 else e + 1 + rnd.randint(0, 3)
+                k += 1
+            off.append(len(recs))
+    return np.array(recs, dtype=lib._rec_dtype()), np.array(off, dtype=np.int64)
+
+
+def _seam_range_fn(read_seqs, mono_seqs, lo, hi, **_):
+    recs, off = _seam_job()
+    return recs[off[lo]:off[hi]], off[lo:hi + 1] - off[lo]
+
+
+def _seam_files_fn(reads_fa, monomers_fa, rank, ws, **_):
+    recs, off = _seam_job()
+    n = len(off) - 1
+    lo, hi = shard.block_range(n, rank, ws)
+    return recs[off[lo]:off[hi]], off[lo:hi + 1] - off[lo], lo, hi, n
+
+
+def _seam_worker(rank, ws, port, q, tmp):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ws),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist = shard.init_process_group("gloo")
+    names = ["r%d" % i for i in range(len(_SEAM_READS))]
+    seqs = ["A" * n for n in _SEAM_READS]
+    mono = ["m0", "m1", "m2"]
+    st1, st2 = {}, {}
+    out = shard.decompose_sharded(names, seqs, mono, ["ACGT"] * 3, dist=dist, range_fn=_seam_range_fn,
+                                  part_size=_SEAM_PART, overlap=_SEAM_OV, threads=2, assemble_stats=st1)
+    raw = os.path.join(tmp, "raw.tsv")
+    ok = shard.decompose_files_sharded(os.path.join(tmp, "r.fa"), os.path.join(tmp, "m.fa"), raw, dist,
+                                       range_fn=_seam_files_fn, part_size=_SEAM_PART, overlap=_SEAM_OV, threads=2,
+                                       assemble_stats=st2)
+    os.environ["SD_SHARD_GATHER"] = "1"       # the rank-0 assembly of the same job
+    old = shard.decompose_sharded(names, seqs, mono, ["ACGT"] * 3, dist=dist, range_fn=_seam_range_fn,
+                                  part_size=_SEAM_PART, overlap=_SEAM_OV, threads=2)
+    q.put((rank, out, ok, old, st1, st2))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ws", [2, 3])
+def test_every_rank_writes_its_own_part_of_the_raw_tsv(ws, tmp_path):
+    """decompose_sharded / decompose_files_sharded over gloo: the ranks exchange 160-byte edges and text sizes, each
+    makes the text of its own chunk range and writes it into the file at its offset; bytes equal the serial assembly of
+    all records and the gather path (SD_SHARD_GATHER) of the same job."""
+    from stringdecomposer_amd import lib
+    with open(tmp_path / "r.fa", "w") as f:
+        for i, n in enumerate(_SEAM_READS):
+            f.write(">r%d\n%s\n" % (i, "A" * n))
+    with open(tmp_path / "m.fa", "w") as f:
+        for i in range(3):
+            f.write(">m%d\nACGT\n" % i)
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_seam_worker, args=(r, ws, port, q, str(tmp_path))) for r in range(ws)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(ws))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    recs, off = _seam_job()
+    want = lib.assemble_tsv(["r%d" % i for i in range(len(_SEAM_READS))], _SEAM_READS, ["m0", "m1", "m2"], recs, off,
+                            part_size=_SEAM_PART, overlap=_SEAM_OV, threads=2)
+    assert res[0][1] == want and all(r[1] is None for r in res[1:])
+    assert res[0][3] == want
+    assert res[0][2] is True and all(r[2] is None for r in res[1:])
+    assert (tmp_path / "raw.tsv").read_bytes() == want
+    for r in res:       # the rank-local path ran on every rank, for both forms
+        assert r[4].get("text_bytes", 0) > 0 and r[5].get("text_bytes", 0) > 0, r[4]
+    assert sum(r[5]["text_bytes"] for r in res) == len(want)
