@@ -228,13 +228,13 @@ int sd_assemble_tsv(const char* const* read_names, const int64_t* read_lens, int
  * range boundary (csrc/sd_seam.hpp).  Protocol, host only, no record leaves its rank:
  *   1. sd_range_assemble_begin[_files]: chunk offsets, the merge and text of the reads that lie completely inside
  *      [chunk_lo, chunk_hi), the scan of the crossing pieces from an assumed entry, the text of their middle part;
- *      fills `edge` (POD, 176 bytes) for the exchange;
+ *      fills `edge` (POD, 160 bytes) for the exchange;
  *   2. the caller all-gathers the edges (torch.distributed all_gather_object in shard.py);
  *   3. sd_range_assemble_text(h, edges, world, rank, &bytes): the real entry from the chain of edges, the first
  *      and last rows of the crossing pieces; SD_ERR_UNSUPPORTED when some rank's edge has ok == 0 (an empty share or
  *      a crossing piece of fewer than 32 rows): gather on rank 0 instead;
- *   4. the caller all-gathers `bytes`, rank 0 creates the file at its final size, and every rank calls
- *      sd_range_assemble_write(h, path, offset of its text).
+ *   4. the caller all-gathers `bytes` and every rank calls sd_range_assemble_write(h, path, offset of its text,
+ *      total bytes).
  * The concatenation of the ranks' texts is byte for byte what sd_assemble_tsv makes of all records. */
 typedef struct sd_seam_edge {
     int32_t ok;          /* 0: this share cannot take part */
@@ -258,9 +258,19 @@ int sd_range_assemble_begin_files(const char* reads_fa, const char* monomers_fa,
                                   sd_range_asm** h, char* errbuf, size_t errlen);
 int sd_range_assemble_text(sd_range_asm* h, const sd_seam_edge* edges, int32_t world, int32_t rank, int64_t* text_bytes,
                            char* errbuf, size_t errlen);
-/* the text into the existing file `path` at byte `offset` (no truncation), or into `buf` (text_bytes of room) */
-int sd_range_assemble_write(sd_range_asm* h, const char* path, int64_t offset, char* errbuf, size_t errlen);
+/* The text into the file `path` at byte `offset`.  file_bytes >= 0: the file is created if missing and set to that
+ * size first (the sum of all ranks' text_bytes: every rank passes the same value, so no rank has to wait for another);
+ * file_bytes < 0: an existing file, size untouched.  sd_range_assemble_copy: the text into `buf` (text_bytes of room). */
+int sd_range_assemble_write(sd_range_asm* h, const char* path, int64_t offset, int64_t file_bytes, char* errbuf,
+                            size_t errlen);
 int sd_range_assemble_copy(sd_range_asm* h, char* buf, int64_t room);
+/* DP + step 1 in one call (the FASTA is mapped and indexed once, the records never leave the library): what
+ * sd_decompose_files_range followed by sd_range_assemble_begin_files does.  sd_range_assemble_records lends the
+ * share's records (valid until sd_range_assemble_free) for the gather on rank 0 when step 3 refuses. */
+int sd_decompose_files_range_begin(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank,
+                                   int32_t world, sd_seam_edge* edge, sd_range_asm** h, int64_t* chunk_lo,
+                                   int64_t* chunk_hi, int64_t* n_chunks_total, char* errbuf, size_t errlen);
+int sd_range_assemble_records(sd_range_asm* h, const sd_rec** recs, const int64_t** rec_off, int64_t* n_chunks);
 /* stage times of this handle in ms: [0] begin, [1] of it merge + text of complete reads, [2] assumed scans + text
  * made ahead, [3] sd_range_assemble_text, [4] rows printed by it (repaired head + tail), [5] 1 if the real scan joined
  * the assumed one too late and the piece was formatted again, [6] write */

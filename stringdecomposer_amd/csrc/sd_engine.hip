@@ -2333,12 +2333,14 @@ int sd_decompose_chunk_range(const char* const* read_seqs, const int64_t* read_l
 // (no copy of the sequences), takes the contiguous share block_range(n_chunks, rank, world) of the global
 // chunk table and checks the alphabet of the reads that share touches only (main.cpp:329-341 reports the
 // first offending read in file order: the caller raises the error of the lowest failing rank).
-int sd_decompose_files_range(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank,
-                             int32_t world, sd_rec** recs, int64_t** rec_off, int64_t* chunk_lo, int64_t* chunk_hi,
-                             int64_t* n_chunks_total, char* errbuf, size_t errlen) {
-    if (!recs || !rec_off || !reads_fa || !monomers_fa || world < 1 || rank < 0 || rank >= world) return SD_ERR_PARAM;
-    *recs = nullptr;
-    *rec_off = nullptr;
+struct sd_range_asm;
+static int range_asm_from_files(sd::FastaFile& rf, sd::FastaFile& mf, const sd_params* p, int64_t lo, int64_t hi,
+                                sd_rec* recs, int64_t* off, sd_seam_edge* edge, sd_range_asm** hout, std::string& err);
+
+// edge / hout set: the share's records stay with a range assembler (sd_decompose_files_range_begin)
+static int decompose_files_range_impl(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank,
+                                      int32_t world, sd_rec** recs, int64_t** rec_off, int64_t* chunk_lo, int64_t* chunk_hi,
+                                      int64_t* n_chunks_total, sd_seam_edge* edge, sd_range_asm** hout, char* errbuf, size_t errlen) {
     std::string err;
     int rc = validate_params(p, err);
     if (rc) { set_err(errbuf, errlen, err); return rc; }
@@ -2377,8 +2379,35 @@ int sd_decompose_files_range(const char* reads_fa, const char* monomers_fa, cons
                            validate);
     if (rc == SD_OK && col.failed) { rc = SD_ERR_INTERNAL; err = "out of host memory"; }
     if (rc) { set_err(errbuf, errlen, err); return rc; }
+    if (hout) {
+        sd_rec* r = nullptr;
+        int64_t* o = nullptr;
+        col.release(&r, &o);
+        rc = range_asm_from_files(rf, mf, p, lo, hi, r, o, edge, hout, err);   // (takes r / o over, also when it fails)
+        if (rc) { set_err(errbuf, errlen, err); return rc; }
+        return SD_OK;
+    }
     col.release(recs, rec_off);
     return SD_OK;
+}
+
+int sd_decompose_files_range(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank,
+                             int32_t world, sd_rec** recs, int64_t** rec_off, int64_t* chunk_lo, int64_t* chunk_hi,
+                             int64_t* n_chunks_total, char* errbuf, size_t errlen) {
+    if (!recs || !rec_off || !reads_fa || !monomers_fa || world < 1 || rank < 0 || rank >= world) return SD_ERR_PARAM;
+    *recs = nullptr;
+    *rec_off = nullptr;
+    return decompose_files_range_impl(reads_fa, monomers_fa, p, rank, world, recs, rec_off, chunk_lo, chunk_hi, n_chunks_total,
+                                      nullptr, nullptr, errbuf, errlen);
+}
+
+int sd_decompose_files_range_begin(const char* reads_fa, const char* monomers_fa, const sd_params* p, int32_t rank,
+                                   int32_t world, sd_seam_edge* edge, sd_range_asm** h, int64_t* chunk_lo, int64_t* chunk_hi,
+                                   int64_t* n_chunks_total, char* errbuf, size_t errlen) {
+    if (!edge || !h || !reads_fa || !monomers_fa || world < 1 || rank < 0 || rank >= world) return SD_ERR_PARAM;
+    *h = nullptr;
+    return decompose_files_range_impl(reads_fa, monomers_fa, p, rank, world, nullptr, nullptr, chunk_lo, chunk_hi, n_chunks_total,
+                                      edge, h, errbuf, errlen);
 }
 
 // Rank 0 of a sharded job: the records of all chunks in table order -> raw TSV file (names and lengths come
@@ -2498,6 +2527,10 @@ struct sd_range_asm {
     std::vector<std::string> middle;     // text of the reads that lie completely inside the share
     std::vector<const std::string*> order;   // the text, in order (after sd_range_assemble_text)
     bool text_done = false;
+    sd_rec* own_recs = nullptr;          // sd_decompose_files_range_begin: the records of the share stay with the handle
+    int64_t* own_off = nullptr;          // (sd_range_assemble_records lends them for the gather fall-back)
+    int64_t own_chunks = 0;
+    ~sd_range_asm() { std::free(own_recs); std::free(own_off); }
     double st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     void rows_of(size_t c0, size_t c1, size_t lo, const sd_rec* recs, const int64_t* roff, std::vector<sd_rec>& out) const {
@@ -2665,6 +2698,32 @@ int sd_range_assemble_begin_files(const char* reads_fa, const char* monomers_fa,
     return SD_OK;
 }
 
+static int range_asm_from_files(sd::FastaFile& rf, sd::FastaFile& mf, const sd_params* p, int64_t lo, int64_t hi,
+                                sd_rec* recs, int64_t* off, sd_seam_edge* edge, sd_range_asm** hout, std::string& err) {
+    std::unique_ptr<sd_range_asm> h(new sd_range_asm);
+    h->own_recs = recs;
+    h->own_off = off;
+    h->own_chunks = hi - lo;
+    h->rname_store.reserve(rf.recs.size());
+    for (const auto& r : rf.recs) h->rname_store.emplace_back(r.name, r.name_len);
+    for (size_t r = 0; r < rf.recs.size(); ++r)
+        h->reads.push_back(ReadView{h->rname_store[r].c_str(), h->rname_store[r].size(), nullptr, rf.recs[r].len});
+    for (const auto& r : mf.recs) h->tnames.emplace_back(r.name, r.name_len);
+    for (const auto& r : mf.recs) h->tnames.push_back(std::string(r.name, r.name_len) + "'");
+    const int rc = range_asm_begin(h, p, lo, hi, recs, off, edge, err);
+    if (rc) return rc;
+    *hout = h.release();
+    return SD_OK;
+}
+
+int sd_range_assemble_records(sd_range_asm* h, const sd_rec** recs, const int64_t** rec_off, int64_t* n_chunks) {
+    if (!h || !recs || !rec_off || !n_chunks || !h->own_off) return SD_ERR_PARAM;
+    *recs = h->own_recs;
+    *rec_off = h->own_off;
+    *n_chunks = h->own_chunks;
+    return SD_OK;
+}
+
 int sd_range_assemble_text(sd_range_asm* h, const sd_seam_edge* edges, int32_t world, int32_t rank, int64_t* text_bytes,
                            char* errbuf, size_t errlen) {
     if (!h || !edges || !text_bytes || world < 1 || rank < 0 || rank >= world) return SD_ERR_PARAM;
@@ -2735,11 +2794,18 @@ int sd_range_assemble_text(sd_range_asm* h, const sd_seam_edge* edges, int32_t w
     return SD_OK;
 }
 
-int sd_range_assemble_write(sd_range_asm* h, const char* path, int64_t offset, char* errbuf, size_t errlen) {
+int sd_range_assemble_write(sd_range_asm* h, const char* path, int64_t offset, int64_t file_bytes, char* errbuf, size_t errlen) {
     if (!h || !path || offset < 0 || !h->text_done) return SD_ERR_PARAM;
     const double t0 = now_s();
-    const int fd = ::open(path, O_WRONLY);
+    // file_bytes >= 0: every rank creates the file if it is not there and sets its size (the same value on every rank,
+    // so the order of the ranks does not matter and no rank waits for another before it writes)
+    const int fd = file_bytes >= 0 ? ::open(path, O_WRONLY | O_CREAT, 0644) : ::open(path, O_WRONLY);
     if (fd < 0) { set_err(errbuf, errlen, std::string("cannot write ") + path); return SD_ERR_IO; }
+    if (file_bytes >= 0 && ::ftruncate(fd, (off_t)file_bytes) != 0) {
+        ::close(fd);
+        set_err(errbuf, errlen, std::string("cannot size ") + path);
+        return SD_ERR_IO;
+    }
     struct Ref { const std::string* s; size_t size() const { return s->size(); } const char* data() const { return s->data(); } bool empty() const { return s->empty(); } };
     std::vector<Ref> parts;
     for (const std::string* t : h->order) parts.push_back(Ref{t});

@@ -38,7 +38,8 @@ EXPORTS = [
     "sd_write_records", "sd_read_records", "sd_records_free", "sd_records_to_raw_tsv", "sd_decompose_files_records",
     "sd_run_files_records",
     "sd_range_assemble_begin", "sd_range_assemble_begin_files", "sd_range_assemble_text", "sd_range_assemble_write",
-    "sd_range_assemble_copy", "sd_range_assemble_stats", "sd_range_assemble_free",
+    "sd_range_assemble_copy", "sd_range_assemble_stats", "sd_range_assemble_free", "sd_decompose_files_range_begin",
+    "sd_range_assemble_records",
 ]
 
 
@@ -847,7 +848,9 @@ class RangeAssembler:
         L.sd_range_assemble_free.argtypes = [C.c_void_p]
         L.sd_range_assemble_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.sd_range_assemble_text.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_char_p, C.c_size_t]
-        L.sd_range_assemble_write.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_char_p, C.c_size_t]
+        L.sd_range_assemble_write.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_char_p, C.c_size_t]
+        L.sd_decompose_files_range_begin.restype = C.c_int
+        L.sd_range_assemble_records.restype = C.c_int
         L.sd_range_assemble_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 
     @classmethod
@@ -866,6 +869,39 @@ class RangeAssembler:
         if rc != SD_OK:
             raise SdError(rc, err.value.decode(errors="replace"))
         return cls(h, edge, (r, o))
+
+    @classmethod
+    def run_files(cls, reads_fa, monomers_fa, rank, world, **kw):
+        """DP of this rank's share + step 1 in one library call (sd_decompose_files_range_begin): the records stay in the
+        library.  Sets .chunk_lo / .chunk_hi / .n_chunks; .records() copies the records out for the gather fall-back."""
+        L = load()
+        cls._bind(L)
+        p = make_params(**kw)
+        edge, h = SeamEdge(), C.c_void_p()
+        lo, hi, tot = C.c_int64(), C.c_int64(), C.c_int64()
+        err = C.create_string_buffer(4096)
+        rc = L.sd_decompose_files_range_begin(os.fsencode(reads_fa), os.fsencode(monomers_fa), C.byref(p), C.c_int32(rank),
+                                              C.c_int32(world), C.byref(edge), C.byref(h), C.byref(lo), C.byref(hi),
+                                              C.byref(tot), err, C.c_size_t(4096))
+        if rc != SD_OK:
+            raise SdError(rc, err.value.decode(errors="replace"))
+        a = cls(h, edge, None)
+        a.chunk_lo, a.chunk_hi, a.n_chunks = lo.value, hi.value, tot.value
+        return a
+
+    def records(self):
+        """(recs, rec_off) of the share held by the library (copies)."""
+        import numpy as np
+        L = load()
+        recs, off, n = C.POINTER(Rec)(), C.POINTER(C.c_int64)(), C.c_int64()
+        rc = L.sd_range_assemble_records(self._h, C.byref(recs), C.byref(off), C.byref(n))
+        if rc != SD_OK:
+            raise SdError(rc, "this assembler does not hold its records")
+        o = np.ctypeslib.as_array(off, shape=(n.value + 1,)).copy()
+        nrec = int(o[n.value])
+        r = (np.frombuffer(C.string_at(recs, nrec * C.sizeof(Rec)), dtype=_rec_dtype()).copy() if nrec
+             else np.zeros(0, dtype=_rec_dtype()))
+        return r, o
 
     @classmethod
     def from_lists(cls, read_names, read_lens, mono_names, chunk_lo, chunk_hi, recs, rec_off, **kw):
@@ -903,10 +939,11 @@ class RangeAssembler:
         self.nbytes = n.value
         return n.value
 
-    def write(self, path, offset):
+    def write(self, path, offset, file_bytes=-1):
+        """file_bytes >= 0: create the file if missing and set its size first (every rank passes the same total)."""
         L = load()
         err = C.create_string_buffer(4096)
-        rc = L.sd_range_assemble_write(self._h, os.fsencode(path), int(offset), err, 4096)
+        rc = L.sd_range_assemble_write(self._h, os.fsencode(path), int(offset), int(file_bytes), err, 4096)
         if rc != SD_OK:
             raise SdError(rc, err.value.decode(errors="replace"))
 

@@ -375,7 +375,7 @@ def run(sequences, monomers, num_threads, scoring, batch_size, raw_file, ed_thr,
     if ws > 1:
         # launched with `python -m torch.distributed.run --nproc-per-node G bin/stringdecomposer ...`:
         # one process per GPU, each takes a contiguous range of the global chunk table (shard.py);
-        # the records meet on rank 0 through a host-side (gloo) gather -- no device collective.
+        # every rank writes the rows of its own range into the output (shard._assemble_by_ranks) -- no device collective.
         dist = shard.init_process_group("gloo")
         dev = local_rank % max(lib.device_count(), 1)
         common = dict(scoring=(ins, dels, mm, match), part_size=int(batch_size), overlap=int(overlap), ed_thr=int(ed_thr),
@@ -389,8 +389,14 @@ def run(sequences, monomers, num_threads, scoring, batch_size, raw_file, ed_thr,
                                              second_best=second_best, lr_coef=_lr_coef(), **common)
             if ok is True:
                 return True if rank == 0 else None
-            # a single huge sequence (or no final file wanted): shard by chunk range, rank 0 assembles the raw TSV
-            ok = shard.decompose_files_sharded(sequences, monomers, raw_file, dist, **common)
+            # a single huge sequence (or no final file wanted): shard by chunk range; every rank makes the raw TSV text
+            # of its own range (seam merge across the range boundaries from exchanged edges) and writes it at its offset
+            asm_stats = {}
+            ok = shard.decompose_files_sharded(sequences, monomers, raw_file, dist, assemble_stats=asm_stats, **common)
+            if asm_stats:
+                logger.info("raw TSV: this rank wrote %d bytes of it (merge + text %.1f ms before, %.1f ms after the exchange of "
+                            "edges, write %.1f ms)" % (asm_stats["text_bytes"], asm_stats["begin_ms"], asm_stats["text_ms"],
+                                                       asm_stats["write_ms"]))
             if final_file is not None:
                 # ... and convert_tsv (main.py:168-184) is shared again: every rank converts the rows of its byte range of
                 # the raw file (identities on its own GPU), the parts are copied into the final / _alt files

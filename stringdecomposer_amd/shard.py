@@ -121,17 +121,15 @@ def _edges_ok(edges):
     return all(e is not None and lib.SeamEdge.from_buffer_copy(e).ok for e in edges)
 
 
-def _assemble_by_ranks(dist, rank, ws, make, raw_tsv_out=None, stats=None):
+def _assemble_by_ranks(dist, rank, ws, make, raw_tsv_out=None, stats=None, refused=None):
     """Every rank makes the raw TSV text of its own chunk range (lib.RangeAssembler: `make()` builds this rank's).
     Two small exchanges -- the 160-byte edges, then the text sizes -- and, with `raw_tsv_out`, all ranks write into
-    the file (created at its final size by rank 0) at their offsets; without it the texts are gathered on rank 0.
-    Returns None when the job cannot be shared this way (decided identically on all ranks from the edges: gather
-    the records instead), else (True, text-or-None).  A failure on any rank is raised on every rank."""
-    import os as _os
+    the file at their offsets (each sets the file's size to the same total first, none waits for another); without it
+    the texts are gathered on rank 0.  Returns None when the job cannot be shared this way (decided identically on
+    all ranks from the edges: gather the records instead; `refused`, a dict, then receives the share's records when
+    the assembler holds them), else (True, text-or-None).  A failure on any rank is raised on every rank."""
     import time
     from . import lib
-    if _os.environ.get("SD_SHARD_GATHER"):      # developer knob: the rank-0 assembly of rounds 1-4
-        return None
     failure, a, edge = None, None, None
     t0 = time.perf_counter()
     try:
@@ -149,6 +147,9 @@ def _assemble_by_ranks(dist, rank, ws, make, raw_tsv_out=None, stats=None):
             raise lib.SdError(*first)
         edges = [b[1] for b in box]
         if not _edges_ok(edges):
+            if refused is not None and hasattr(a, "chunk_lo"):
+                refused["recs"], refused["off"] = a.records()
+                refused["range"] = (a.chunk_lo, a.chunk_hi, a.n_chunks)
             return None
         n = None
         try:
@@ -165,18 +166,11 @@ def _assemble_by_ranks(dist, rank, ws, make, raw_tsv_out=None, stats=None):
         t4 = time.perf_counter()
         text = None
         if raw_tsv_out is not None:
-            if rank == 0:
-                try:
-                    with open(raw_tsv_out, "wb") as f:
-                        f.truncate(sum(sizes))
-                except Exception as e:
-                    failure = _status_of(e)
-            _raise_first(dist, ws, failure)     # also the barrier in front of the writes
             try:
-                a.write(raw_tsv_out, sum(sizes[:rank]))
+                a.write(raw_tsv_out, sum(sizes[:rank]), sum(sizes))
             except Exception as e:
                 failure = _status_of(e)
-            _raise_first(dist, ws, failure)
+            _raise_first(dist, ws, failure)     # the file is complete when this returns
         else:
             mine = a.bytes()
             got = [None] * ws if rank == 0 else None
@@ -231,7 +225,7 @@ def decompose_sharded(read_names, read_seqs, mono_names, mono_seqs, dist=None, r
     recs = np.ascontiguousarray(recs)
     off = np.ascontiguousarray(off, dtype=np.int64)
     keep = {k: v for k, v in params.items() if k in ("scoring", "part_size", "overlap", "threads")}
-    if dist is not None and ws > 1:
+    if dist is not None and ws > 1 and not os.environ.get("SD_SHARD_GATHER"):   # (knob: the rank-0 assembly of rounds 1-4)
         done = _assemble_by_ranks(dist, rank, ws, lambda: lib.RangeAssembler.from_lists(
             read_names, read_lens, mono_names, lo, hi, recs, off, **keep), stats=asm_stats)
         if done is not None:
@@ -267,18 +261,31 @@ def decompose_files_sharded(reads_fa, monomers_fa, raw_tsv_out, dist, range_fn=N
     asm_stats = params.pop("assemble_stats", None)
     params = dict(params, device=params.get("device", local_rank))
     fn = range_fn or lib.decompose_files_range
-    failure, res = None, None
-    try:
-        res = fn(reads_fa, monomers_fa, rank, ws, **params)
-    except Exception as e:   # ANY failure is exchanged: a rank that left the collective sequence would hang the others
-        failure = _status_of(e)
-    _raise_first(dist, ws, failure)
-    recs, off, lo, hi, n_chunks = res
     keep = {k: v for k, v in params.items() if k in ("scoring", "part_size", "overlap", "threads")}
-    done = _assemble_by_ranks(dist, rank, ws, lambda: lib.RangeAssembler.from_files(
-        reads_fa, monomers_fa, rank, ws, recs, off, **keep), raw_tsv_out=raw_tsv_out, stats=asm_stats)
-    if done is not None:
-        return True if rank == 0 else None
+    gather_only = bool(os.environ.get("SD_SHARD_GATHER"))   # developer knob: the rank-0 assembly of rounds 1-4
+    failure, res = None, None
+    if range_fn is None and not gather_only:
+        # DP of the share and the first step of the assembly in ONE library call: the FASTA is indexed once and the
+        # records stay in the library (a failure of the DP travels with the edges and is raised on every rank)
+        refused = {}
+        done = _assemble_by_ranks(dist, rank, ws, lambda: lib.RangeAssembler.run_files(reads_fa, monomers_fa, rank, ws, **params),
+                                  raw_tsv_out=raw_tsv_out, stats=asm_stats, refused=refused)
+        if done is not None:
+            return True if rank == 0 else None
+        recs, off = refused["recs"], refused["off"]
+        lo, hi, n_chunks = refused["range"]
+    else:
+        try:
+            res = fn(reads_fa, monomers_fa, rank, ws, **params)
+        except Exception as e:   # ANY failure is exchanged: a rank that left the collective sequence would hang the others
+            failure = _status_of(e)
+        _raise_first(dist, ws, failure)
+        recs, off, lo, hi, n_chunks = res
+        if not gather_only:
+            done = _assemble_by_ranks(dist, rank, ws, lambda: lib.RangeAssembler.from_files(
+                reads_fa, monomers_fa, rank, ws, recs, off, **keep), raw_tsv_out=raw_tsv_out, stats=asm_stats)
+            if done is not None:
+                return True if rank == 0 else None
     box = [None] * ws if rank == 0 else None
     dist.gather_object((lo, recs, off), box, dst=0)
     failure = None
