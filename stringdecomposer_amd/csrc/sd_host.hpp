@@ -427,10 +427,19 @@ inline std::atomic<int>& write_parts_hook() {
 inline bool write_parts_fallocate_ok() { return write_parts_hook().load(std::memory_order_relaxed) == 0; }
 
 // parts -> the file `fd` at `off` (advanced by the total).  The cost of a TSV write is the copy into the page cache
-// (300 MB of _alt rows per --second-best batch).  On tmpfs, where write(2) serialises on the inode and a page fault is
-// cheap, large texts are copied by all threads through a shared mapping of the file's new range (65 instead of 88 ms per
-// 297 MB); on a disk file system a page fault of a mapped write allocates blocks one page at a time (measured: 100 ms
-// per 25 MB on the GPU box's /tmp), so everything else is ONE pwritev stream in order, as an fwrite would do.
+// (300 MB of _alt rows per --second-best batch).  On tmpfs, where write(2) serialises on the inode, large texts are copied
+// by all threads through a shared mapping of the file's new range (65 instead of 88 ms per 297 MB); on a disk file system
+// a page fault of a mapped write allocates blocks one page at a time (measured: 100 ms per 25 MB on the GPU box's /tmp),
+// so everything else is ONE pwritev stream in order, as an fwrite would do.
+// A store into a sparse tmpfs mapping that the file system cannot back (full or small /dev/shm) raises SIGBUS and kills
+// the process, so the mapped copy is taken only when fallocate has really reserved the pages of the new range; the
+// pwritev loop below reports the same condition as a short write (-> SD_ERR_IO).  fallocate zeroes the pages on ONE
+// thread (36-49 ms per 280 MB at C4: what bounds that job).  Round 5 measured the alternative that reports failure
+// without a signal and runs on all threads -- every copying thread populating the pages of its part with
+// madvise(MADV_POPULATE_WRITE) -- on the GPU box: 66-87 ms per 294 MB against 35-44 (fallocate) and 43-54 (pwritev), C4
+// 106-123 ms per step against 76-80: concurrent page allocation in one tmpfs file contends harder than one thread
+// zeroing; not kept.  SD_WRITE_PATH=1: pwritev only (A/B).
+// sd_write_parts_test_hook() != 0 makes fallocate "fail" (CPU test of the fall-back).
 template <class Part>
 inline bool write_parts(int fd, int64_t& off, const std::vector<Part>& parts, int threads) {
     std::vector<int64_t> at(parts.size() + 1, off);
@@ -440,10 +449,6 @@ inline bool write_parts(int fd, int64_t& off, const std::vector<Part>& parts, in
     struct statfs fs;
     const bool ram = ::fstatfs(fd, &fs) == 0 && ((unsigned long)fs.f_type == 0x01021994ul /* tmpfs */ ||
                                                  (unsigned long)fs.f_type == 0x858458f6ul /* ramfs */);
-    // The mapped copy is taken only when fallocate has really reserved the pages of the new range: a store into a
-    // sparse tmpfs mapping that the file system cannot back (full or small /dev/shm) raises SIGBUS and kills the
-    // process, where the pwritev loop below reports the same condition as a short write (-> SD_ERR_IO).
-    // sd_write_parts_test_hook() != 0 makes fallocate "fail" (CPU test of the fall-back).
     static const int wmode = [] { const char* e = getenv("SD_WRITE_PATH"); return e ? atoi(e) : 0; }();   // developer A/B: 1 = pwritev only
     if (ram && wmode != 1 && total >= (4 << 20) && write_parts_fallocate_ok() &&
         ::fallocate(fd, 0, (off_t)off, (off_t)total) == 0) {
