@@ -433,6 +433,11 @@ def bench_strong(args):
 _REAL_STDOUT = None
 
 
+# Steps outstanding before the oldest one's rows are collected: with 2 the library's three engines all have a batch (the
+# next fill is already queued when a fill ends; csrc/sd_engine.hip at Pipeline::NS).  SD_BENCH_DEPTH=1 + SD_PIPE_SLOTS=2 is
+# the round-1-4 pipeline (A/B).
+BENCH_DEPTH = max(1, int(os.environ.get("SD_BENCH_DEPTH", "2")))
+
 KERNEL_SOURCES = ("sd_fast_fill.hpp", "sd_fast_dev.hpp", "sd_fast_trace2.hip", "sd_fast_wide_fill.hpp")
 
 
@@ -499,7 +504,7 @@ def main():
                     help="host threads of a rank (default: its share of the usable CPUs, at most 32); e.g. 2 = what a rank gets on a "
                          "16-CPU box shared by 8 ranks")
     ap.add_argument("--sub-batches", type=int, default=1,
-                    help="device batches per step (two batches are in flight, across steps; 1 is fastest: the "
+                    help="device batches per step (three batches are in flight, across steps; 1 is fastest: the "
                          "persistent kernels want >= 2 chunks per resident wave)")
     args = ap.parse_args()
 
@@ -550,7 +555,7 @@ def main():
     # ---- the timed region: SURVEY.md 8(d) -- sequences in host memory -> chunk -> 2-bit pack -> H2D ->
     # fill -> traceback -> compaction -> D2H -> per-read assembly (chunk offsets, seam merge) -> rows in
     # host memory.  Every step submits the rank's whole read set; the stream cuts it into sub-batches
-    # and keeps two of them in flight on two HIP streams, across step boundaries (a long job is a
+    # and keeps three of them in flight (fills alternate between two HIP streams), across step boundaries (a long job is a
     # stream of such batches), so packing / upload / assembly run under the kernels of the neighbours.
     readset = lib.ReadSet(rs)
 
@@ -564,7 +569,7 @@ def main():
         st = lib.Stream(ms, sub_batches=args.sub_batches, device=local_rank, kernel=kernel, threads=threads,
                         ed_thr=args.ed_thr, pipe_mode=pipe_mode)
         inf = st.info()
-        for _ in range(max(warmup, 2)):   # at least one step per pipeline slot: buffers of both engines exist
+        for _ in range(max(warmup, 3)):   # at least one step per pipeline slot: buffers of all engines exist
             st.submit(readset)
             st.collect()
         a = st.stats()
@@ -574,7 +579,7 @@ def main():
         c0 = os.times()
         t0 = time.perf_counter()
         nrows = 0
-        depth = int(os.environ.get("SD_BENCH_DEPTH", "1"))   # developer A/B: steps kept outstanding before collecting
+        depth = BENCH_DEPTH   # steps kept outstanding before the oldest is collected
         out = 0
         step_t = [] if os.environ.get("SD_BENCH_STEP_TIMES") else None   # developer: wall time of every step on stderr
         for k in range(steps):
@@ -793,9 +798,11 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": info["cells"].split("/")[0],
         "data": "synthetic",
         "timed_region": "sequences in host memory -> chunk -> 2-bit pack -> H2D -> fill -> traceback -> compaction -> "
-                        "D2H -> per-read assembly -> rows in host memory (SURVEY 8(d)); %d device batch(es) per step, two "
-                        "batches in flight (pinned staging, copies on their own streams), pipelined across steps; kernel "
-                        "streams: %s" % (args.sub_batches, "one, in order (pipe_mode 0)" if args.pipe_mode == 0 else
+                        "D2H -> per-read assembly -> rows in host memory (SURVEY 8(d)); %d device batch(es) per step, %d "
+                        "batches in flight (pinned staging, copies on their own streams), pipelined across steps: a step's "
+                        "rows are collected when %d later step(s) have been submitted; every step's rows are in host memory "
+                        "inside the timed region; kernel streams: %s" % (
+                            args.sub_batches, BENCH_DEPTH + 1, BENCH_DEPTH, "one, in order (pipe_mode 0)" if args.pipe_mode == 0 else
                                          "overlapped (pipe_mode %d, the library default is 2)" % args.pipe_mode),
         "config": {"workload": "%s: synthetic %d reads x %d bp per GPU, %d monomers (~171 bp) + reverse complements, "
                                "default scoring -1,-1,-1,1, part 5000 / overlap 500" % (

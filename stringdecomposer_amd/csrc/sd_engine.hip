@@ -1391,7 +1391,7 @@ struct TemplateSet {
 };
 }  // namespace
 
-// Device pipeline: up to two batches of chunks in flight on two engines / two non-blocking streams.
+// Device pipeline: up to three batches of chunks in flight on three engines (fills alternate between two streams).
 // push() packs a batch into the engine's pinned staging buffer, starts its H2D copy and enqueues its
 // kernels (all asynchronous); pop() waits for the oldest batch, brings its records into pinned host
 // memory and hands them to that batch's sink.  While the device works on batch b the host packs and
@@ -1405,7 +1405,12 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 struct Pipeline {
     static constexpr int NSMAX = 3;
-    int NS = 2;                                    // batches in flight (SD_PIPE_SLOTS=3: developer A/B)
+    // Batches in flight.  Three since round 5: with two, the engine of batch b is busy until b's traceback -- which shares
+    // the machine with the fill of b+1 at low priority and so ends with it -- has been fetched; only then can b+2 be packed
+    // and enqueued, and every second fill ended with nothing but two tracebacks behind it (SD_TIMELINE=1 shows it: 4-5 ms
+    // of a 28-ms pair).  With a third engine the next fill is already queued: C2 14.3 -> 13.7 ms per step on the same box
+    // (a caller of the stream form gets that with two jobs outstanding before it collects).  SD_PIPE_SLOTS=2: A/B.
+    int NS = 3;
     sd_params p{};
     std::vector<const char*> mseq;
     std::vector<int32_t> mlen;
@@ -1444,6 +1449,9 @@ struct Pipeline {
     double pack_s = 0, wait_s = 0, sink_s = 0;
     int64_t launches = 0, batches = 0, rows = 0;
 
+    const bool timeline = getenv("SD_TIMELINE") != nullptr;   // developer knob, see pop_fetch
+    hipEvent_t tl_ref = nullptr;
+    double tl_host0 = 0, tl_push0[NSMAX] = {0, 0, 0}, tl_push1[NSMAX] = {0, 0, 0};
     bool restart_idle = false;   // an idle pipeline starts over at slot 0 (see push)
     bool ident_ok = false;   // a cached pipeline's engines carry the identity tables of their job (run_files_impl)
     // a pipeline kept from an earlier job with the same parameters and monomers: new borrowed arrays, fresh counters
@@ -1468,7 +1476,7 @@ struct Pipeline {
         if (rc == SD_OK && on_engine) on_engine(eng[0]);
         return rc;
     }
-    // rows one batch may hold: <= 64 M (~1200 reads of 50 kb, 18 GB of checkpoints) and <= 27 % of the free HBM.
+    // rows one batch may hold: <= 64 M (~1200 reads of 50 kb, 18 GB of checkpoints) and <= 80 % / NS of the free HBM.
     // The kernels are persistent -- 4096 resident waves pull chunks from a queue -- so a launch is efficient
     // only with a few chunks per wave: batches are kept large (C2's 10 000 chunks are ONE batch; cutting them
     // into 4 x 2 500 costs 1.4x, measured) and overlap comes from pipelining whole batches.  Larger batches
@@ -1480,7 +1488,7 @@ struct Pipeline {
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             // per row: B + argB + records (24 B) + fast-family checkpoints (P*256 B every FAST_R rows)
             const double per_row = 26.0 + (eng[0]->family == 2 ? eng[0]->fplan.P * 256.0 * eng[0]->fplan.waves / sd::FAST_R : 0.0);
-            budget = std::min<int64_t>(budget, (int64_t)(0.27 * (double)(free_b + held_bytes()) / per_row));
+            budget = std::min<int64_t>(budget, (int64_t)(0.8 / NS * (double)(free_b + held_bytes()) / per_row));
             budget = std::max<int64_t>(budget, (int64_t)p.part_size + p.overlap);
         }
         if (const char* ev = getenv("SD_BATCH_ROWS")) { const long long v = atoll(ev); if (v > 0) budget = v; }  // developer A/B
@@ -1553,6 +1561,14 @@ struct Pipeline {
         }
         make_streams();
         const double t0 = now_s();
+        if (timeline && !tl_ref && fill_st) {
+            if (hipEventCreate(&tl_ref) == hipSuccess) {
+                (void)hipEventRecord(tl_ref, fill_st);
+                (void)hipEventSynchronize(tl_ref);
+                tl_host0 = now_s();
+            } else tl_ref = nullptr;
+        }
+        tl_push0[k] = t0;
         eng[k]->copy_stream = copy_st[k];
         rc = load_chunks_impl(eng[k], cptr, clen, copy_st[k] ? copy_st[k] : fill_st, eb, sizeof eb);
         hipStream_t fs = (fill_st2 && (pushed & 1)) ? fill_st2 : fill_st;
@@ -1560,6 +1576,7 @@ struct Pipeline {
         eng[k]->slice_end = slice_end;
         if (rc == SD_OK) rc = engine_run2(eng[k], fs, trace_st ? trace_st : fs, eb, sizeof eb);
         pack_s += now_s() - t0;
+        tl_push1[k] = now_s();
         if (rc) return rc;
         sinks[k] = std::move(sink);
         ++pushed;
@@ -1655,6 +1672,19 @@ struct Pipeline {
         }
         float ms[4];
         if (sd_engine_timings(e, ms) == SD_OK) { fill_ms += ms[0]; trace_ms += ms[1]; compact_ms += ms[2]; run_ms += ms[3]; }
+        if (timeline && tl_ref && e->family == 2 && !e->chunks.empty()) {
+            // developer knob SD_TIMELINE=1: where each kernel of the batch began and ended on the DEVICE clock (ms since the
+            // pipeline's reference event) next to the host's clock for its enqueue and fetch -- shows whether the device waited
+            float f0 = 0, f1 = 0, t0e = 0, t1e = 0, c1 = 0;
+            (void)hipEventElapsedTime(&f0, tl_ref, e->ev_fill[0]);
+            (void)hipEventElapsedTime(&f1, tl_ref, e->ev_fill[1]);
+            (void)hipEventElapsedTime(&t0e, tl_ref, e->ev_trace[0]);
+            (void)hipEventElapsedTime(&t1e, tl_ref, e->ev_trace[1]);
+            (void)hipEventElapsedTime(&c1, tl_ref, e->ev_cmp1);
+            std::fprintf(stderr, "[sd timeline] batch %llu slot %d: device fill %.2f-%.2f trace %.2f-%.2f compact end %.2f | host enqueue %.2f-%.2f fetch done %.2f\n",
+                         (unsigned long long)popped, k, f0, f1, t0e, t1e, c1, (tl_push0[k] - tl_host0) * 1e3, (tl_push1[k] - tl_host0) * 1e3,
+                         (now_s() - tl_host0) * 1e3);
+        }
         if (e->ident_mode && !e->chunks.empty()) {
             float im = 0.f;
             if (hipEventElapsedTime(&im, e->ev_id0, e->ev_id1) == hipSuccess) ident_ms += im;

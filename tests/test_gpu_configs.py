@@ -9,6 +9,7 @@
       batches: sampled reads byte-for-byte against the oracle, structural invariants on every row.
 """
 import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -17,7 +18,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import GOLDEN, ROOT
 
 import edlib_ref
 from stringdecomposer_amd import lib, shard, synth
@@ -109,6 +110,12 @@ def test_c5_200mb_single_sequence_chunk_ranges_and_oracle(oracle):
     got = lib.assemble_tsv(["chr"], [len(seq)], mn, recs, off, scoring=sc, threads=th)
     assert hashlib.sha256(got).hexdigest() == hashlib.sha256(one).hexdigest()
     assert one.count(b"\n") > 1_100_000
+    # every row of the 200-Mb job against the REAL reference: sha256 of what oracle/_ref/dp printed for this sequence in the
+    # build container (tests/golden/make_fullsize_hashes.py; 4-8 minutes of the reference's CPU path, not repeated here)
+    with open(os.path.join(GOLDEN, "fullsize_sha256.json")) as f:
+        gold = json.load(f)["c5"]
+    assert one.count(b"\n") == gold["rows"] and len(one) == gold["bytes"]
+    assert hashlib.sha256(one).hexdigest() == gold["sha256"]
     # the multi-GPU form: eight ranks, each makes the text of its own 25-Mb share from its records and the exchanged
     # edges (csrc/sd_seam.hpp); their texts in rank order are the file
     asm = []

@@ -163,6 +163,12 @@ def test_full_c2_sample_of_200_reads_equals_the_reference_binary(tmp_path):
     t0 = lib.guard_trips()
     got = lib.decompose(rn, rs, mn, ms, threads=8)
     assert lib.guard_trips() == t0
+    # ALL 1000 reads: the sha256 of what the reference binary printed for this input in the build container
+    # (tests/golden/make_fullsize_hashes.py; a hash of expected output, the GPU box needs no reference for it)
+    with open(os.path.join(GOLDEN, "fullsize_sha256.json")) as f:
+        gold = json.load(f)["c2"]
+    assert got.count(b"\n") == gold["rows"] and len(got) == gold["bytes"]
+    assert hashlib.sha256(got).hexdigest() == gold["sha256"]
     by_read = {}
     for line in got.split(b"\n")[:-1]:
         by_read.setdefault(line[:line.index(b"\t")], []).append(line)
