@@ -340,10 +340,13 @@ int sd_plan_info(const sd_params* p, const char* const* mono_seqs, const int32_t
 
 /* ---- streaming form: sequences in host memory -> rows in host memory ------------------------
  * AlignReadsSet (main.cpp:67-122) without the text: chunk table (:70-81), DP + traceback per chunk
- * (:84-102), per-read flush with chunk offsets and seam merge (:104-117).  A stream keeps two device
+ * (:84-102), per-read flush with chunk offsets and seam merge (:104-117).  A stream keeps up to three device
  * batches in flight: every submitted job (a read set) is cut into `sub_batches` device batches of
- * consecutive chunks; while the device works on one batch the host packs and uploads the next (pinned
- * staging, asynchronous copies) and assembles the previous one, across job boundaries.  This is the
+ * consecutive chunks; while the device works on one batch the host packs and uploads the next ones (pinned
+ * staging, asynchronous copies) and assembles the previous one, across job boundaries.  A caller whose jobs
+ * are one batch each keeps the device busiest with TWO jobs outstanding before it collects the oldest (the
+ * traceback of a batch runs at low priority beside the next fill and ends with it: with one job outstanding
+ * the job after that is enqueued late).  This is the
  * region SURVEY.md 8(d) defines the throughput metric on, and what bench.py times.
  * Sequences are NOT validated here (they went through sd_fasta_load / sd_decompose's check). */
 typedef struct sd_stream sd_stream;
