@@ -2756,10 +2756,18 @@ int sd_range_assemble_records(sd_range_asm* h, const sd_rec** recs, const int64_
 
 int sd_range_assemble_text(sd_range_asm* h, const sd_seam_edge* edges, int32_t world, int32_t rank, int64_t* text_bytes,
                            char* errbuf, size_t errlen) {
-    if (!h || !edges || !text_bytes || world < 1 || rank < 0 || rank >= world) return SD_ERR_PARAM;
+    if (!h || !edges || !text_bytes || world < 1 || rank < 0 || rank >= world || h->text_done) return SD_ERR_PARAM;
     const double t0 = now_s();
     const sd::SeamEntry en = sd::seam_resolve(edges, world, rank);
     if (!en.ok) { set_err(errbuf, errlen, "a share of this job cannot assemble its own range"); return SD_ERR_UNSUPPORTED; }
+    {   // the edges must describe THIS handle at position `rank` (a caller that mixed up the order would get wrong text)
+        const sd_range_asm::Piece* bk = h->back ? h->back.get() : (h->front && h->front->sp.open_back ? h->front.get() : nullptr);
+        const bool has_front = h->front && h->front->sp.open_front;
+        if ((edges[rank].has_front != 0) != has_front || (edges[rank].has_back != 0) != (bk != nullptr)) {
+            set_err(errbuf, errlen, "edges[rank] is not this share's edge");
+            return SD_ERR_PARAM;
+        }
+    }
     int64_t printed = 0;
     auto finish = [&](sd_range_asm::Piece& pc, int e, int32_t prev_end, const int32_t (*next_head)[2]) {
         sd::SeamPiece& sp = pc.sp;

@@ -159,9 +159,12 @@ inline SeamEntry seam_resolve(const sd_seam_edge* edges, int world, int rank) {
     for (int q = 0; q < world; ++q)
         if (!edges[q].ok) { s.ok = false; return s; }
     if (edges[0].has_front || edges[world - 1].has_back) { s.ok = false; return s; }
+    // the whole chain, whatever `rank` is: every rank reaches the same verdict about the same edges
     int e = 0;
     int32_t pe = 0;
-    for (int q = 0; q < rank; ++q) {
+    for (int q = 0; q + 1 < world; ++q) {
+        if (q == rank) { s.e = e; s.prev_end = pe; }
+        if (edges[q].through && !(edges[q].has_front && edges[q].has_back)) { s.ok = false; return s; }
         if (!edges[q].has_back) {
             if (edges[q + 1].has_front) { s.ok = false; return s; }
             e = 0;
@@ -173,8 +176,7 @@ inline SeamEntry seam_resolve(const sd_seam_edge* edges, int world, int rank) {
         if (x < 0 || x > 7) { s.ok = false; return s; }
         e = seam_window(edges[q].tail, edges[q + 1].head, x, pe, [](int) {});
     }
-    s.e = e;
-    s.prev_end = pe;
+    if (rank == world - 1) { s.e = e; s.prev_end = pe; }
     return s;
 }
 

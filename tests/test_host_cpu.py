@@ -1034,3 +1034,18 @@ def test_rank_local_assembly_when_the_real_scan_never_meets_the_assumed_one():
                 again += a.stats()["formatted_again"]
             assert got == want, (per_chunk, world)
     assert again > 0
+    # misuse is refused, not answered with wrong text: the text of a handle is made once, and edges[rank] must be its own
+    lo, hi = shard.block_range(n_chunks, 1, 3)
+    a = lib.RangeAssembler.from_lists(names, read_lens, mono, lo, hi, arr[off[lo]:off[hi]], off[lo:hi + 1] - off[lo], part_size=part, overlap=ov)
+    others = [lib.RangeAssembler.from_lists(names, read_lens, mono, *shard.block_range(n_chunks, g, 3),
+                                            arr[off[shard.block_range(n_chunks, g, 3)[0]]:off[shard.block_range(n_chunks, g, 3)[1]]],
+                                            off[shard.block_range(n_chunks, g, 3)[0]:shard.block_range(n_chunks, g, 3)[1] + 1] - off[shard.block_range(n_chunks, g, 3)[0]],
+                                            part_size=part, overlap=ov).edge for g in (0, 2)]
+    edges = [others[0], a.edge, others[1]]
+    with pytest.raises(lib.SdError) as ei:
+        a.text(edges, 0)            # rank 0's edge has no front piece: not this handle's
+    assert ei.value.code == lib.SD_ERR_PARAM
+    a.text(edges, 1)
+    with pytest.raises(lib.SdError) as ei:
+        a.text(edges, 1)
+    assert ei.value.code == lib.SD_ERR_PARAM
