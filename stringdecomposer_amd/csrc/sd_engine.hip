@@ -1759,6 +1759,21 @@ void plan_batches(const std::vector<CRef>& table, size_t c_lo, size_t c_hi, int6
         c0 = c1;
     }
 }
+// Rows per batch for a pipeline whose engines do not exist yet (the first job of a process, or of a parameter set).
+// Such a job pays for every byte it allocates -- the driver scrubs memory before it hands it out, ~58 ms per GB on the
+// GPU box: the three full-size engines of a 500-Mbp job (25 GB) cost 1.45 s for 0.14 s of device work.  Buffers scale
+// with the rows of a batch, launches get less efficient below two rounds of the persistent kernels (C2 per 50 Mbp:
+// 13.7 ms in batches of 10 000 chunks, 14.0 at 5 000, 15.0 at 2 500, 22.7 at 1 250), so between "one batch" and "many
+// full batches" a job is cut into batches of 14.7 M rows (2 670 chunks of 5.5 kb: 2.1 GB per engine), a job of less than
+// eight of those into eight (down to 7 M rows), and only a job beyond 3 G rows (15 Gbp on this GPU) takes 29 M-row
+// batches, beyond 20 G rows full ones.  A pipeline from the cache has its buffers and takes `budget` as it is.
+// (SD_FRESH_ROWS: developer A/B, 0 = off.)
+int64_t fresh_row_budget(int64_t budget, int64_t job_rows) {
+    int64_t cap = job_rows > 20000000000ll ? budget : job_rows > 3000000000ll ? ((int64_t)28 << 20) : ((int64_t)14 << 20);
+    if (const char* ev = getenv("SD_FRESH_ROWS")) { const long long v = atoll(ev); if (v > 0) cap = v; else return budget; }
+    if (job_rows <= cap) return std::min(budget, cap);                 // (a job of one batch: the callers' own rules)
+    return std::min(budget, std::max<int64_t>(cap / 2, std::min(cap, job_rows / 8)));
+}
 }  // namespace
 
 // Pipelines of finished jobs (sd_run_files, the chunk-range calls), kept for the next job with the same parameters and monomer set: creating
@@ -1841,6 +1856,7 @@ static int run_chunk_batches(const std::vector<ReadView>& reads, const std::vect
     }
     std::unique_ptr<Pipeline> pipe_h = getenv("SD_PIPE_CACHE_OFF") ? nullptr : pipe_cache_take(pkey);
     int rc = SD_OK;
+    const bool from_cache = pipe_h != nullptr;
     if (pipe_h) {
         pipe_h->begin_job(p, ts.mseq.data(), ts.mlen.data(), (int32_t)ts.mseq.size());
     } else {
@@ -1851,7 +1867,15 @@ static int run_chunk_batches(const std::vector<ReadView>& reads, const std::vect
     if (rc) { err = pipe.eb; return rc; }
     pipe.restart_idle = true;
     std::vector<std::pair<size_t, size_t>> batches;
-    plan_batches(table, c_lo, c_hi, pipe.row_budget(), 1, batches);
+    {
+        int64_t budget = pipe.row_budget();
+        if (!from_cache) {
+            int64_t rows = 0;
+            for (size_t c = c_lo; c < c_hi; ++c) rows += table[c].len;
+            if (rows > budget) budget = fresh_row_budget(budget, rows);   // (a job of one batch stays one batch)
+        }
+        plan_batches(table, c_lo, c_hi, budget, 1, batches);
+    }
     std::vector<const char*> cptr;
     std::vector<int32_t> clen;
     for (size_t b = 0; b < batches.size() && rc == SD_OK; ++b) {
@@ -3471,7 +3495,15 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         min_batches = std::max(min_batches, nc >= 4096 ? 8 : nc >= 1024 ? 4 : 1);
     }
     if (const char* ev = getenv("SD_MIN_BATCHES")) min_batches = std::max(1, atoi(ev));   // developer A/B
-    if (rc == SD_OK) plan_batches(job.table, 0, job.table.size(), pipe.row_budget(), min_batches, batches);
+    if (rc == SD_OK) {
+        int64_t budget = pipe.row_budget();
+        if (!reused) {
+            int64_t rows = 0;
+            for (const CRef& c : job.table) rows += c.len;
+            if (rows > budget) budget = fresh_row_budget(budget, rows);   // many batches: smaller ones, smaller engines
+        }
+        plan_batches(job.table, 0, job.table.size(), budget, min_batches, batches);
+    }
     lap("batch plan");
     const double t_setup = now_s() - t_begin;
     if (progress) std::fprintf(stderr, "Prepared reads\n");   // main.cpp:82
