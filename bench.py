@@ -582,7 +582,7 @@ def main():
         depth = BENCH_DEPTH   # steps kept outstanding before the oldest is collected
         out = 0
         step_t = [] if os.environ.get("SD_BENCH_STEP_TIMES") else None   # developer: wall time of every step on stderr
-        for k in range(steps):
+        for k in range(steps):      # (the order of calls of lib.Stream.imap)
             if step_t is not None:
                 step_t.append(time.perf_counter())
             st.submit(readset)

@@ -584,6 +584,25 @@ class Stream:
         self.L.sd_free(off)
         return out
 
+    DEPTH = 2   # jobs outstanding before the oldest is collected: all three engines of the pipeline have a batch then
+
+    def imap(self, jobs, as_lists=False, depth=None):
+        """Rows of every job of the iterable `jobs` (read lists / ReadSets), in order, with `depth` later jobs submitted
+        before a job is collected -- the order of calls that keeps the device busy (sd_hip.h at sd_stream_create: the
+        traceback of a batch ends with the fill of the next one, so with only ONE job outstanding the job after that is
+        enqueued late; bench.py's timed loop is this generator)."""
+        depth = self.DEPTH if depth is None else max(0, int(depth))
+        out = 0
+        for reads in jobs:
+            self.submit(reads)
+            out += 1
+            if out > depth:
+                out -= 1
+                yield self.collect(as_lists=as_lists)
+        while out > 0:
+            out -= 1
+            yield self.collect(as_lists=as_lists)
+
     def stats(self):
         v = (C.c_double * 16)()
         self.L.sd_stream_stats(self.h, v)

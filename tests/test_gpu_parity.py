@@ -533,6 +533,13 @@ def test_stream_rows_equal_oracle(oracle, sub, cap):
         assert txt == oracle.decompose(names, seqs, mn, ms, threads=8)
     with pytest.raises(lib.SdError):
         lib.Stream(ms).collect()
+    # the same jobs through Stream.imap (two later jobs submitted before a job is collected: all three engines busy),
+    # and with every depth from 0 to more jobs than there are
+    for depth in (None, 0, 1, 3, 9):
+        st = lib.Stream(ms, sub_batches=sub, max_batch_rows=cap, threads=6)
+        again = list(st.imap([seqs for _, seqs in jobs] * 2, as_lists=True, depth=depth))
+        st.close()
+        assert again == got + got, depth
 
 
 # (4, 520, 1000) / (3, 700, 2000): monomers beyond 512 bp -- a pair across 16 / 32 lanes (sd_nw_long.hip); the pairs edlib
