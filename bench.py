@@ -466,8 +466,8 @@ def _claimed_stdout():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default, the driver's SCALE runs): every rank owns its own C2 read set; strong: ONE job -- "
                          "--config c3 (a set of reads) or c5 (one 200-Mb sequence) -- split over the ranks exactly as the "
