@@ -830,7 +830,8 @@ def main():
         "amd_direct_dispatch": AMD_DIRECT_DISPATCH,
         # batches repeated with integer cells because the fp16 range guard tripped: must be 0 (checked below)
         "f16_guard_trips": lib.guard_trips(),
-        "rows_out_per_gpu": rows_out, "hbm_workspace_bytes": einfo["workspace_bytes"],
+        "rows_out_per_gpu": rows_out, "hbm_workspace_bytes": einfo["workspace_bytes"] * (BENCH_DEPTH + 1),
+        "hbm_workspace_per_engine_bytes": einfo["workspace_bytes"],   # (one engine per batch in flight)
         # kernels only, batch packed and resident in HBM before the clock starts, one launch per kernel
         "device_resident": None if not res_steps else {
             "bp_per_s": bp_rank * res_steps / dtr, "ms_per_step": dtr / res_steps * 1e3,

@@ -1760,11 +1760,11 @@ void plan_batches(const std::vector<CRef>& table, size_t c_lo, size_t c_hi, int6
     }
 }
 // Rows per batch for a pipeline whose engines do not exist yet (the first job of a process, or of a parameter set).
-// Such a job pays for every byte it allocates -- the driver scrubs memory before it hands it out, ~58 ms per GB on the
-// GPU box: the three full-size engines of a 500-Mbp job (25 GB) cost 1.45 s for 0.14 s of device work.  Buffers scale
+// Such a job pays for every byte it allocates -- the driver scrubs memory before it hands it out, ~29 ms per GB on the
+// GPU box: the three full-size engines of a 500-Mbp job (50 GB) cost 1.45 s for 0.14 s of device work.  Buffers scale
 // with the rows of a batch, launches get less efficient below two rounds of the persistent kernels (C2 per 50 Mbp:
 // 13.7 ms in batches of 10 000 chunks, 14.0 at 5 000, 15.0 at 2 500, 22.7 at 1 250), so between "one batch" and "many
-// full batches" a job is cut into batches of 14.7 M rows (2 670 chunks of 5.5 kb: 2.1 GB per engine), a job of less than
+// full batches" a job is cut into batches of 14.7 M rows (2 670 chunks of 5.5 kb: 4.4 GB per engine), a job of less than
 // eight of those into eight (down to 7 M rows), and only a job beyond 3 G rows (15 Gbp on this GPU) takes 29 M-row
 // batches, beyond 20 G rows full ones.  A pipeline from the cache has its buffers and takes `budget` as it is.
 // (SD_FRESH_ROWS: developer A/B, 0 = off.)
