@@ -943,6 +943,8 @@ def test_bench_line_contract():
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["parity_on_sample"] is True and c["cores"] >= 1 and c["value"] > 0
     assert j["other_pipe_mode"]["pipe_mode"] == 0 and j["device_resident"]["bp_per_s"] > 0
+    # three batches in flight, one engine each (the timed loop keeps two later steps outstanding)
+    assert j["hbm_workspace_bytes"] == 3 * j["hbm_workspace_per_engine_bytes"] and "3 batches in flight" in j["timed_region"]
 
 
 @pytest.mark.gpu
