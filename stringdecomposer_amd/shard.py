@@ -148,8 +148,14 @@ def _assemble_by_ranks(dist, rank, ws, make, raw_tsv_out=None, stats=None, refus
         edges = [b[1] for b in box]
         if not _edges_ok(edges):
             if refused is not None and hasattr(a, "chunk_lo"):
-                refused["recs"], refused["off"] = a.records()
-                refused["range"] = (a.chunk_lo, a.chunk_hi, a.n_chunks)
+                # the caller goes on to a gather: a rank that cannot hand its records back (SdError, MemoryError on a
+                # large share) must not leave the others waiting there -- every rank learns every rank's status first
+                try:
+                    refused["recs"], refused["off"] = a.records()
+                    refused["range"] = (a.chunk_lo, a.chunk_hi, a.n_chunks)
+                except Exception as e:
+                    failure = _status_of(e)
+                _raise_first(dist, ws, failure)
             return None
         n = None
         try:
@@ -172,7 +178,12 @@ def _assemble_by_ranks(dist, rank, ws, make, raw_tsv_out=None, stats=None, refus
                 failure = _status_of(e)
             _raise_first(dist, ws, failure)     # the file is complete when this returns
         else:
-            mine = a.bytes()
+            mine = None
+            try:
+                mine = a.bytes()
+            except Exception as e:
+                failure = _status_of(e)
+            _raise_first(dist, ws, failure)     # nobody enters the gather unless everybody has its text
             got = [None] * ws if rank == 0 else None
             dist.gather_object(mine, got, dst=0)
             text = b"".join(got) if rank == 0 else None

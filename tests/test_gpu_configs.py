@@ -96,8 +96,12 @@ def test_c4_64_monomers_second_best_final_and_alt_tsv(tmp_path, oracle):
 def test_c5_200mb_single_sequence_chunk_ranges_and_oracle(oracle):
     mb = 200
     mn, ms = synth.make_monomers(12, seed=1)
-    rn, rs = synth.make_reads(ms, 1, read_len=2_000_000, seed=7)
-    seq = (rs[0] * (mb // 2 + 1))[: mb * 1_000_000]
+    # 100 independent 2-Mb reads end to end: 40 000 DISTINCT chunks (rounds 4-5 tiled one 2-Mb read; 2 000 000 is a
+    # multiple of the part size, so chunk c and chunk c + 400 were the same bytes)
+    rn, rs = synth.make_reads(ms, mb // 2, read_len=2_000_000, seed=7)
+    seq = b"".join(rs)
+    assert len(seq) == mb * 1_000_000
+    assert len({seq[c * 5000: c * 5000 + 5500] for c in range(0, 40000, 37)}) == len(range(0, 40000, 37))
     sc = (-2, -3, -4, 2)
     th = min(64, os.cpu_count() or 1)
     one = lib.decompose(["chr"], [seq], mn, ms, scoring=sc, threads=th)

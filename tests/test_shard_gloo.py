@@ -542,3 +542,77 @@ def test_every_rank_writes_its_own_part_of_the_raw_tsv(ws, tmp_path):
     for r in res:       # the rank-local path ran on every rank, for both forms
         assert r[4].get("text_bytes", 0) > 0 and r[5].get("text_bytes", 0) > 0, r[4]
     assert sum(r[5]["text_bytes"] for r in res) == len(want)
+
+
+class _FailingAssembler:
+    """A RangeAssembler whose `bytes()` or `records()` raises on one rank (those two calls could fail on one
+    rank only, MemoryError on a 50-MB share, and the others then waited in gather_object for ever)."""
+
+    def __init__(self, inner, fail_at, refuse, lo, hi, n):
+        self._a, self._fail, self._refuse = inner, fail_at, refuse
+        self.chunk_lo, self.chunk_hi, self.n_chunks = lo, hi, n
+        self._share = None
+
+    @property
+    def edge(self):
+        return None if self._refuse else self._a.edge       # an edge of None makes every rank take the fall-back
+
+    def text(self, edges, rank):
+        return self._a.text(edges, rank)
+
+    def bytes(self):
+        if self._fail == "bytes":
+            raise MemoryError("injected")
+        return self._a.bytes()
+
+    def records(self):
+        if self._fail == "records":
+            raise MemoryError("injected")
+        return self._share       # (from_lists leaves the records with its caller)
+
+    def stats(self):
+        return self._a.stats()
+
+    def close(self):
+        self._a.close()
+
+
+def _fail_point_worker(rank, ws, port, q, point):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ws),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from stringdecomposer_amd import lib
+    dist = shard.init_process_group("gloo")
+    names = ["r%d" % i for i in range(len(_SEAM_READS))]
+    recs, off = _seam_job()
+    lo, hi = shard.block_range(len(off) - 1, rank, ws)
+
+    def make():
+        a = lib.RangeAssembler.from_lists(names, _SEAM_READS, ["m0", "m1", "m2"], lo, hi, recs[off[lo]:off[hi]],
+                                          off[lo:hi + 1] - off[lo], part_size=_SEAM_PART, overlap=_SEAM_OV, threads=2)
+        f = _FailingAssembler(a, point if rank == 1 else None, point == "records", lo, hi, len(off) - 1)
+        f._share = (recs[off[lo]:off[hi]], off[lo:hi + 1] - off[lo])
+        return f
+    try:
+        done = shard._assemble_by_ranks(dist, rank, ws, make, refused={})
+        q.put((rank, "ok", done is None))
+    except lib.SdError as e:
+        q.put((rank, "err", (e.code, e.msg)))
+    shard.barrier(dist)      # every rank left _assemble_by_ranks at the same point of the collective sequence
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("point", ["bytes", "records"])
+def test_a_failure_of_one_rank_behind_the_edge_exchange_is_raised_on_every_rank(point):
+    from stringdecomposer_amd import lib
+    ws, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_fail_point_worker, args=(r, ws, port, q, point)) for r in range(ws)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(ws))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == ["err", "err"], res
+    assert all(r[2][0] == lib.SD_ERR_INTERNAL and "MemoryError" in r[2][1] for r in res)
