@@ -258,7 +258,7 @@ def bench_c4_second_best(args):
         out = {"metric": "decomposed read-bp/sec at 64 monomers x 50kb reads, --second-best (BASELINE config 4), FASTA files -> "
                          "final_decomposition{_raw,,_alt}.tsv", "value": bp * K / dt, "unit": "bp/s", "n_gpus": 1,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f16 DP cells (exact integers), u32 bit vectors (identities)",
+               "scaling": "weak", "vs_baseline": None, "dtype": "f16 DP cells holding exact integers (the 128-template wide fill), u32 bit vectors (identities)",
                "data": "synthetic",
                "timed_region": "one sd_run_files call per step: FASTA files on tmpfs -> index + alphabet check -> chunk -> pack -> "
                                "H2D -> fill -> traceback -> compaction -> identities in-stream -> D2H -> per-read assembly -> raw / "
@@ -415,7 +415,7 @@ def bench_strong(args):
         st.close()
     out = {"metric": "decomposed read-bp/sec (whole node), one job split over the GPUs", "value": rate, "unit": "bp/s",
            "n_gpus": ws, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
-           "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "scaling": "strong", "vs_baseline": None, "dtype": lib.plan_info(ms, scoring=scoring)["cells"].split("/")[0], "data": "synthetic",
            "config": {"workload": workload, "job_bp": job_bp, "share": [kind, lo, hi], "scoring": list(scoring),
                       "host_threads": threads, "seed": args.seed,
                       "sharding": "contiguous blocks of %s, no collective (shard.strong_share)" % kind},
@@ -438,7 +438,9 @@ _REAL_STDOUT = None
 # the round-1-4 pipeline (A/B).
 BENCH_DEPTH = max(1, int(os.environ.get("SD_BENCH_DEPTH", "2")))
 
-KERNEL_SOURCES = ("sd_fast_fill.hpp", "sd_fast_dev.hpp", "sd_fast_trace2.hip", "sd_fast_wide_fill.hpp")
+# the sources that decide the instruction streams of the profiled fills / tracebacks (the list of four missed the
+# multi-wave fill used by --monomers 150 / 400)
+KERNEL_SOURCES = ("sd_fast_fill.hpp", "sd_fast_dev.hpp", "sd_fast_trace2.hip", "sd_fast_wide_fill.hpp", "sd_fast_wn_fill.hpp")
 
 
 def kernel_source_hashes():
@@ -650,11 +652,11 @@ def main():
     res_recs = eng.total_rows() if res_steps else None   # records of the resident batch (before the per-read seam merge)
     eng.close()
 
-    # ---- the same launch with INTEGER cells (SD_FLAG_NO_F16): the figure at the reading "no narrower than the
-    # reference's arithmetic wants int16" beside the headline's exact-integer fp16 cells (roofline.int16_cells) ----
-    int16_leg = None
-    if ws == 1 and not args.timed_only and info["cells"].split("/")[0] == "f16" and args.ed_thr < 0:
-        e16 = lib.Engine(ms, device=local_rank, kernel=kernel, threads=threads, flags=lib.FLAG_NO_F16)
+    # ---- the same launch with the other cell formats of the layout: saturating int16 (SD_FLAG_NO_F16; roofline.int16_cells,
+    # reported since round 4) and, where the headline runs the biased-u16 cells of round 6, the exact-integer fp16 cells
+    # of rounds 1-5 (SD_FLAG_NO_U16; roofline.f16_cells) -- same rows required of both ----
+    def cell_format_leg(flags):
+        e16 = lib.Engine(ms, device=local_rank, kernel=kernel, threads=threads, flags=flags)
         e16.load_reads(rs)
         i16 = e16.info()
         n16 = max(2, min(res_steps, 5))
@@ -668,9 +670,16 @@ def main():
             f16ms += tm["fill_ms"]
             t16ms += tm["trace_ms"]
         torch.cuda.synchronize()
-        int16_leg = {"cells": i16["cells"], "fill_ms": f16ms / n16, "traceback_ms": t16ms / n16, "steps": n16,
-                     "rows_out": rows16, "launched": "alone, batch resident in HBM (as isolated_*)"}
         e16.close()
+        return {"cells": i16["cells"], "fill_ms": f16ms / n16, "traceback_ms": t16ms / n16, "steps": n16,
+                "rows_out": rows16, "launched": "alone, batch resident in HBM (as isolated_*)"}
+    int16_leg = f16_leg = None
+    if ws == 1 and not args.timed_only and info["cells"].split("/")[0] in ("f16", "u16") and args.ed_thr < 0:
+        int16_leg = cell_format_leg(lib.FLAG_NO_F16)
+        if info["cells"] == "u16":
+            f16_leg = cell_format_leg(lib.FLAG_NO_U16)
+            if f16_leg["cells"] != "f16":
+                f16_leg = None
 
     # ---- roofline of the dominant kernel (fill) over the timed region, rank 0 ---------------------
     sumL, rows = info["sum_template_len"], einfo["rows"]
@@ -741,6 +750,9 @@ def main():
         v_ach = valu["wave_insts_per_launch"] / fill_s / 1e9
         v_iso = valu["wave_insts_per_launch"] / res_fill_s / 1e9 if res_steps and res_fill_s > 0 else None
         roofline = {"bound": "valu", "achieved": v_ach, "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s",
+                    "peak_note": "1024 SIMDs x 2.4 GHz / 4.1 cycles per wave64 instruction: the issue rate MEASURED on this GPU for "
+                                 "packed / DPP / SDWA / VOP3 instructions (profiles/r03_ubench_issue.txt); the micro-architecture "
+                                 "guide's 2-cycle SIMD-32 figure would double the peak and halve every fraction quoted against it",
                     "frac": v_ach / VALU_PEAK_GINST,
                     "stream_span_frac": v_ach / VALU_PEAK_GINST,
                     "isolated_frac": None if v_iso is None else v_iso / VALU_PEAK_GINST}
@@ -790,6 +802,10 @@ def main():
         int16_leg["hbm_notional_frac"] = alg_bytes / max(einfo["fill_launches"], 1) / (int16_leg["fill_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS
         int16_leg["same_rows_as_headline"] = bool(int16_leg.pop("rows_out") == res_recs)   # records of the same resident batch
         roofline["int16_cells"] = int16_leg
+    if f16_leg is not None:
+        f16_leg["hbm_notional_frac"] = alg_bytes / max(einfo["fill_launches"], 1) / (f16_leg["fill_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS
+        f16_leg["same_rows_as_headline"] = bool(f16_leg.pop("rows_out") == res_recs)
+        roofline["f16_cells"] = f16_leg
 
     out = {
         "metric": "decomposed read-bp/sec (whole node) at 12 monomers x 50kb reads",
@@ -811,7 +827,8 @@ def main():
                    "reads_per_gpu": args.reads, "read_len": args.read_len, "n_templates": info["n_templates"],
                    "sum_template_len": sumL, "chunks_per_gpu": n_chunks, "rows_per_gpu": rows,
                    "kernel_family": info["family"], "cells_per_lane": info["cells_per_lane"],
-                   "cell_arithmetic": info["cells"] + (" (packed pairs holding exact integers)" if info["cells"] == "f16" else ""),
+                   "cell_arithmetic": info["cells"] + (" (packed pairs holding exact integers)" if info["cells"] == "f16" else
+                                                       " (packed pairs of biased unsigned 16-bit integers, exact over +-15 k)" if info["cells"] == "u16" else ""),
                    "sub_batches": args.sub_batches, "host_threads": threads, "ed_thr": args.ed_thr,
                    "seed": args.seed, "sharding": "reads dealt to ranks in contiguous blocks, no collective"},
         # contract figure: SURVEY 8(d) algorithmic bytes of a fill launch / its HIP-event duration, launches of
@@ -860,6 +877,8 @@ def main():
         problems.append("rows of the HIP path differ from the CPU baseline's on the sample")
     if int16_leg is not None and not int16_leg["same_rows_as_headline"]:
         problems.append("integer-cell run produced a different number of rows")
+    if f16_leg is not None and not f16_leg["same_rows_as_headline"]:
+        problems.append("fp16-cell run produced a different number of rows")
     if problems:
         out["invalid"] = problems
     if profile_problems:   # (the measured value stands; only the figures derived from the committed counters are withheld)

@@ -54,6 +54,7 @@ typedef struct sd_params {
     int32_t reserved[5];
 } sd_params;
 #define SD_FLAG_NO_F16 1           /* no fp16 cell format: integer cells (or the generic family)                   */
+#define SD_FLAG_NO_U16 128         /* narrow layout: no biased-u16 cells (fp16 where the range allows, as in rounds 1-5; A/B) */
 #define SD_FLAG_FULL_FLOOR 2       /* fills that take the start-term maximum in every slot (A/B of the FL variants) */
 #define SD_FLAG_NO_EDTHR_COMPACT 4 /* --ed_thr with > 128 templates: every chunk on the W-wave ranked kernel (a set
                                     * beyond eight waves, whose only fast form is the compacted one: generic family)   */

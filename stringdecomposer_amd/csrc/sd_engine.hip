@@ -379,6 +379,7 @@ void apply_env_overrides(sd_params& p) {
         if (const char* ev = getenv("SD_PIPE_MODE")) p.reserved[0] = std::max(0, std::min(2, atoi(ev))) + 1;
     auto on = [](const char* name, char c) { const char* e = getenv(name); return e && e[0] == c; };
     if (on("SD_FILL_CELLS", 'i')) p.reserved[1] |= SD_FLAG_NO_F16;
+    if (on("SD_FILL_CELLS", 'f')) p.reserved[1] |= SD_FLAG_NO_U16;   // f16: the narrow layout's cells of rounds 1-5 (A/B)
     if (getenv("SD_FILL_FULLFLOOR")) p.reserved[1] |= SD_FLAG_FULL_FLOOR;
     if (on("SD_EDTHR_COMPACT", '0')) p.reserved[1] |= SD_FLAG_NO_EDTHR_COMPACT;
     if (getenv("SD_FILTER_GENERAL")) p.reserved[1] |= SD_FLAG_FILTER_GENERAL;
@@ -454,7 +455,8 @@ static int engine_pick_family(sd_engine* e, bool allow_f16, std::string& err) {
     // the packed two-block traceback unless switched off, and not after a range guard tripped (its own check raises the same flag)
     const bool tr2 = allow_f16 && !(p->reserved[1] & SD_FLAG_TRACE_V1);
     const bool fast_ok = sd::fast_plan_build(e->tseq, e->sc, p->part_size + p->overlap, e->fplan, why, !no_f16, tr2,
-                                             p->ed_thr > -1 && !(p->reserved[1] & SD_FLAG_NO_EDTHR_COMPACT));
+                                             p->ed_thr > -1 && !(p->reserved[1] & SD_FLAG_NO_EDTHR_COMPACT),
+                                             !(p->reserved[1] & SD_FLAG_NO_U16));
     e->fplan.full_floor = (p->reserved[1] & SD_FLAG_FULL_FLOOR) != 0;
     e->sc.rebase_mask = fast_ok ? e->fplan.rebase - 1 : 127;
     if (family == 0) family = fast_ok ? 2 : 1;
@@ -480,7 +482,8 @@ static int engine_pick_family(sd_engine* e, bool allow_f16, std::string& err) {
             e->d_vlane0.upload(e->fplan.vlane0);
         }
         // run-time guard of the fp16 cell formats (sd_fast_dev.hpp: F16Guard); reserved[2]: a smaller limit (tests)
-        e->sc.guard_lim = p->reserved[2] > 0 ? p->reserved[2] : 2040;
+        // (biased-u16 cells: the window the plan left around the bias, FastPlan::u16_lim)
+        e->sc.guard_lim = p->reserved[2] > 0 ? p->reserved[2] : e->fplan.u16 ? e->fplan.u16_lim : 2040;
         // the same hook lowers the range check of the packed traceback's 16-bit words (its own run-time guard: a
         // checkpoint cell or start term beyond it raises the same flag, and the batch is repeated with sd_fast_trace)
         if (p->reserved[2] > 0 && e->fplan.tr2_ok) e->fplan.tr2_xlim = std::min(e->fplan.tr2_xlim, (int)p->reserved[2]);
@@ -532,12 +535,13 @@ int sd_plan_info(const sd_params* p, const char* const* mono_seqs, const int32_t
     sd_params pe = *p;
     apply_env_overrides(pe);
     const bool ok = sd::fast_plan_build(tseq, sc, p->part_size + p->overlap, plan, why, !(pe.reserved[1] & SD_FLAG_NO_F16), true,
-                                        pe.ed_thr > -1 && !(pe.reserved[1] & SD_FLAG_NO_EDTHR_COMPACT));
+                                        pe.ed_thr > -1 && !(pe.reserved[1] & SD_FLAG_NO_EDTHR_COMPACT),
+                                        !(pe.reserved[1] & SD_FLAG_NO_U16));
     for (int i = 0; i < 8; ++i) info[i] = 0;
     info[0] = ok ? 2 : 1;                       // kernel family "auto" would take: 2 fast, 1 generic
     if (!ok) { set_err(errbuf, errlen, why); return SD_OK; }
     info[1] = plan.P;
-    info[2] = plan.tiled ? (plan.f16 ? 6 : 8) : plan.waves > 1 ? (plan.f16 ? 5 : 7) : plan.wide ? (plan.f16 ? 4 : 3) : plan.f16 ? 2 : 1;   // as sd_engine_info [4] >> 8
+    info[2] = plan.tiled ? (plan.f16 ? 6 : 8) : plan.waves > 1 ? (plan.f16 ? 5 : 7) : plan.wide ? (plan.f16 ? 4 : 3) : plan.u16 ? 9 : plan.f16 ? 2 : 1;   // as sd_engine_info [4] >> 8
     info[3] = plan.floor_slots;
     info[4] = plan.waves | ((int64_t)plan.range_bound << 8) | ((int64_t)plan.rebase << 40);
     // narrow layout: cells in the shortest first lane of a template and in the fullest lane (from slot_of)
@@ -1344,7 +1348,7 @@ int sd_engine_info(sd_engine* e, int64_t info[8]) {
     info[1] = e->sumL;
     info[2] = (int64_t)e->chunks.size();
     info[3] = e->rows;
-    info[4] = e->family | ((e->family == 1 ? 0 : e->fplan.tiled ? (e->fplan.f16 ? 6 : 8) : e->fplan.waves > 1 ? (e->fplan.f16 ? 5 : 7) : e->fplan.wide ? (e->fplan.f16 ? 4 : 3) : e->fplan.f16 ? 2 : 1) << 8);
+    info[4] = e->family | ((e->family == 1 ? 0 : e->fplan.tiled ? (e->fplan.f16 ? 6 : 8) : e->fplan.waves > 1 ? (e->fplan.f16 ? 5 : 7) : e->fplan.wide ? (e->fplan.f16 ? 4 : 3) : e->fplan.u16 ? 9 : e->fplan.f16 ? 2 : 1) << 8);
     info[5] = e->family == 1 ? e->Q : (e->fplan.P | ((int64_t)e->fplan.floor_slots << 16));
     info[6] = (int64_t)e->workspace_bytes();
     info[7] = (e->family == 1 ? (int64_t)e->subs.size() : 1) |

@@ -191,8 +191,10 @@ __global__ __launch_bounds__(64 * trace_waves_per_group(QK), (QK <= 4 ? SD_TRACE
                     const int v = slot[q] & 127, s = (slot[q] >> 7) & 511, wv_ = slot[q] >> 16;
                     const uint32_t wv = ckq[(wv_ * P + s) * 64 + (v & 63)];
                     const uint32_t hw = (v >> 6) ? (wv >> 16) : (wv & 0xffffu);
-                    const int32_t Ev = cb + (ckf16 ? (int)(float)__builtin_bit_cast(_Float16, (unsigned short)hw)
-                                                   : (int)(short)hw);
+                    // checkpoint cell formats (FastPlan): 0 int16, 1 fp16, 2 biased u16 (0 = "-inf")
+                    const int32_t Ev = ckf16 == 2 ? (hw ? cb + (int)hw - U16_BIAS : -0x10000000)
+                                       : cb + (ckf16 ? (int)(float)__builtin_bit_cast(_Float16, (unsigned short)hw)
+                                                     : (int)(short)hw);
                     // row a-1, shifted by (a-1)*ins; padding cells hold the fill's "-inf": keep them far below, no overflow
                     T[q] = 4 * (max(Ev, -0x08000000) - (a - 1) * ins) + 2;
                 }
@@ -323,7 +325,7 @@ static int code_of(char ch) {
 }
 
 bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max_rows,
-                     FastPlan& plan, std::string& why, bool allow_f16, bool allow_tr2, bool filter_only_ok) {
+                     FastPlan& plan, std::string& why, bool allow_f16, bool allow_tr2, bool filter_only_ok, bool allow_u16) {
     (void)max_rows;
     plan = FastPlan();
     const int T = (int)tseq.size();
@@ -364,7 +366,10 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     int rebase = FAST_REBASE;
     if (ub_of(rebase) > 2040 && allow_f16 && ub_of(64) <= 2040) rebase = 64;
     const int64_t ub = ub_of(rebase);
-    if (ub > 12000) { why = "scores too large for int16 cells"; return false; }
+    // (the biased-u16 cells of the narrow layout reach a little further than saturating int16: checked again once the layout is known)
+    const int64_t u16_room = 15800 - (int64_t)(Lmax + 1) * ab(sc.del) - 8 * (int64_t)maxabs;
+    const bool u16_fits = allow_f16 && allow_u16 && ub_of(FAST_REBASE) <= u16_room;
+    if (ub > 12000 && !u16_fits) { why = "scores too large for int16 cells"; return false; }
     plan.range_bound = (int)ub;
     plan.rebase = rebase;
     if (Lmax > 64 * 32) { why = "template longer than 2048 bp"; return false; }
@@ -456,8 +461,22 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
 
     plan.wide = wide;
     {
+        // Narrow layout, round 6: biased unsigned 16-bit cells (CellOps<CF_U16>): U = S + 0x3E00 must stay inside
+        // 0..0x7BFF together with every intermediate sum -- the row maximum takes the cells with up to (Lmax + 1) * |del|
+        // taken off (end offsets), a table value or a few single scores ride on top -- so the guard window is what is
+        // left of +-15 800 after those, and the proven bound of the full 128-row period must fit it.  Where it does the
+        // format replaces both fp16 (+-2040) and int16 cells; the rebase period goes back to 128 rows.
+        const int64_t room = u16_room;
+        const int64_t ub128 = ub_of(FAST_REBASE);
+        plan.u16 = !wide && u16_fits;
+        if (!plan.u16 && ub > 12000) { why = "scores too large for int16 cells"; return false; }
+        if (plan.u16) {
+            plan.u16_lim = (int)room;
+            plan.rebase = FAST_REBASE;
+            plan.range_bound = (int)ub128;
+        }
         // fp16 cells are exact while every value stays an integer below 2048 in magnitude
-        plan.f16 = !wide && ub <= 2040 && allow_f16;   // (SD_FLAG_NO_F16 / SD_FILL_CELLS=i16 arrive as allow_f16 = false)
+        plan.f16 = !wide && !plan.u16 && ub <= 2040 && allow_f16;   // (SD_FLAG_NO_F16 / SD_FILL_CELLS=i16 arrive as allow_f16 = false)
     }
     plan.P = P;
     plan.P4 = (P + 3) & ~3;
@@ -830,11 +849,18 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
     // FastPlan::full_floor (SD_FLAG_FULL_FLOOR) keeps the full kernel (developer A/B and the parity test of the two)
     const bool has1 = ((plan.Hx >> 10) & 1) != 0;   // 1-bp templates: the full-floor kernels carry the FLC_ONE form
     if (!plan.full_floor && !has1 &&
-        (plan.f16 ? launch_fast_fill_fl(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
-                                        argV, ckpt, ckbase, queue, order, cendoff, crank)
-                  : launch_fast_fill_fl_i16(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc,
-                                            B, argV, ckpt, ckbase, queue, order, cendoff, crank)))
+        (plan.u16 ? launch_fast_fill_fl_u16(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
+                                            argV, ckpt, ckbase, queue, order, cendoff, crank)
+         : plan.f16 ? launch_fast_fill_fl(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
+                                          argV, ckpt, ckbase, queue, order, cendoff, crank)
+                    : launch_fast_fill_fl_i16(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc,
+                                              B, argV, ckpt, ckbase, queue, order, cendoff, crank)))
         return;
+    if (plan.u16) {   // the full-floor kernels of the biased-u16 cell format live in their own unit (sd_fast_u16.hip)
+        launch_fast_fill_full_u16(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B, argV, ckpt,
+                                  ckbase, queue, order, cendoff, crank);
+        return;
+    }
     switch (plan.P) {
         SD_FILL(4) SD_FILL(8) SD_FILL(12) SD_FILL(16) SD_FILL(20) SD_FILL(24) SD_FILL(28) SD_FILL(30)
         SD_FILL(31) SD_FILL(32) SD_FILL(33) SD_FILL(34) SD_FILL(35) SD_FILL(36) SD_FILL(37) SD_FILL(38)
@@ -867,7 +893,7 @@ void launch_fast_trace(const FastPlan& plan, hipStream_t st, const ChunkDesc* ch
 #define SD_TRACE(QQ)                                                                              \
     hipLaunchKernelGGL(sd_fast_trace<QQ>, dim3(grid), dim3(64 * trace_waves_per_group(QQ)), 0, st, chunks, n_chunks, bases2, \
                        nmask, slot_of, tcodes, lane_consts, toff, tlen, sc, plan.P, B, argV, ckpt, \
-                       ckbase, recs, rec_cnt, queue, order, plan.f16 ? 1 : 0, plan.bshift, plan.waves, klist, kpos, \
+                       ckbase, recs, rec_cnt, queue, order, plan.u16 ? 2 : plan.f16 ? 1 : 0, plan.bshift, plan.waves, klist, kpos, \
                        nkept, plan.filter_only ? -plan.T : plan.T, lane_t)
     switch (plan.Qk) {
         case 1: SD_TRACE(1); break;

@@ -39,6 +39,9 @@ struct FastPlan {
     bool ok = false;
     bool wide = false;    // one template per virtual lane, int8 table streamed from LDS (P > 64)
     bool f16 = false;     // narrow layout with packed-fp16 cells (3 ops per cell pair, v_pk_maximum3_f16)
+    bool u16 = false;     // narrow layout with biased unsigned 16-bit cells (CellOps<CF_U16>: the same 3 ops, the add a plain
+                          // v_add_u32, exact range +-15 k); takes precedence over f16 and int16 where the range fits
+    int u16_lim = 0;      // |stored cell| the u16 format's run-time guard allows (>= range_bound)
     int P = 0;            // slots per virtual lane
     int P4 = 0;           // P rounded up to a multiple of 4 (LDS table row)
     int H = 0;            // carry hops of the cross-lane chain: Vmax-1
@@ -92,7 +95,8 @@ static const int FAST_TILED_P_LIST[] = {96, 128, 160, 192, 224};   // slots per 
 // input exactly (then the generic family is used).
 bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max_rows,
                      FastPlan& plan, std::string& why, bool allow_f16 = true, bool allow_tr2 = true,
-                     bool filter_only_ok = false);   // --ed_thr is on: a set beyond eight waves may take the filter-only form
+                     bool filter_only_ok = false,    // --ed_thr is on: a set beyond eight waves may take the filter-only form
+                     bool allow_u16 = true);         // false: SD_FLAG_NO_U16 (the narrow layout's fp16 / int16 cells as in rounds 1-5)
 
 // --ed_thr prefilter on the device (sd_filter.hip): infix edit distances, kept set and ranks per
 // chunk -> per-chunk lane constants of the fast family (cendoff, crank: [chunk][64] packed {lo,hi}
@@ -128,6 +132,23 @@ bool launch_fast_fill_fl(const FastPlan& plan, hipStream_t st, int grid, int nw,
                          const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
                          int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
                          const uint32_t* crank);
+
+// the same for the biased-u16 cell format (sd_fast_fl_u16.hip, sd_fast_fl_long_u16.hip) and its full-floor kernels (sd_fast_u16.hip)
+bool launch_fast_fill_fl_u16(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
+                             int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                             const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
+                             int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
+                             const uint32_t* crank);
+bool launch_fast_fill_fl_long_u16(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
+                                  int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                                  const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
+                                  int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
+                                  const uint32_t* crank);
+void launch_fast_fill_full_u16(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
+                               int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                               const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
+                               int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
+                               const uint32_t* crank);
 
 bool launch_fast_fill_fl_i16(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
                              int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,

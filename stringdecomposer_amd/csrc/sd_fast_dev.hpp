@@ -86,15 +86,29 @@ __device__ __forceinline__ int wave_prefix_max(int v) {
     return v;
 }
 
-// Cell arithmetic of the fill kernels: packed int16 (saturating) or packed fp16 holding exact integers.
-// gfx950 has a packed three-input maximum only for fp16 (v_pk_maximum3_f16), which folds the last two
-// maxima of the cell update:  u = max(S[x-1], KB);  v = u + tbl;  S_new[x] = max3(S_new[x-1], v, S[x]).
-template <bool F16>
+// Cell arithmetic of the fill kernels.  Three cell formats (CF):
+//   0  packed int16 (saturating adds);
+//   1  packed fp16 holding exact integers.  gfx950 has a packed three-input maximum only for fp16 (v_pk_maximum3_f16),
+//      which folds the last two maxima of the cell update:  u = max(S[x-1], KB);  v = u + tbl;  S_new[x] = max3(S_new[x-1], v, S[x]);
+//   2  (round 6) packed BIASED UNSIGNED 16-bit integers, U = S + U16_BIAS, every word inside 0x0000..0x7BFF: on those bit
+//      patterns the fp16 maxima ARE unsigned integer maxima and v_cmp_eq_f16 is pattern equality (tools/ubench_u16max.hip,
+//      exhaustive on the device; the packed traceback has used this since round 4), so the three-input maximum stays, the
+//      add is a plain 32-bit add of a signed pair (hi * 65536 + lo: no carry crosses the halves while both sums stay in
+//      0..65535) -- v_add_u32 issues in 2.3 cycles where v_pk_add_f16 takes 4.1 -- and the exact range is +-15 k instead of
+//      fp16's +-2 k.  0 is "-inf": the identity of every maximum, what an AND with a lane mask leaves, what idle planes hold.
+constexpr int CF_I16 = 0, CF_F16 = 1, CF_U16 = 2;
+constexpr int U16_BIAS = 0x3E00;                  // centre of 0..0x7BFF
+constexpr uint32_t U16_BIAS2 = 0x3E003E00u;
+// a signed pair as ONE 32-bit addend: adding it to a packed pair of fields adds lo to the low and hi to the high field
+__device__ __forceinline__ uint32_t spair(int lo, int hi) { return (uint32_t)(hi * 65536 + lo); }
+
+template <int CF>
 struct CellOps {
-    static constexpr uint32_t NEG = F16 ? 0xFC00FC00u : NEG2;
+    static constexpr bool F16 = CF == CF_F16, U16 = CF == CF_U16;
+    static constexpr uint32_t NEG = F16 ? 0xFC00FC00u : U16 ? 0u : NEG2;
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ uint32_t mx(uint32_t a, uint32_t b) {
-        if constexpr (F16) {
+        if constexpr (F16 || U16) {
             return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_bit_cast(h2, a),
                                                                               __builtin_bit_cast(h2, b)));
         } else {
@@ -107,33 +121,42 @@ struct CellOps {
                           __builtin_elementwise_maximum(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b)),
                           __builtin_bit_cast(h2, c)));
     }
+    // cell + offset (U16: the offset is a signed pair, spair / splat / from_i16x2)
     static __device__ __forceinline__ uint32_t add(uint32_t a, uint32_t b) {
         if constexpr (F16) {
             return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, a) + __builtin_bit_cast(h2, b));
+        } else if constexpr (U16) {
+            return a + b;
         } else {
             return pk_adds(a, b);
         }
     }
     static __device__ __forceinline__ uint32_t sub(uint32_t a, uint32_t b) {
         if constexpr (F16) return add(a, b ^ 0x80008000u);
+        else if constexpr (U16) return a - b;
         else return pk_subs(a, b);
     }
-    // {x, x}
+    // {x, x} as an OFFSET (U16: a signed pair; a value needs U16_BIAS2 on top)
     static __device__ __forceinline__ uint32_t splat(int x) {
         if constexpr (F16) {
             const float f = (float)x;
             return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(f, f));
+        } else if constexpr (U16) {
+            return spair(x, x);
         } else {
             return pack2(x);
         }
     }
-    // host-built packed int16 constant -> cell format (anything <= -30000 is "-inf")
-    static __device__ __forceinline__ uint32_t from_i16x2(uint32_t w) {
+    // host-built packed int16 constant -> cell format (anything <= -30000 is "-inf"; U16: an offset, "-inf" -> `ninf`)
+    static __device__ __forceinline__ uint32_t from_i16x2(uint32_t w, int ninf = 0) {
         if constexpr (F16) {
             const int lo = (int)(short)(w & 0xffffu), hi = (int)w >> 16;
             const float fl = lo <= -30000 ? -__builtin_inff() : (float)lo;
             const float fh = hi <= -30000 ? -__builtin_inff() : (float)hi;
             return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(fl, fh));
+        } else if constexpr (U16) {
+            const int lo = (int)(short)(w & 0xffffu), hi = (int)w >> 16;
+            return spair(lo <= -30000 ? ninf : lo, hi <= -30000 ? ninf : hi);
         } else {
             return w;
         }
@@ -146,6 +169,9 @@ struct CellOps {
             asm("v_cvt_i16_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(b) : "v"(w));
             lo = (int)(short)(a & 0xffffu);
             hi = (int)(short)(b & 0xffffu);
+        } else if constexpr (U16) {
+            lo = (int)(w & 0xffffu) - U16_BIAS;
+            hi = (int)(w >> 16) - U16_BIAS;
         } else {
             lo = (int)(short)(w & 0xffffu);
             hi = (int)w >> 16;
@@ -194,6 +220,46 @@ struct F16Guard {
         for (int s = 1; s + 1 < P; s += 2) m = CellOps<true>::mx3(m, L[s], L[s + 1]);
         if ((P & 1) == 0) m = CellOps<true>::mx(m, L[P - 1]);
         const uint32_t t = mn(m, pos2);
+        bad = bad || __ballot(t != m) != 0ull;
+    }
+    __device__ __forceinline__ void finish(int* flag) {
+        if (bad && flag && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+    }
+};
+
+// The same guard for the biased-u16 cells (CellOps<CF_U16>): every real cell inside [BIAS - lim, BIAS + lim].  The plan
+// leaves room below and above that window for every intermediate sum (FastPlan::u16_lim), so while the guard holds no sum
+// ever left 0..0xFFFF -- no carry crossed the halves of a word -- and no maximum saw a pattern beyond 0x7BFF.  Idle planes
+// hold 0 in every slot and are exempt (`pm`: the lane's plane mask).
+template <int P>
+struct U16Guard {
+    uint32_t hi2 = 0, lo2 = 0;         // packed {BIAS + lim} / {BIAS - lim}: SGPRs
+    bool bad = false;
+    typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ uint32_t mn(uint32_t a, uint32_t b) {
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u2, a), __builtin_bit_cast(u2, b)));
+    }
+    static __device__ __forceinline__ uint32_t mxu(uint32_t a, uint32_t b) {
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u2, a), __builtin_bit_cast(u2, b)));
+    }
+    __device__ __forceinline__ void start(int lim_) {
+        bad = false;
+        const int l = lim_ < U16_BIAS ? lim_ : U16_BIAS;
+        hi2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pack2(U16_BIAS + l));
+        lo2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)pack2(U16_BIAS - l));
+    }
+    __device__ __forceinline__ void check_low(const uint32_t (&L)[P], uint32_t pm) {
+        uint32_t m = L[0];
+#pragma unroll
+        for (int s = 1; s < P; ++s) m = mn(m, L[s]);
+        const uint32_t t = mxu(m, lo2 & pm);
+        bad = bad || __ballot(t != m) != 0ull;
+    }
+    __device__ __forceinline__ void check_high(const uint32_t (&L)[P]) {
+        uint32_t m = L[0];
+#pragma unroll
+        for (int s = 1; s < P; ++s) m = mxu(m, L[s]);
+        const uint32_t t = mn(m, hi2);
         bad = bad || __ballot(t != m) != 0ull;
     }
     __device__ __forceinline__ void finish(int* flag) {

@@ -32,9 +32,18 @@ namespace sd {
 // folds the last two maxima:  u = max(S[x-1], KB);  v = u + tbl;  S_new[x] = max3(S_new[x-1], v, S[x])
 // -- 3 packed ops per cell pair instead of 4.  fast_plan_build() enables it when the score range
 // fits (FastPlan::f16); the checkpoints then hold fp16 pairs (the traceback converts them).
+// U16 variant (CF = 2, round 6): the same three ops on biased unsigned 16-bit integers (CellOps<CF_U16>): the fp16 maxima
+// are exact unsigned maxima on the patterns 0..0x7BFF, the add is a plain v_add_u32 of a signed pair.  "-inf" is 0, and
+// nothing may be ADDED to it (a negative addend would borrow from the other half of the word), so:
+//   * table values of pad slots are min(tmin, 0), tmin = the smallest real table value: a pad's candidate
+//     max(S[x-1], KB) + pad then never exceeds what the chain already carries (S'[x-1] >= S'[0] >= KB + tmin; S'[x-1] >= S[x-1]),
+//     so the pad still only forwards the template's last cell;
+//   * idle planes (no template) hold 0 in every slot: their table values and end offsets are 0 and the row's start term
+//     is ANDed with the lane's plane mask before it enters the slots (one v_and_b32 per row);
+//   * a rebase shifts the real planes only (per-half add of the masked shift).
 // ONE: the set has 1-bp templates (FLC_ONE lanes end at slot 0); instantiated for the full-floor kernels of
 // sd_fast.hip only -- as a run-time branch in every kernel it cost the C2 fill 3 % (12.3 against 11.9 ms, same box)
-template <int P, bool RANKED, bool F16, int FL = P, bool ONE = false>
+template <int P, bool RANKED, int CF, int FL = P, bool ONE = false>
 __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
@@ -45,13 +54,25 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     constexpr int P4 = (P + 3) & ~3;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // [5][P4/4][64][4]
     constexpr int TBL = 5 * P4 * 64;
-    using CO = CellOps<F16>;
+    constexpr bool F16 = CF == CF_F16, U16 = CF == CF_U16;
+    using CO = CellOps<CF>;
     constexpr uint32_t NEGC = CO::NEG;
     for (int idx = threadIdx.x * 4; idx < TBL; idx += blockDim.x * 4) {
         uint4 q = *reinterpret_cast<const uint4*>(&table[idx]);
         if constexpr (F16) {
             q.x = CO::from_i16x2(q.x); q.y = CO::from_i16x2(q.y);
             q.z = CO::from_i16x2(q.z); q.w = CO::from_i16x2(q.w);
+        }
+        if constexpr (U16) {
+            // signed pairs; pads: min(tmin, 0) in a plane that holds a template, 0 in an idle plane (see above)
+            const uint32_t tm = lane_consts[((idx >> 2) & 63) * FAST_LANE_WORDS + FLC_TMPL];
+            const int tpad = min(min(sc.match, sc.mismatch) - sc.del - sc.ins, 0);
+            const int plo = (tm & 0xffffu) == 0xffffu ? 0 : tpad, phi = (tm >> 16) == 0xffffu ? 0 : tpad;
+            auto cv = [&](uint32_t w) {
+                const int lo = (int)(short)(w & 0xffffu), hi = (int)w >> 16;
+                return spair(lo <= -30000 ? plo : lo, hi <= -30000 ? phi : hi);
+            };
+            q.x = cv(q.x); q.y = cv(q.y); q.z = cv(q.z); q.w = cv(q.w);
         }
         *reinterpret_cast<uint4*>(&lds[idx]) = q;
     }
@@ -90,7 +111,7 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     // --ed_thr: per-chunk end offsets (-inf for dropped templates) and tie-break ranks
     // fp16, unranked: the whole B reduction stays in fp16 (no per-row int conversions); `del` is folded
     // into the end offsets so that the wave maximum is directly the start term B_i + del of the next row
-    constexpr bool HRED = F16;   // (ranked too: sd_rank_keep writes the per-chunk end offsets on every lane of a template)
+    constexpr bool HRED = F16 || U16;   // (ranked too: sd_rank_keep writes the per-chunk end offsets on every lane of a template)
     // HRED row tail.  With a_l = max(last slot, K_l) the total of virtual lane l:
     //   * the end cell of a template is the maximum of a_l over ALL its lanes (prefix maximum along the
     //     template), so the B reduction takes every lane's total with its template's end offset
@@ -100,11 +121,21 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     //     KB = max(K, B+del) >= K: slot 0's u is KB itself;
     //   * totals never decrease from row to row in the stored domain (the insertion move is "keep"),
     //     so the new carry replaces the old one without a max.
-    const uint32_t endOff = HRED ? CO::from_i16x2(pk_adds(RANKED ? cendoff[(size_t)c * 64 + lane] : lc[FLC_ENDALL], pack2(sc.del)))
+    const uint32_t endOffRaw = pk_adds(RANKED ? cendoff[(size_t)c * 64 + lane] : lc[FLC_ENDALL], pack2(sc.del));
+    const uint32_t endOff = HRED ? CO::from_i16x2(endOffRaw)
                                  : CO::from_i16x2(RANKED ? cendoff[(size_t)c * 64 + lane] : endOffPlan);
     const uint32_t rank2 = RANKED ? crank[(size_t)c * 64 + lane] : 0u;
     const uint32_t row0adj = CO::from_i16x2(lc[FLC_ROW0]);
     const uint32_t ins2 = CO::splat(sc.ins);
+    // U16: which planes of this lane hold a template; which ends take part in the row maximum (an idle plane's and, with
+    // --ed_thr, a dropped template's end must stay 0 = "-inf": the end offset is 0 there and the sum is masked)
+    uint32_t planeMask = 0xffffffffu, endMask = 0xffffffffu, notStart = ~startMask;
+    if constexpr (U16) {
+        const uint32_t tm = lc[FLC_TMPL];
+        planeMask = ((tm & 0xffffu) == 0xffffu ? 0u : 0xffffu) | ((tm >> 16) == 0xffffu ? 0u : 0xffff0000u);
+        endMask = ((int)(short)(endOffRaw & 0xffffu) <= -30000 ? 0u : 0xffffu) | (((int)endOffRaw >> 16) <= -30000 ? 0u : 0xffff0000u);
+        asm volatile("" : "+v"(planeMask), "+v"(endMask), "+v"(notStart));   // plain AND masks in registers
+    }
 
     int32_t* Bc = Bout + cd.row0 + (uint64_t)c;
     uint32_t* ck = ckpt + (uint64_t)cd.pad * (uint64_t)(P * 64) + lane;
@@ -164,7 +195,8 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     // B_{row} (relative to base) = max over template ends; arg = smallest virtual lane attaining it
     auto reduce_ends = [&](uint32_t Eend, int row) {
         if constexpr (HRED) {
-            const uint32_t val = CO::add(Eend, endOff);
+            uint32_t val = CO::add(Eend, endOff);
+            if constexpr (U16 && RANKED) val &= endMask;   // (unranked: an idle plane's total and end offset are both 0)
             uint32_t m;
             asm("v_max_f16_sdwa %0, %1, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"
                 "s_nop 1\n\t"
@@ -204,7 +236,7 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
                 // 64 rows at once: fp16 -> int, B = base + (b + del) - del + tp_row * ins
                 asm volatile("");   // keeps this a scalar branch: the lane test below is not evaluated on every row
                 const uint32_t w = (uint32_t)accBV;
-                const int bi = (int)(float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 7));
+                const int bi = U16 ? (int)(w >> 7) - U16_BIAS : (int)(float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 7));
                 const int tpl = tp - (slot - lane);
                 const int Bv = base + bi - sc.del + tpl * sc.ins;
                 if (lane <= slot) Bc[row - slot + lane] = (int)(((uint32_t)Bv << 7) | (w & 127u));
@@ -245,15 +277,26 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     uint32_t pin = 0;
     load_table(rs.code(0), pin);
     rs.advance(0);
+    if constexpr (U16) {
+        // values: BIAS + ..., idle planes 0
+        L[0] = (tb[0] + row0adj + U16_BIAS2) & planeMask;
+#pragma unroll
+        for (int q = 1; q < P; ++q) L[q] = CO::mx(L[q - 1], (tb[q] + ins2 + U16_BIAS2) & planeMask);
+    } else {
     L[0] = CO::add(tb[0], row0adj);
 #pragma unroll
     for (int q = 1; q < P; ++q) L[q] = CO::mx(L[q - 1], CO::add(tb[q], ins2));
+    }
     load_table(rs.code(1), L[P - 1]);
     rs.advance(1);
-    F16Guard<P> guard;
+    std::conditional_t<U16, U16Guard<P>, F16Guard<P>> guard;
     if constexpr (F16) {
         guard.start(L[P - 1], sc.guard_lim);
         guard.check_low(L);
+    }
+    if constexpr (U16) {
+        guard.start(sc.guard_lim);
+        guard.check_low(L, planeMask);
     }
     if constexpr (HRED) reduce_ends(L[P - 1], 1);
     K = excl_scan(L[P - 1]);
@@ -268,15 +311,29 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
             bperm_scan = bperm_ok && (!fair.drained || ((Hx >> 9) & 1));
             if ((i & (127 >> ((Hx >> 11) & 1))) == 0) {   // FastPlan::rebase rows: 128, or 64 (Hx bit 11; Hx is live here anyway)
                 // rebase the int16 state on B_i and fold the row offset tp*ins back in
-                if constexpr (HRED)
+                if constexpr (F16)
                     Brel = __builtin_amdgcn_readfirstlane((int)(float)__builtin_bit_cast(_Float16, (unsigned short)bdel16)) -
                            sc.del + tp * sc.ins;
-                const uint32_t d2 = CO::splat(F16 ? -(Brel - tp * sc.ins) : Brel - tp * sc.ins);
+                if constexpr (U16) Brel = (int)bdel16 - U16_BIAS - sc.del + tp * sc.ins;
+                const uint32_t d2 = U16 ? pack2(-(Brel - tp * sc.ins)) : CO::splat(F16 ? -(Brel - tp * sc.ins) : Brel - tp * sc.ins);
                 base += Brel;
                 Brel = 0;
                 tp = 0;
-                if constexpr (HRED) bdel16 = __builtin_amdgcn_readfirstlane((int)(CO::splat(sc.del) & 0xffffu));
-                if constexpr (F16) {
+                if constexpr (F16) bdel16 = __builtin_amdgcn_readfirstlane((int)(CO::splat(sc.del) & 0xffffu));
+                if constexpr (U16) bdel16 = (uint32_t)(U16_BIAS + sc.del);
+                if constexpr (U16) {
+                    // per-half (wrapping) add of the shift, real planes only: idle planes and the carry of start lanes stay 0
+                    typedef unsigned short u2_t __attribute__((ext_vector_type(2)));
+                    auto shift = [](uint32_t x, uint32_t d) {
+                        return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u2_t, x) + __builtin_bit_cast(u2_t, d));
+                    };
+                    const uint32_t d2m = d2 & planeMask;
+                    guard.check_high(L);
+                    K = shift(K, d2m & notStart);
+#pragma unroll
+                    for (int s = 0; s < P; ++s) L[s] = shift(L[s], d2m);
+                    guard.check_low(L, planeMask);
+                } else if constexpr (F16) {
                     guard.check_high(L);
                     K = bfi(startMask, NEGC, CO::add(K, d2));
                     Eend = CO::add(Eend, d2);
@@ -302,17 +359,18 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
         if constexpr (HRED) {
             // max(K, {b+del, b+del}): the scalar's low half feeds both lanes of the packed op
             asm("v_pk_max_f16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(KB) : "v"(K), "s"(bdel16));
+            if constexpr (U16) KB &= planeMask;   // an idle plane takes no start term: its slots stay 0
         } else {
             KB = CO::mx(K, CO::splat(Brel + sc.del - tp * sc.ins));
         }
         // slot 0's diagonal input is the true last slot of the previous lane = this lane's carry K, and
         // KB >= K: its u is KB itself (all variants)
-        const uint32_t w0 = bfi(startMask, NEGC, L[0]);
+        const uint32_t w0 = U16 ? (L[0] & notStart) : bfi(startMask, NEGC, L[0]);
         uint32_t u_[P], v_[P], c_[P];
         uint32_t run = 0;
         // software-pipelined over the slots so that no packed op consumes the result of the
         // instruction right before it (gfx950 needs a wait state there)
-        if constexpr (F16) {
+        if constexpr (HRED) {
 #pragma unroll
             for (int s = 0; s < P + 4; ++s) {
                 if (s >= 4) {
@@ -363,7 +421,7 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
         }
         load_table(rs.code(i + 1), L[P - 1]);  // unconditional (clamped): keeps tb[] out of phi copies
         rs.advance(i + 1);
-        uint32_t a = F16 ? L[P - 1] : CO::mx(L[P - 1], K);  // fp16: K already joined the chain
+        uint32_t a = HRED ? L[P - 1] : CO::mx(L[P - 1], K);  // fp16 / u16: K already joined the chain
         // a 1-bp template ends in slot 0: the pads behind a k = 0 cell keep their old value when the cell's falls
         if constexpr (ONE) a = bfi(oneMask, L[0], a);   // (the lane is a start lane: no carry to join)
         ++tp;
@@ -387,7 +445,7 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
         }
         }   // rows of the group
     }
-    if constexpr (F16) {
+    if constexpr (HRED) {
         guard.check_high(L);
         guard.finish(sc.guard_flag);
     }

@@ -14,16 +14,24 @@
 // variants; everything else runs the full kernels of sd_fast.hip.
 #include "sd_fast_fill.hpp"
 
+// (sd_fast_fl_u16.hip compiles this file again for the biased-u16 cell format: SD_FL_CF = CF_U16, its own entry names)
+#ifndef SD_FL_CF
+#define SD_FL_CF CF_F16
+#define SD_FL_ENTRY launch_fast_fill_fl
+#define SD_FL_ENTRY_LONG launch_fast_fill_fl_long
+#define SD_FL_TAKES(plan) ((plan).f16)
+#endif
+
 namespace sd {
 
-bool launch_fast_fill_fl(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
+bool SD_FL_ENTRY(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
                          int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                          const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
                          int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
                          const uint32_t* crank) {
-    if (!plan.f16 || plan.wide || plan.P < 30 || plan.floor_slots < 1) return false;
+    if (!SD_FL_TAKES(plan) || plan.wide || plan.P < 30 || plan.floor_slots < 1) return false;
     if (plan.P > 40)
-        return launch_fast_fill_fl_long(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
+        return SD_FL_ENTRY_LONG(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
                                         argV, ckpt, ckbase, queue, order, cendoff, crank);
     int fl = 0;
     for (int c : {12, 16, 20, 24, 28})
@@ -32,9 +40,9 @@ bool launch_fast_fill_fl(const FastPlan& plan, hipStream_t st, int grid, int nw,
     const bool ranked = cendoff != nullptr;
 #define SD_FL_K(PP, RK, FF)                                                                           \
     {                                                                                                \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, true, FF>),     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, SD_FL_CF, FF>),     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-        hipLaunchKernelGGL((sd_fast_fill<PP, RK, true, FF>), dim3(grid), dim3(nw * 64), lds,  \
+        hipLaunchKernelGGL((sd_fast_fill<PP, RK, SD_FL_CF, FF>), dim3(grid), dim3(nw * 64), lds,  \
                            st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, plan.Hx, B,   \
                            argV, ckpt, ckbase, queue, order, cendoff, crank);                        \
         return true;                                                                                 \

@@ -10,7 +10,7 @@ bool launch_fast_fill_fl_i16(const FastPlan& plan, hipStream_t st, int grid, int
                              const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
                              int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
                              const uint32_t* crank) {
-    if (plan.f16 || plan.wide || plan.P < 30 || plan.floor_slots < 1) return false;
+    if (plan.f16 || plan.u16 || plan.wide || plan.P < 30 || plan.floor_slots < 1) return false;
     const int fl = plan.P <= 40 ? (plan.floor_slots <= 16 ? 16 : plan.floor_slots <= 24 ? 24 : 0)
                                 : (plan.floor_slots <= 24 ? 24 : 0);
     if (fl == 0) return false;

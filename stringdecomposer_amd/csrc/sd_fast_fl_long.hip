@@ -2,22 +2,29 @@
 // of ~170 bp, or longer monomers), in their own translation unit so that the library builds in parallel.
 #include "sd_fast_fill.hpp"
 
+// (sd_fast_fl_long_u16.hip compiles this file again for the biased-u16 cell format)
+#ifndef SD_FL_CF
+#define SD_FL_CF CF_F16
+#define SD_FL_ENTRY_LONG launch_fast_fill_fl_long
+#define SD_FL_TAKES(plan) ((plan).f16)
+#endif
+
 namespace sd {
 
-bool launch_fast_fill_fl_long(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
+bool SD_FL_ENTRY_LONG(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
                               int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                               const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
                               int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
                               const uint32_t* crank) {
-    if (!plan.f16 || plan.wide || plan.P <= 40 || plan.floor_slots < 1) return false;
+    if (!SD_FL_TAKES(plan) || plan.wide || plan.P <= 40 || plan.floor_slots < 1) return false;
     const int fl = plan.floor_slots <= 16 ? 16 : plan.floor_slots <= 24 ? 24 : plan.floor_slots <= 32 ? 32 : 0;
     if (fl == 0) return false;
     const bool ranked = cendoff != nullptr;
 #define SD_FL_K(PP, RK, FF)                                                                           \
     {                                                                                                \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, true, FF>),     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, SD_FL_CF, FF>),     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-        hipLaunchKernelGGL((sd_fast_fill<PP, RK, true, FF>), dim3(grid), dim3(nw * 64), lds,  \
+        hipLaunchKernelGGL((sd_fast_fill<PP, RK, SD_FL_CF, FF>), dim3(grid), dim3(nw * 64), lds,  \
                            st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, plan.Hx, B,   \
                            argV, ckpt, ckbase, queue, order, cendoff, crank);                        \
         return true;                                                                                 \

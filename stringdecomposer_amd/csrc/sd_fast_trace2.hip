@@ -192,7 +192,9 @@ __global__ __launch_bounds__(64 * TR2_NWV, 7) void sd_fast_trace_pk(
                         if (idx != 0xffffffffu) {
                             const uint32_t wv = ckq[idx & 0x7fffffffu];
                             const uint32_t hw = (idx >> 31) ? (wv >> 16) : (wv & 0xffffu);
-                            const int val = ckf16 ? (int)(float)__builtin_bit_cast(_Float16, (unsigned short)hw) : (int)(short)hw;
+                            // checkpoint cell formats: 0 int16, 1 fp16, 2 biased u16 (0 = "-inf")
+                            const int val = ckf16 == 2 ? (hw ? (int)hw - U16_BIAS : -0x10000000)
+                                            : ckf16 ? (int)(float)__builtin_bit_cast(_Float16, (unsigned short)hw) : (int)(short)hw;
                             const int X = max(val, -0x08000000) - shift;
                             bad = bad || X > xlim || X < -xlim;
                             t16 = (uint32_t)(4 * min(max(X, -xlim), xlim) + 2 + TR2_BIAS);
@@ -417,7 +419,7 @@ bool launch_fast_trace2(const FastPlan& plan, hipStream_t st, const ChunkDesc* c
 #define SD_TRACE2(QQ)                                                                                              \
     hipLaunchKernelGGL(sd_fast_trace_pk<QQ>, dim3(grid), dim3(64 * TR2_NWV), 0, st, chunks, n_chunks, bases2, nmask, \
                        lane_consts, tcodes, toff, tlen, sc, plan.P, B, ckpt, ckbase, tr2_tab, recs, rec_cnt, queue,  \
-                       order, plan.f16 ? 1 : 0, plan.bshift, margin, plan.tr2_xlim)
+                       order, plan.u16 ? 2 : plan.f16 ? 1 : 0, plan.bshift, margin, plan.tr2_xlim)
     switch (plan.tr2_qm) {
         case 1: SD_TRACE2(1); break;
         case 2: SD_TRACE2(2); break;

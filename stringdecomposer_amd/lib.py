@@ -185,6 +185,7 @@ def _strs(seq):
 
 FLAG_NO_F16, FLAG_FULL_FLOOR, FLAG_NO_EDTHR_COMPACT, FLAG_FILTER_GENERAL, FLAG_NO_STREAM_IDENT, FLAG_PROGRESS = 1, 2, 4, 8, 16, 32
 FLAG_TRACE_V1 = 64
+FLAG_NO_U16 = 128     # narrow layout: fp16 / int16 cells as in rounds 1-5 instead of the biased-u16 format
 
 
 def make_params(scoring=(-1, -1, -1, 1), part_size=5000, overlap=500, ed_thr=-1, threads=1,
@@ -225,7 +226,7 @@ def plan_info(mono_seqs, **kw):
     rc = L.sd_plan_info(C.byref(p), _strs(ms), ml, len(ms), v, err, 4096)
     if rc != SD_OK:
         raise SdError(rc, err.value.decode(errors="replace"))
-    cells = {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table", 4: "f16/bf8-table", 5: "f16/bf8-codes x waves", 6: "f16/bf8-codes tiled x waves",
+    cells = {0: "int32", 1: "int16", 2: "f16", 9: "u16", 3: "int16/int8-table", 4: "f16/bf8-table", 5: "f16/bf8-codes x waves", 6: "f16/bf8-codes tiled x waves",
              7: "int16/int8-codes x waves", 8: "int16/int8-codes tiled x waves"}
     return {"family": {1: "generic", 2: "fast"}[v[0]], "cells_per_lane": v[1], "cells": cells.get(v[2], "?") if v[0] == 2 else "int32",
             "floor_slots": v[3], "waves": v[4] & 0xff, "range_bound": (v[4] >> 8) & 0xffffffff, "rebase": v[4] >> 40, "min_first_lane_cells": v[5], "max_lane_cells": v[6],
@@ -507,7 +508,7 @@ class Engine:
 def _info_dict(v):
     return {"n_templates": v[0], "sum_template_len": v[1], "n_chunks": v[2], "rows": v[3],
             "family": {1: "generic", 2: "fast"}.get(v[4] & 0xff, "?"),
-            "cells": {0: "int32", 1: "int16", 2: "f16", 3: "int16/int8-table", 4: "f16/bf8-table",
+            "cells": {0: "int32", 1: "int16", 2: "f16", 9: "u16", 3: "int16/int8-table", 4: "f16/bf8-table",
                       5: "f16/bf8-codes x waves", 6: "f16/bf8-codes tiled x waves", 7: "int16/int8-codes x waves",
                       8: "int16/int8-codes tiled x waves"}.get(v[4] >> 8, "?"),
             "cells_per_lane": v[5] if (v[4] & 0xff) == 1 else v[5] & 0xffff,

@@ -202,22 +202,32 @@ def test_full_c2_sample_of_200_reads_equals_the_reference_binary(tmp_path):
                                              ((0, -10, -4, -1), "int16", 128), ((-1, -5, -2, 1), "f16", 128),
                                              # a common factor is divided out on the device and multiplied back
                                              ((-10, -10, -10, 10), "f16", 128), ((-4, -6, -8, 4), "f16", 128), ((0, 0, -3, 45), "f16", 64),
-                                             ((0, 0, -3, 150), "int16", 128)])
-def test_fill_cell_format_switch_at_the_fp16_range_limit(oracle, sc, cells, rebase):
-    """The fill uses packed fp16 cells while the score range keeps every value an exact integer
+                                             ((0, 0, -3, 150), "int16", 128),
+                                             # round 6: beyond saturating int16, inside the biased-u16 window
+                                             ((0, 0, -1, 100), "u16", 128)])
+@pytest.mark.parametrize("legacy", [False, True])
+def test_fill_cell_format_switch_at_the_fp16_range_limit(oracle, sc, cells, rebase, legacy):
+    """Round 6: the narrow fill keeps its cells as biased unsigned 16-bit integers (CellOps<CF_U16>: exact over +-15 k, one
+    format for all of these scorings, 128 rows between rebases).  With FLAG_NO_U16 (`legacy`) the formats of rounds 1-5:
+    packed fp16 cells while the score range keeps every value an exact integer
     (fast_plan_build: with 128 or 64 rows between two rebases of the stored cells), packed int16 beyond.
     Scorings on both sides of every switch, on reads that
     maximise score growth (exact repeats), insertions (unrelated sequence) and ordinary noise."""
+    if legacy and cells == "u16":
+        pytest.skip("no 16-bit format of rounds 1-5 holds this scoring")
+    fl = lib.FLAG_NO_U16 if legacy else 0
+    if not legacy:
+        cells, rebase = "u16", 128
     mn, ms = synth.make_monomers(12, seed=3)
     st = synth.Stream(3, 5)
     rn, rs = synth.make_reads(ms, 2, read_len=12000, seed=4)
     rs = list(rs) + [(ms[0] * 40)[:6100], synth._ACGT[st.below(5600, 4)].tobytes(), ms[5] * 3 + b"A" * 700 + ms[2] * 20]
     rn = ["r%d" % i for i in range(len(rs))]
-    e = lib.Engine(ms, scoring=sc, kernel=lib.KERNEL_FAST)
-    assert e.info()["cells"] == cells and lib.plan_info(ms, scoring=sc)["rebase"] == rebase
+    e = lib.Engine(ms, scoring=sc, kernel=lib.KERNEL_FAST, flags=fl)
+    assert e.info()["cells"] == cells and lib.plan_info(ms, scoring=sc, flags=fl)["rebase"] == rebase
     e.close()
     t0 = lib.guard_trips()
-    got = lib.decompose(rn, rs, mn, ms, scoring=sc, kernel=lib.KERNEL_FAST)
+    got = lib.decompose(rn, rs, mn, ms, scoring=sc, kernel=lib.KERNEL_FAST, flags=fl)
     assert lib.guard_trips() == t0   # (the run-time check of the fp16 range agrees with the plan's period)
     assert got == oracle.decompose(rn, rs, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc)
 
@@ -741,13 +751,19 @@ def _late_base_monomers():
 
 @pytest.mark.parametrize("name", ["synthetic12", "synthetic12_i16", "dxz1_i16_ed", "dxz1", "late_bases", "late_bases_ed",
                                   "synthetic16", "synthetic20_ed",
-                                  "wide64", "wide64_ed", "waves140"])
+                                  "wide64", "wide64_ed", "waves140",
+                                  # the same narrow sets with the cell formats of rounds 1-5 (FLAG_NO_U16: fp16 / int16)
+                                  "synthetic12+legacy", "synthetic12_i16+legacy", "dxz1_i16_ed+legacy", "dxz1+legacy",
+                                  "late_bases_ed+legacy", "synthetic16+legacy", "synthetic20_ed+legacy"])
 def test_fill_without_dominated_start_maxima(oracle, name):
     """csrc/sd_fast_fl.hip: behind the first FL slots of a lane the fill leaves out the maximum with the start
     term (the candidate is dominated there).  Same rows as the full kernel (SD_FILL_FULLFLOOR=1) and as the
     oracle, for template sets with small, typical and large floor_slots, with and without --ed_thr."""
     ed = -1
     sc = (-1, -1, -1, 1)
+    legacy = name.endswith("+legacy")
+    name = name.split("+")[0]
+    fl = lib.FLAG_NO_U16 if legacy else 0
     if name.startswith("synthetic12"):
         mn, ms = synth.make_monomers(12, seed=1)
         if name.endswith("_i16"):
@@ -774,13 +790,13 @@ def test_fill_without_dominated_start_maxima(oracle, name):
     rs = list(rs) + [(ms[0].replace(b"N", b"A") * 30)[:3000], synth._ACGT[st.below(2500, 4)].tobytes(),
                      b"G" * 400 + ms[-1].replace(b"N", b"C") * 4 + b"N" * 3 + ms[1].replace(b"N", b"C") * 3]
     rn = ["r%d" % i for i in range(len(rs))]
-    e = lib.Engine(ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc)
+    e = lib.Engine(ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc, flags=fl)
     info = e.info()
     e.close()
     if len(ms) <= 12:
-        assert info["cells"] == ("int16" if "_i16" in name else "f16") and 30 <= info["cells_per_lane"] <= 40
+        assert info["cells"] == (("int16" if "_i16" in name else "f16") if legacy else "u16") and 30 <= info["cells_per_lane"] <= 40
     elif len(ms) <= 20:
-        assert info["cells"] == "f16" and 42 <= info["cells_per_lane"] <= 64
+        assert info["cells"] == ("f16" if legacy else "u16") and 42 <= info["cells_per_lane"] <= 64
     else:
         assert info["cells"] in ("f16/bf8-table", "f16/bf8-codes x waves"), info
     lo, hi = {"synthetic12": (8, 16), "synthetic12_i16": (8, 16), "dxz1": (17, 24), "dxz1_i16_ed": (17, 24),
@@ -788,10 +804,10 @@ def test_fill_without_dominated_start_maxima(oracle, name):
               "synthetic16": (8, 24), "synthetic20_ed": (8, 32), "wide64": (8, 32), "wide64_ed": (8, 32), "waves140": (8, 48)}[name]
     assert lo <= info["floor_slots"] <= hi, info
     exp = oracle.decompose(rn, rs, mn, ms, threads=8, ed_thr=ed, sc=sc)
-    got = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc)
+    got = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc, flags=fl)
     os.environ["SD_FILL_FULLFLOOR"] = "1"
     try:
-        full = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc)
+        full = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc, flags=fl)
     finally:
         del os.environ["SD_FILL_FULLFLOOR"]
     assert full == exp
@@ -801,10 +817,10 @@ def test_fill_without_dominated_start_maxima(oracle, name):
         # need the start term much deeper into the lanes (other FL variants, or the full kernel)
         os.environ["SD_PLAN_UNIFORM_LANES"] = "1"
         try:
-            e = lib.Engine(ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc)
+            e = lib.Engine(ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc, flags=fl)
             uinfo = e.info()
             e.close()
-            uni = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc)
+            uni = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, ed_thr=ed, scoring=sc, flags=fl)
         finally:
             del os.environ["SD_PLAN_UNIFORM_LANES"]
         assert uinfo["floor_slots"] >= info["floor_slots"] and (name == "dxz1" or uinfo["floor_slots"] >= 25), (uinfo, info)
@@ -929,7 +945,7 @@ def test_bench_line_contract():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["unit"] == "bp/s" and j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak"
-    assert j["higher_is_better"] is True and j["vs_baseline"] is None and j["data"] == "synthetic" and j["dtype"] == "f16"
+    assert j["higher_is_better"] is True and j["vs_baseline"] is None and j["data"] == "synthetic" and j["dtype"] == "u16"
     assert j["value"] > 1e8 and abs(j["value"] - 120 * 50000 / (j["ms_per_step"] / 1e3)) / j["value"] < 1e-6
     assert "workload" in j["config"] and "model" not in j["config"]
     r = j["roofline"]
@@ -948,12 +964,15 @@ def test_bench_line_contract():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nm", [12, 64, 140, "tiled"])
+@pytest.mark.parametrize("nm", [12, "12+legacy", 64, 140, "tiled"])
 def test_f16_range_guard_trips_and_the_batch_is_repeated_with_integer_cells(oracle, nm):
     """VERDICT r02 (weak 6): the fp16 fills check at run time that their cells stay in the exact-integer range
     (F16Guard, csrc/sd_fast_dev.hpp).  With the real limit nothing trips; with a limit any input exceeds
     (sd_params.reserved[2], the test hook) the guard raises its flag, the engine repeats the batch with integer
     cells -- for more than 128 templates on the generic family -- and the rows still equal the oracle's."""
+    fl = 0
+    if nm == "12+legacy":   # the narrow layout's fp16 cells (F16Guard); 12: its biased-u16 cells (U16Guard), the default since round 6
+        nm, fl = 12, lib.FLAG_NO_U16
     if nm == "tiled":   # thirty 342-bp monomers: the tiled multi-wave layout (fp16 only: the repeat runs on the generic family)
         mn, ms = synth.make_monomers(60, seed=3)
         mn, ms = mn[:30], [ms[2 * j] + ms[2 * j + 1] for j in range(30)]
@@ -964,13 +983,13 @@ def test_f16_range_guard_trips_and_the_batch_is_repeated_with_integer_cells(orac
     rn, rs = synth.make_reads(ms, 5, read_len=3000 if nm > 64 else 6000, seed=5)
     want = oracle.decompose(rn, rs, mn, ms, threads=8)
     t0 = lib.guard_trips()
-    assert lib.decompose(rn, rs, mn, ms) == want
+    assert lib.decompose(rn, rs, mn, ms, flags=fl) == want
     assert lib.guard_trips() == t0
-    assert lib.decompose(rn, rs, mn, ms, f16_guard=40) == want
+    assert lib.decompose(rn, rs, mn, ms, f16_guard=40, flags=fl) == want
     assert lib.guard_trips() > t0
     t1 = lib.guard_trips()
     # the streaming form: two batches, the first trips, the engine stays on integer cells
-    st = lib.Stream(ms, sub_batches=2, f16_guard=40)
+    st = lib.Stream(ms, sub_batches=2, f16_guard=40, flags=fl)
     st.submit(rs)
     rows = st.collect(as_lists=True)
     st.close()

@@ -575,16 +575,42 @@ def test_two_decimal_text_equals_python_format():
                                              ((0, 0, -3, 150), "int16", 128)])
 def test_plan_cell_format_switch(sc, cells, rebase):
     """sd_plan_info (host only): the fp16 / int16 decision of fast_plan_build for scorings on both sides of the
-    exact-integer range of fp16 -- the same cases the GPU test runs against the oracle."""
+    exact-integer range of fp16 -- the same cases the GPU test runs against the oracle.  Since round 6 that decision is
+    what FLAG_NO_U16 leaves (and what a set beyond the narrow layout gets); the narrow layout itself takes the biased-u16
+    cells for all of them, at the full 128-row rebase period."""
+    mn, ms = synth.make_monomers(12, seed=3)
+    info = lib.plan_info(ms, scoring=sc, flags=lib.FLAG_NO_U16)
+    assert info["family"] == "fast" and info["cells"] == cells and info["rebase"] == rebase, info
+    info = lib.plan_info(ms, scoring=sc)
+    assert info["family"] == "fast" and info["cells"] == "u16" and info["rebase"] == 128, info
+
+
+@pytest.mark.parametrize("sc,cells", [((0, 0, -1, 90), "u16"),          # 129 * 91 + ... = 12 600: beyond saturating int16's 12 000
+                                      ((0, 0, -1, 100), "u16"),         # 13 900 of the 15 000 the window leaves
+                                      ((0, 0, -1, 115), "int32"),       # beyond it: generic family
+                                      ((-3, -60, -4, 5), "int32"),      # (Lmax + 1) * |del| alone takes 10 500 of the window
+                                      ((-30, -30, -40, 50), "u16")])
+def test_plan_biased_u16_window(sc, cells):
+    """The biased-u16 cells (CellOps<CF_U16>): the stored-cell bound of the 128-row period must fit what +-15 800 leaves after
+    the end offsets ((Lmax + 1) * |del|) and a few single scores (FastPlan::u16_lim)."""
     mn, ms = synth.make_monomers(12, seed=3)
     info = lib.plan_info(ms, scoring=sc)
-    assert info["family"] == "fast" and info["cells"] == cells and info["rebase"] == rebase, info
+    assert info["cells"] == cells, info
+    if cells == "u16":
+        lmax = max(len(m) for m in ms)
+        g = 1
+        import math
+        g = math.gcd(math.gcd(abs(sc[0]), abs(sc[1])), math.gcd(abs(sc[2]), abs(sc[3]))) or 1
+        room = 15800 - (lmax + 1) * abs(sc[1] // g) - 8 * max(abs(x // g) for x in sc)
+        assert info["range_bound"] <= room, (info, room)
 
 
 def test_plan_layouts_of_the_baseline_sets_and_fuzz_fixtures():
     mn, ms = synth.make_monomers(12, seed=1)
     c2 = lib.plan_info(ms)
-    assert (c2["cells_per_lane"], c2["cells"], c2["waves"]) == (35, "f16", 1) and c2["floor_slots"] <= 16, c2
+    assert (c2["cells_per_lane"], c2["cells"], c2["waves"]) == (35, "u16", 1) and c2["floor_slots"] <= 16, c2
+    c2f = lib.plan_info(ms, flags=lib.FLAG_NO_U16)
+    assert (c2f["cells_per_lane"], c2f["cells"], c2f["waves"]) == (35, "f16", 1), c2f
     mn, ms = synth.make_monomers(64, seed=1)
     c4 = lib.plan_info(ms)
     assert c4["cells"] == "f16/bf8-table" and c4["cells_per_lane"] == 176 and c4["floor_slots"] <= 32, c4
@@ -620,7 +646,8 @@ def test_plan_layouts_of_the_baseline_sets_and_fuzz_fixtures():
     fz = os.path.join(GOLDEN, "fuzz")
     # the scoring that overran fp16 before the range bound charged B's growth (seed 906)
     mn, ms, _ = lib.fasta_load(os.path.join(fz, "fuzz_fail_906_791", "m.fa"))
-    assert lib.plan_info(ms, scoring=(0, -4, -4, -1))["cells"] == "int16"
+    assert lib.plan_info(ms, scoring=(0, -4, -4, -1), flags=lib.FLAG_NO_U16)["cells"] == "int16"
+    assert lib.plan_info(ms, scoring=(0, -4, -4, -1))["cells"] == "u16"
     # the 5-bp template whose first lane must keep two cells (seed 1301)
     mn, ms, _ = lib.fasta_load(os.path.join(fz, "fuzz_fail_1301_1135", "m.fa"))
     assert lib.plan_info(ms, scoring=(-9, -7, -8, 9))["min_first_lane_cells"] >= 2
