@@ -93,6 +93,20 @@ def test_c4_64_monomers_second_best_final_and_alt_tsv(tmp_path, oracle):
         assert f[:5] == b[:5] and f[5:11] == ["None", "-1.00", "None", "-1.00", "None", "-1.00"]
 
 
+def test_c4_full_size_raw_tsv_equals_the_reference_binary():
+    """BASELINE config 4 at its full size -- 64 monomers (128 templates) x 256 reads x 50 kb, 305 G cells -- every row of the
+    raw TSV against the REAL reference: sha256 of what oracle/_ref/dp printed for this input in the build container
+    (tests/golden/make_fullsize_hashes.py; ~25 minutes of the reference's CPU path, not repeated here)."""
+    with open(os.path.join(GOLDEN, "fullsize_sha256.json")) as f:
+        gold = json.load(f).get("c4")
+    assert gold, "tests/golden/fullsize_sha256.json has no c4 entry: run tests/golden/make_fullsize_hashes.py <threads> c4"
+    mn, ms = synth.make_monomers(64, seed=11)
+    rn, rs = synth.make_reads(ms, 256, read_len=50000, seed=14)
+    got = lib.decompose(rn, rs, mn, ms, threads=min(64, os.cpu_count() or 1))
+    assert got.count(b"\n") == gold["rows"] and len(got) == gold["bytes"]
+    assert hashlib.sha256(got).hexdigest() == gold["sha256"]
+
+
 def test_c5_200mb_single_sequence_chunk_ranges_and_oracle(oracle):
     mb = 200
     mn, ms = synth.make_monomers(12, seed=1)

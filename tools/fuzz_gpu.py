@@ -59,6 +59,15 @@ for case in range(cases):
             return ((Lmax - 1) * d + 129 * max(0, max(mm_, ma_) + d) + 128 * i_ + 8 * max(i_, d, abs(mm_), abs(ma_)) + 8)
         d = max([x for x in range(0, 40) if ub(x) <= 2040] or [0])
         sc = (-i_, -d, mm_, ma_)
+    elif rnd(5) == 0:   # round 6: the largest match score still inside the biased-u16 window of the narrow layout
+        Lmax, i_, d_, mm_ = max(len(m) for m in ms), rnd(4), rnd(6), rnd(9) - 6   # (csrc/sd_fast.hip: ub_of(128) <= u16_room)
+        def fits(ma_):
+            mx = max(i_, d_, abs(mm_), abs(ma_))
+            ub = (Lmax - 1) * d_ + 129 * max(0, max(mm_, ma_) + d_) + 128 * i_ + 8 * mx + 8
+            return ub <= 15800 - (Lmax + 1) * d_ - 8 * mx
+        ok_ = [x for x in range(1, 120) if fits(x)]
+        if ok_:
+            sc = (-i_, -d_, mm_, max(ok_) - rnd(2))
     part, ov = [(5000, 500), (700, 100), (333, 77), (150, 20), (5000, 0)][rnd(5)]
     reads = []
     for r in range(1 + rnd(3)):
@@ -90,8 +99,10 @@ for case in range(cases):
     if shape[0] >= 300 and rnd(2):   # the big sets mostly with the filter (their fast form exists only then); sometimes one that keeps everything
         ed = rnd(60) if rnd(6) else 400
     try:
+        # (one run in four with the narrow layout's cell formats of rounds 1-5: fp16 / int16 instead of biased u16)
         got = lib.decompose(rn, reads, mn, ms, scoring=sc, part_size=part, overlap=ov, ed_thr=ed,
-                            threads=1 + rnd(6), max_batch_rows=[0, 0, 200, 1500][rnd(4)])
+                            threads=1 + rnd(6), max_batch_rows=[0, 0, 200, 1500][rnd(4)],
+                            flags=lib.FLAG_NO_U16 if rnd(4) == 0 else 0)
     except lib.SdError as e:
         if e.code == lib.SD_ERR_UNSUPPORTED:
             continue
