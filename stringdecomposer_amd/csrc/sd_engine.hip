@@ -3439,6 +3439,91 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         rc = rec_w.open(records_out, *p, ts.tnames, err);
         if (rc) { close_all(); set_err(errbuf, errlen, err); return rc; }
     }
+    // Round 6: the pages of the _alt file are reserved WHILE THE DEVICE RUNS THE DP.  A --second-best job writes 2T rows of
+    // text per block (280 MB at BASELINE config 4) and the page-cache copy of that text bounded the job: on tmpfs the pages
+    // of a new range are zeroed by ONE thread inside fallocate (36-49 ms per 280 MB, sd::write_parts), and that could only
+    // begin when the first identities arrived, 20 ms into the job.  The size of the file is known closely from the reads
+    // alone -- every base ends up in a block (main.cpp:217-269), a block prints one row per template -- so a helper thread
+    // reserves that much in steps of 16 MB from the start of the job (short steps: write_parts' own fallocate of a range
+    // that already has its pages, and the page faults of the copying threads, take the inode's lock in between); the file
+    // is cut to its real size at the end.  Only with -i 0 (a higher threshold drops rows, main.py:152), only on tmpfs /
+    // ramfs (where write_parts copies through a mapping), only for texts of at least 32 MB.
+    // The reserved range is mapped ONCE for the job and the helper also fills its page tables (MADV_POPULATE_WRITE on pages
+    // that exist is a walk, not an allocation): a hand-over's _alt text is then a plain parallel copy -- the per-hand-over
+    // fallocate / mmap / 8 000 minor faults / munmap of write_parts made eight 34-MB writes take 5.5-7 ms each, back to
+    // back on the writer thread from the first identities to 30 ms after the last (profiles/r06_c4_second_best_timeline.txt).
+    std::thread prealloc;
+    std::atomic<bool> pre_stop{false};
+    std::atomic<int64_t> pre_done{0};
+    char* alt_map = nullptr;
+    int64_t alt_map_len = 0;
+    int64_t alt_unmapped = 0;   // the mapping below this (page-aligned) offset is gone again
+    {
+        struct statfs fs;
+        const bool ram = ::fstatfs(fa, &fs) == 0 && ((unsigned long)fs.f_type == 0x01021994ul || (unsigned long)fs.f_type == 0x858458f6ul);
+        double lmean = 0, nmean = 0;
+        for (const sd::Seq& m : monos) { lmean += (double)m.seq.size(); nmean += (double)m.name.size() + 0.5; }   // (half of the templates carry the "'")
+        lmean /= std::max<size_t>(1, monos.size());
+        nmean /= std::max<size_t>(1, monos.size());
+        double est = 0;
+        auto digits = [](int64_t v) { int d = 1; while (v >= 10) { v /= 10; ++d; } return d; };
+        for (const ReadView& r : reads)
+            est += ((double)r.len / std::max(1.0, lmean) + 1.0) * (2.0 * (double)monos.size()) *
+                   ((double)r.name_len + nmean + 2.0 * digits(r.len) + 5 + 1 + 6);
+        const int64_t want = (int64_t)est;
+        if (second_best && min_identity <= 0 && ram && want >= (32 << 20) && sd::write_parts_fallocate_ok() && !getenv("SD_ALT_PREALLOC_OFF"))
+        {
+            void* mp = getenv("SD_ALT_MAP_OFF") ? MAP_FAILED : ::mmap(nullptr, (size_t)want, PROT_READ | PROT_WRITE, MAP_SHARED, fa, 0);
+            if (mp != MAP_FAILED) { alt_map = static_cast<char*>(mp); alt_map_len = want; }
+            prealloc = std::thread([&, want]() {
+                const double tp0 = now_s();
+                const int64_t step = 16 << 20;
+                for (int64_t at = 0; at < want && !pre_stop.load(std::memory_order_relaxed); at += step) {
+                    const int64_t n = std::min(step, want - at);
+                    if (::fallocate(fa, 0, (off_t)at, (off_t)n) != 0) break;   // (no space: write_parts reports it)
+                    pre_done.store(at + n, std::memory_order_release);
+#ifdef MADV_POPULATE_WRITE
+                    if (alt_map) (void)::madvise(alt_map + at, (size_t)n, MADV_POPULATE_WRITE);
+#endif
+                }
+                if (getenv("SD_TIMING"))
+                    std::fprintf(stderr, "[sd timing] _alt pages reserved ahead: %lld of %lld bytes in %.1f ms (from %.1f ms into the job)\n",
+                                 (long long)pre_done.load(), (long long)want, (now_s() - tp0) * 1e3, (tp0 - t_begin) * 1e3);
+            });
+        }
+    }
+    auto end_prealloc = [&]() {   // before the files are closed, on every path
+        pre_stop.store(true);
+        if (prealloc.joinable()) prealloc.join();
+        if (pre_done.load() > off_a) (void)!::ftruncate(fa, (off_t)off_a);
+        if (alt_map) {   // (what write_alt has not unmapped yet: the page of the file's end and the unused rest of the estimate)
+            if (alt_unmapped < alt_map_len) ::munmap(alt_map + alt_unmapped, (size_t)(alt_map_len - alt_unmapped));
+            alt_map = nullptr;
+        }
+    };
+    // a hand-over's _alt text: into the job's mapping where its pages are reserved, else as every other text
+    auto write_alt = [&](const std::vector<sd::TextBuf>& parts) -> bool {
+        std::vector<int64_t> at(parts.size() + 1, off_a);
+        for (size_t i = 0; i < parts.size(); ++i) at[i + 1] = at[i] + (int64_t)parts[i].size();
+        if (alt_map && at[parts.size()] <= pre_done.load(std::memory_order_acquire)) {
+            sd::parallel_for((int64_t)parts.size(), p->threads, 1, [&](int64_t i) {
+                const sd::TextBuf& q = parts[(size_t)i];
+                if (q.size()) std::memcpy(alt_map + at[(size_t)i], q.data(), q.size());
+            });
+            off_a = at[parts.size()];
+            // The pages behind the text just written leave the mapping at once, on this (the writer's) thread: taking all
+            // 70 000 page-table entries of a 280-MB file down at the end of the job was 10-13 ms on the job's critical
+            // path -- or, from a detached thread, on the mmap lock of whatever the process did next.
+            const int64_t pg = (int64_t)::sysconf(_SC_PAGESIZE);
+            const int64_t upto = off_a / pg * pg;
+            if (upto > alt_unmapped) {
+                ::munmap(alt_map + alt_unmapped, (size_t)(upto - alt_unmapped));
+                alt_unmapped = upto;
+            }
+            return true;
+        }
+        return sd::write_parts(fa, off_a, parts, p->threads);
+    };
     RowJob job;
     job.n_reads = (int32_t)reads.size();
     job.threads = p->threads;
@@ -3447,6 +3532,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     lap("chunk table");
     job.row_off = static_cast<int64_t*>(std::calloc(reads.size() + 1, sizeof(int64_t)));
     if (!job.row_off) {
+        end_prealloc();
         close_all();
         set_err(errbuf, errlen, "out of host memory");
         return SD_ERR_INTERNAL;
@@ -3554,11 +3640,15 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
             }
             io_cv.notify_all();
             const double t0 = now_s();
+            const int64_t a0 = off_a;
             if (sink_rc.load() == SD_OK &&
                 (!sd::write_parts(fr, off_r, j.raw, p->threads) || !sd::write_parts(ff, off_f, j.fin, p->threads) ||
-                 !sd::write_parts(fa, off_a, j.alt, p->threads)))
+                 !write_alt(j.alt)))
                 sink_fail(SD_ERR_IO, std::string("short write to ") + raw_tsv_out);
             t_io += now_s() - t0;
+            if (timing)
+                std::fprintf(stderr, "[sd timing] write of a hand-over: %.1f MB of _alt rows in %.1f ms, at %.1f ms into the job\n",
+                             (double)(off_a - a0) / 1e6, (now_s() - t0) * 1e3, (now_s() - t_begin) * 1e3);
             g_textpool.give(std::move(j));
         }
     };
@@ -3724,6 +3814,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
     io_cv.notify_all();
     io_thread.join();
     if (rc == SD_OK && sink_rc.load()) { rc = sink_rc.load(); err = sink_err; }
+    end_prealloc();
     if (!close_all() && rc == SD_OK) { rc = SD_ERR_IO; err = std::string("short write to ") + raw_tsv_out; }
     if (records_out && rc == SD_OK) rc = rec_w.close(err, records_out);
     if (timing)
