@@ -61,6 +61,7 @@ typedef struct sd_params {
 #define SD_FLAG_FILTER_GENERAL 8   /* --ed_thr: the general prefilter kernel instead of the uniform one             */
 #define SD_FLAG_NO_STREAM_IDENT 16 /* sd_run_files: identities from the read text in the post-processing (round 2)  */
 #define SD_FLAG_TRACE_V1 64        /* the one-block int32 traceback (sd_fast_trace) where the packed two-block form would run */
+#define SD_FLAG_NO_IDENT_PRUNE 256 /* sd_run_files --second-best: every homopolymer-compressed pair aligned in full (rounds 3-5; A/B) */
 #define SD_FLAG_PROGRESS 32        /* sd_run_files: the reference binary's progress lines on stderr ("Scores: ...",
                                       "Prepared reads", "<p>%: Aligned <read>", main.cpp:82,115,393); the command line sets it */
 

@@ -102,6 +102,29 @@ struct AllocTimer {
     ~AllocTimer() { g_alloc_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
+// hipFree and hipHostFree wait for EVERY queue of the process (a barrier packet and a completion handler per hardware queue).
+// Issued while batch pipelines had work in flight -- a pinned buffer that had to grow in sd_engine_fetch, a small device
+// buffer in a load -- that wait never returned on this runtime once the process held enough queues (AMD_LOG_LEVEL=4: "hsa_amd_
+// signal_async_handler() failed to set the handler!" on the last queue, then nothing; round 6, found by running two tests of
+// the GPU suite on their own; rounds 1-5 had the same calls).  So nothing is handed back to the runtime on a hot path any
+// more: a block that is replaced goes to its pool where one exists, else on this list, which sd_release_cache() empties --
+// the caller's statement that the device is idle.  Buffers grow by doubling, so the list stays below what is in use.
+struct DeferredFrees {
+    std::mutex m;
+    std::vector<void*> dev, host;
+    void dev_later(void* p) { if (p) { std::lock_guard<std::mutex> g(m); dev.push_back(p); } }
+    void host_later(void* p) { if (p) { std::lock_guard<std::mutex> g(m); host.push_back(p); } }
+    void drain() {
+        std::lock_guard<std::mutex> g(m);
+        for (void* p : dev) (void)hipFree(p);
+        for (void* p : host) (void)hipHostFree(p);
+        dev.clear();
+        host.clear();
+    }
+};
+static DeferredFrees& g_deferred_ref() { static DeferredFrees* d = new DeferredFrees; return *d; }
+#define g_deferred g_deferred_ref()
+
 // Page-locked blocks that change hands: the identity words of a batch (up to 2 x 84 MB with --second-best) go with
 // the batch's rows to the thread that turns them into text, while the engine already fetches the next batch; a freed
 // block waits here for the next taker instead of going through hipHostFree / hipHostMalloc (milliseconds per 10 MB).
@@ -114,7 +137,8 @@ struct PinPool {
             std::lock_guard<std::mutex> g(m);
             size_t best = free_.size();
             for (size_t i = 0; i < free_.size(); ++i)
-                if (free_[i].bytes >= bytes && (best == free_.size() || free_[i].bytes < free_[best].bytes)) best = i;
+                if (free_[i].bytes >= bytes && free_[i].bytes <= 2 * bytes + ((size_t)1 << 20) &&   // (no 80-MB block for a 4-byte flag)
+                    (best == free_.size() || free_[i].bytes < free_[best].bytes)) best = i;
             if (best < free_.size()) {
                 Blk b = free_[best];
                 free_.erase(free_.begin() + (long)best);
@@ -133,8 +157,8 @@ struct PinPool {
         if (!p) return;
         std::lock_guard<std::mutex> g(m);
         free_.push_back(Blk{p, bytes});
-        while (free_.size() > 6) {   // keep a handful; the oldest goes back to the runtime
-            (void)hipHostFree(free_.front().p);
+        while (free_.size() > 12) {   // keep a dozen; the oldest waits for sd_release_cache (no hipHostFree here: see DeferredFrees)
+            g_deferred.host_later(free_.front().p);
             free_.erase(free_.begin());
         }
     }
@@ -154,7 +178,7 @@ struct DevBuf {
     void free_() {
         if (p) {
             if (DevPool::enabled() && cap * sizeof(T) >= DevPool::kMin) g_pool.give(dev, p, cap * sizeof(T));
-            else (void)hipFree(p);
+            else g_deferred.dev_later(p);   // (small: a few KB to 4 MB; no hipFree on a hot path, see DeferredFrees)
         }
         p = nullptr;
         n = 0;
@@ -163,7 +187,9 @@ struct DevBuf {
     size_t cap = 0;  // allocated elements (grow-only: batches of similar size reuse the buffer)
     void alloc(size_t count) {
         if (count == 0) count = 1;
+        const size_t asked = count;
         if (count > cap) {
+            if (cap * sizeof(T) < DevPool::kMin && count < 2 * cap) count = 2 * cap;   // small buffers double (their old blocks wait on a list)
             free_();
             SD_HIP(hipGetDevice(&dev));
             const size_t bytes = count * sizeof(T);
@@ -183,7 +209,7 @@ struct DevBuf {
                 cap = count;
             }
         }
-        n = count;
+        n = asked;
     }
     void upload(const std::vector<T>& h) {
         alloc(h.size());
@@ -201,16 +227,19 @@ struct PinBuf {
     void alloc(size_t count) {
         if (count == 0) count = 1;
         if (count <= cap) return;
+        const size_t want = std::max(count + count / 8, 2 * cap);  // a little slack: batches of similar size reuse it
         free_();
-        const size_t want = count + count / 8;  // a little slack: batches of similar size reuse it
-        AllocTimer at;
-        SD_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), want * sizeof(T), hipHostMallocDefault));
-        cap = want;
+        size_t got = 0;
+        p = static_cast<T*>(g_pinpool.take(want * sizeof(T), got));   // (a block another buffer gave up, or a new one)
+        cap = got / sizeof(T);
+        bytes_ = got;
     }
+    size_t bytes_ = 0;
     void free_() {
-        if (p) (void)hipHostFree(p);
+        if (p) g_pinpool.give(p, bytes_);   // never hipHostFree on a hot path (DeferredFrees)
         p = nullptr;
         cap = 0;
+        bytes_ = 0;
     }
     ~PinBuf() { free_(); }
 };
@@ -305,6 +334,8 @@ struct sd_engine {
     DevBuf<int> d_ilongcnt, d_ickpos;
     DevBuf<uint4> d_ick;
     DevBuf<uint32_t> d_ident, d_identh;
+    DevBuf<uint32_t> d_icand;      // pruned homopolymer pass: pairs to align in full (sd_ident.hpp: IdentArgs::cand_list)
+    DevBuf<int> d_icandcnt;
     uint32_t* h_ident = nullptr;                 // pinned blocks from g_pinpool, owned until a sink takes them
     uint32_t* h_identh = nullptr;
     size_t h_ident_bytes = 0, h_identh_bytes = 0;
@@ -350,7 +381,7 @@ struct sd_engine {
                d_fckbase.bytes() + d_in.bytes() +
                d_B.bytes() + d_argB.bytes() + d_cnt.bytes() + d_recs.bytes() + d_dense.bytes() +
                d_roff.bytes() + d_recchunk.bytes() + d_ilong.bytes() + d_ick.bytes() + d_ickpos.bytes() +
-               d_ident.bytes() + d_identh.bytes();
+               d_ident.bytes() + d_identh.bytes() + d_icand.bytes();
     }
 };
 
@@ -385,6 +416,7 @@ void apply_env_overrides(sd_params& p) {
     if (getenv("SD_FILTER_GENERAL")) p.reserved[1] |= SD_FLAG_FILTER_GENERAL;
     if (on("SD_IDENT_STREAM", '0')) p.reserved[1] |= SD_FLAG_NO_STREAM_IDENT;
     if (on("SD_TRACE", '1')) p.reserved[1] |= SD_FLAG_TRACE_V1;
+    if (on("SD_IDENT_PRUNE", '0')) p.reserved[1] |= SD_FLAG_NO_IDENT_PRUNE;
     if (p.reserved[2] == 0)
         if (const char* ev = getenv("SD_F16_GUARD")) p.reserved[2] = std::max(0, atoi(ev));
 }
@@ -780,6 +812,14 @@ static void engine_alloc_batch(sd_engine* e, int64_t nck) {
             a.grid_long = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->n_cu, ((size_t)192 << 20) / per_block));
             a.long_cnt = e->d_ilongcnt.p; a.long_list = e->d_ilong.p;
             a.out = homo ? e->d_identh.p : e->d_ident.p;
+            // the homopolymer pass in its pruned form (distances, bounds, full alignments of the possible two best only)
+            if (homo && per >= 3 && (int64_t)e->ident_cap * per < ((int64_t)1 << 32) && !(e->p.reserved[1] & SD_FLAG_NO_IDENT_PRUNE)) {
+                e->d_icand.alloc((size_t)e->ident_cap * per);
+                e->d_icandcnt.alloc(1);
+                a.cand_list = e->d_icand.p;
+                a.cand_cnt = e->d_icandcnt.p;
+                a.grid_cand = e->n_cu * 3;
+            }
         };
         fill_args(e->ia_plain, false);
         size_t lanes = sd::ident_ck_lanes(e->ia_plain) * (size_t)e->ia_plain.K;
@@ -1129,14 +1169,14 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
                         e->ia_plain.rec_lo = e->ia_homo.rec_lo = e->d_roff.p + c_lo;
                         e->ia_plain.rec_hi = e->ia_homo.rec_hi = e->d_roff.p + c_hi;
                         sd::launch_ident(ts, e->ia_plain);
-                        if (e->ident_mode == 2) sd::launch_ident(ts, e->ia_homo);
+                        if (e->ident_mode == 2) sd::launch_ident_pruned(ts, e->ia_homo);
                         SD_HIP(hipEventRecord(e->ev_slice[sl], ts));
                         c_lo = c_hi;
                     }
                 } else {
                     e->ia_plain.rec_lo = e->ia_homo.rec_lo = e->ia_plain.rec_hi = e->ia_homo.rec_hi = nullptr;
                     sd::launch_ident(ts, e->ia_plain);
-                    if (e->ident_mode == 2) sd::launch_ident(ts, e->ia_homo);
+                    if (e->ident_mode == 2) sd::launch_ident_pruned(ts, e->ia_homo);
                 }
                 SD_HIP(hipEventRecord(e->ev_id1, ts));
             }
@@ -2285,7 +2325,7 @@ int sd_records_to_raw_tsv(const char* records_path, const char* raw_tsv_out, int
 // chunk-range form: multi-GPU sharding of one job, one process per GPU
 // -------------------------------------------------------------------------------------------
 static void text_pool_clear();
-void sd_release_cache(void) { pipe_cache_clear(); g_pool.release_all(); g_pinpool.release_all(); text_pool_clear(); }
+void sd_release_cache(void) { pipe_cache_clear(); g_pool.release_all(); g_pinpool.release_all(); g_deferred.drain(); text_pool_clear(); }
 
 int64_t sd_chunk_table_size(const int64_t* read_lens, int32_t n_reads, int32_t part_size, int32_t overlap) {
     if (!read_lens || n_reads < 0 || part_size <= 0 || overlap < 0) return -1;

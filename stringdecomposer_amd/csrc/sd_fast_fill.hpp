@@ -298,9 +298,12 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
         guard.start(sc.guard_lim);
         guard.check_low(L, planeMask);
     }
-    if constexpr (HRED) reduce_ends(L[P - 1], 1);
-    K = excl_scan(L[P - 1]);
-    uint32_t Eend = CO::mx(L[P - 1], K);
+    // (a 1-bp template's lane ends at slot 0 in row 0 too: with fp16 cells its pads are -inf and the last slot IS slot 0's
+    // value; the u16 format's pads are finite -- tpad + ins may exceed mm_0 -- so the end is taken where it is)
+    const uint32_t a0 = ONE ? bfi(oneMask, L[0], L[P - 1]) : L[P - 1];
+    if constexpr (HRED) reduce_ends(a0, 1);
+    K = excl_scan(a0);
+    uint32_t Eend = CO::mx(a0, K);
     if constexpr (!HRED) reduce_ends(Eend, 1);
 
     // rows in groups of FAST_R: the per-group work (fairness, scan form, rebase, checkpoint) sits between two inner loops

@@ -35,10 +35,20 @@ struct IdentArgs {
     int* long_cnt;                  // zeroed by launch_ident
     int32_t* long_list;             // rec_cap entries
     uint32_t* out;                  // [record][T]: (dist << 16) | matches; IDENT_NONE where nothing was computed
+    // Pruned homopolymer pass (launch_ident_pruned; round 6): the post-processing reports only the two best templates of the
+    // homopolymer-compressed alignments (main.py:137-146), so every pair first gets its distance alone, the identity bounds
+    // that follow from it pick the pairs that can be among a record's two best, and only those are aligned in full.
+    uint32_t* cand_list = nullptr;  // rec_cap * T entries: output index (record * T + template) of a pair to align in full
+    int* cand_cnt = nullptr;        // zeroed by launch_ident_pruned
+    int grid_cand = 0;
 };
 constexpr uint32_t IDENT_NONE = 0xffffffffu;
 
 void launch_ident(hipStream_t st, const IdentArgs& a);
+// the same outputs for a.homo != 0, T >= 3 and a.cand_list set, computed as described at IdentArgs::cand_list: the words of
+// the pairs that cannot be among a record's two best hold (dist << 16 | the FEWEST matches the distance allows) -- an
+// identity strictly below the record's second best, so the stable sort of main.py:145 never sees them in its first two
+void launch_ident_pruned(hipStream_t st, const IdentArgs& a);
 // bytes of checkpoint workspace (ck) and ints of ckpos for the two launches of launch_ident
 size_t ident_ck_lanes(const IdentArgs& a);
 

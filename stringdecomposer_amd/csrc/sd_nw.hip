@@ -118,15 +118,25 @@ void nw_build_masks(const std::vector<std::string>& ts, int K, std::vector<unsig
 // host driver
 // ---------------------------------------------------------------------------------------------
 namespace {
+// A buffer that has to grow is NOT freed on the spot: hipFree / hipHostFree wait for every stream of the device, and this
+// code runs on the post-processing thread of sd_run_files while the batch pipeline has kernels in flight on three streams --
+// on this runtime a hipHostFree issued there never returned (round 6: the text-based identities of a job that followed a
+// smaller identity call in the same process hung the job; found by running two tests of the suite on their own).  The old
+// block goes on a list that NwCtx::release() empties (sd_release_cache, a change of device); blocks grow by doubling, so
+// the list holds less than the current block.
+struct NwRetired {
+    std::vector<void*> dev, host;
+};
+NwRetired& nw_retired() { static NwRetired* r = new NwRetired; return *r; }
 struct NwBuf {
     void* p = nullptr;
     size_t cap = 0;
     bool need(size_t bytes) {
         if (bytes <= cap) return true;
-        if (p) (void)hipFree(p);
+        if (p) nw_retired().dev.push_back(p);
+        const size_t want = std::max(bytes + bytes / 4 + 4096, 2 * cap);
         p = nullptr;
         cap = 0;
-        const size_t want = bytes + bytes / 4 + 4096;
         if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return false; }
         cap = want;
         return true;
@@ -148,6 +158,10 @@ struct NwCtx {
             b->p = nullptr;
             b->cap = 0;
         }
+        for (void* q : nw_retired().dev) (void)hipFree(q);
+        for (void* q : nw_retired().host) (void)hipHostFree(q);
+        nw_retired().dev.clear();
+        nw_retired().host.clear();
     }
 };
 NwCtx g_nw;
@@ -265,10 +279,10 @@ int nw_identity_device(const std::vector<std::pair<const char*, int64_t>>& spans
     if (g_nw.dev != device) { if (g_nw.dev >= 0) g_nw.release(); g_nw.dev = device; }
     // text -> pinned staging (alphabet checked on the way) -> device
     if ((size_t)text + 8 > g_nw.stage_cap) {
-        if (g_nw.stage) (void)hipHostFree(g_nw.stage);
+        if (g_nw.stage) nw_retired().host.push_back(g_nw.stage);   // (not freed here: see NwRetired)
+        const size_t want = std::max((size_t)text + (size_t)text / 4 + 4096, 2 * g_nw.stage_cap);
         g_nw.stage = nullptr;
         g_nw.stage_cap = 0;
-        const size_t want = (size_t)text + (size_t)text / 4 + 4096;
         if (hipHostMalloc(reinterpret_cast<void**>(&g_nw.stage), want, hipHostMallocDefault) != hipSuccess) return SD_ERR_HIP;
         g_nw.stage_cap = want;
     }

@@ -261,4 +261,48 @@ __device__ __forceinline__ bool nw_pair(Query& q, int ql, const uint2* __restric
     return true;
 }
 
+// Distance only: pass 1 of nw_pair without its checkpoints -- the edit distance and the number of columns (kept query
+// symbols) of the pair.  Half the work of the full pair; what the bounds of the pruned homopolymer pass are made of
+// (sd_ident.hip: sd_ident_dist).
+template <int K, class Query>
+__device__ __forceinline__ void nw_dist(Query& q, int ql, const uint2* __restrict__ eqt, int tl, bool homo,
+                                        int& dist_out, int& cols_out) {
+    constexpr int S = nw_block_cols(K);
+    const int pad = 64 * K - tl;
+    NwState<K> st;
+#pragma unroll
+    for (int b = 0; b < K; ++b) {
+        const int lo = pad - 64 * b;
+        const unsigned long long m = lo <= 0 ? ~0ull : lo >= 64 ? 0ull : (~0ull << lo);
+        st.PvL[b] = (uint32_t)m; st.PvH[b] = (uint32_t)(m >> 32);
+        st.MvL[b] = 0u; st.MvH[b] = 0u;
+    }
+    int score = tl, c = 0, prev = -1, i = 0;
+    auto next_kept = [&](int& r) -> bool {
+        while (i < ql) {
+            r = q.code(i++);
+            const bool skip = homo && r == prev;
+            prev = r;
+            if (!skip) return true;
+        }
+        return false;
+    };
+    while (true) {   // S columns per trip, statically unrolled, as in pass 1 of nw_pair
+        int r0 = 0;
+        if (!next_kept(r0)) break;
+        score += nw_column<K, false>(st, eqt + r0 * K, nullptr, nullptr);
+        ++c;
+#pragma unroll
+        for (int x = 1; x < S; ++x) {
+            int r = 0;
+            const bool got = next_kept(r);
+            const int h = nw_column<K, false>(st, eqt + (got ? r : 0) * K, nullptr, nullptr);
+            score += got ? h : 0;
+            c += got ? 1 : 0;
+        }
+    }
+    dist_out = score;
+    cols_out = c;
+}
+
 }  // namespace sd

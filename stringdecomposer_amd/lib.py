@@ -185,6 +185,7 @@ def _strs(seq):
 
 FLAG_NO_F16, FLAG_FULL_FLOOR, FLAG_NO_EDTHR_COMPACT, FLAG_FILTER_GENERAL, FLAG_NO_STREAM_IDENT, FLAG_PROGRESS = 1, 2, 4, 8, 16, 32
 FLAG_TRACE_V1 = 64
+FLAG_NO_IDENT_PRUNE = 256   # --second-best: every homopolymer-compressed pair aligned in full (no distance-only pruning)
 FLAG_NO_U16 = 128     # narrow layout: fp16 / int16 cells as in rounds 1-5 instead of the biased-u16 format
 
 
