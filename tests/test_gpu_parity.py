@@ -1047,6 +1047,38 @@ def test_in_stream_identities_equal_the_text_based_path_across_batches(tmp_path,
     assert outs["stream"][1].count(b"\n") > 500
 
 
+_FRESH_ORDER = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from stringdecomposer_amd import lib, synth
+mn, ms = synth.make_monomers(6, seed=21)
+tm = [m.decode() for m in ms]
+seq = (ms[0] + ms[1]) * 20
+st = np.arange(0, 3000, 150)
+lib.identity_segments(seq, st, st + 160, tm, False, threads=4, device=0)     # a SMALL device identity call first ...
+rn, rs = synth.make_reads(ms, 14, read_len=9000, seed=22)
+synth.write_fasta(sys.argv[1] + "/r.fa", rn, rs, width=70)
+synth.write_fasta(sys.argv[1] + "/m.fa", mn, ms)
+o = [sys.argv[1] + "/" + x for x in ("raw", "final", "alt")]
+# ... then a job of many device batches whose post-processing thread grows the identity buffers while batches are in flight
+for flags in (0, lib.FLAG_NO_STREAM_IDENT):      # (the in-stream form first, as the suite's own test does: more queues in the process)
+    lib.run_files(sys.argv[1] + "/r.fa", sys.argv[1] + "/m.fa", o[0], o[1], o[2], second_best=False, threads=4, part_size=1000,
+                  overlap=200, max_batch_rows=7000, flags=flags)
+print("done", lib.last_run_stats()["batches"])
+"""
+
+
+@pytest.mark.gpu
+def test_no_device_wide_free_while_batches_are_in_flight(tmp_path):
+    """Round 6: hipFree / hipHostFree wait for every queue of the process; issued from a worker thread while the batch
+    pipeline had kernels in flight (a buffer of the text-based identities that had to grow after a smaller call) that wait
+    never returned -- the job hung.  Latent since round 1 and invisible in the suite's own order; the two-call sequence
+    that showed it, in a process of its own with a deadline."""
+    p = subprocess.run([sys.executable, "-c", _FRESH_ORDER % ROOT, str(tmp_path)], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=180)
+    assert p.returncode == 0 and b"done" in p.stdout, p.stdout.decode()[-2000:]
+
+
 @pytest.mark.gpu
 def test_second_best_job_is_cut_into_device_batches_with_the_same_files(tmp_path, monkeypatch):
     """A --second-best job that fits one device batch: ONE fill / traceback launch, the identities in slices of whole

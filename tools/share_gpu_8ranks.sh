@@ -17,10 +17,10 @@ print("n_gpus=%d reads/rank=%d  ms/step %.1f  rank0: process_cpu_ms/step %.1f (p
     h["d2h_assemble"], h["cpu_quota_cores"]))
 PY
 done
-SD_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --scaling strong --config c3 --reads-total 600 --steps 3 --warmup 1 > $O/strong_c3_gpus2.json 2> $O/strong_c3.err
-SD_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --scaling strong --config c5 --seq-len 20000000 --steps 3 --warmup 1 > $O/strong_c5_gpus2.json 2> $O/strong_c5.err
-timeout 900 python bench.py --scaling strong --config c3 --reads-total 2000 --steps 3 --warmup 1 > $O/strong_c3_gpus1.json 2>> $O/strong_c3.err
-timeout 900 python bench.py --scaling strong --config c5 --seq-len 50000000 --steps 3 --warmup 1 > $O/strong_c5_gpus1.json 2>> $O/strong_c5.err
+SD_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --scaling strong --config c3 --reads-total 600 --steps 6 --warmup 4 > $O/strong_c3_gpus2.json 2> $O/strong_c3.err
+SD_BENCH_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --scaling strong --config c5 --seq-len 20000000 --steps 6 --warmup 4 > $O/strong_c5_gpus2.json 2> $O/strong_c5.err
+timeout 900 python bench.py --scaling strong --config c3 --reads-total 2000 --steps 6 --warmup 4 > $O/strong_c3_gpus1.json 2>> $O/strong_c3.err
+timeout 900 python bench.py --scaling strong --config c5 --seq-len 50000000 --steps 6 --warmup 4 > $O/strong_c5_gpus1.json 2>> $O/strong_c5.err
 for f in $O/strong_*.json; do python3 -c "
 import json,sys; j=json.loads([l for l in open('$f').read().splitlines() if l.startswith('{')][-1]); print('$f'.split('/')[-1], j['n_gpus'], j['scaling'], '%.2f Gbp/s' % (j['value']/1e9), '%.1f ms/step' % j['ms_per_step'], j['config']['share'])"; done
 for e in $O/*.err; do tail -n 3 $e; done
