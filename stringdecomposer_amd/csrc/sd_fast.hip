@@ -340,7 +340,13 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     // with an insertion move -- cannot stand for it at the lane's last slot.  The narrow and the tiled fills take such a
     // lane's end from slot 0 (FLC_ONE); the plain wide layouts do not know the form (such sets take the tiled one).
     const bool has1 = Lmin < 2;
-    if (sc.ins > 0 || sc.del > 0) { why = "positive gap scores"; return false; }
+    // Gap scores.  A positive INSERTION score is taken since round 6: nothing in the kernels depends on its sign -- the stored
+    // domain S = E - base - tp*ins makes the insertion move "keep" whatever ins is, so lane totals still never decrease
+    // between rebases (what the lazy carry and the range guard rely on), and the range bound below charges B's growth per
+    // row with max(0, smax - del, ins).  A positive DELETION score is not: deleting a whole template then GAINS
+    // (L - 1) * del, so B can grow by that much in ONE row (start a template, delete all of it: main.cpp:187-207 allows it)
+    // -- two orders of magnitude beyond what 16-bit cells hold over a 128-row period; such scorings keep the generic family.
+    if (sc.del > 0) { why = "positive deletion score"; return false; }
     if (T > 65535) { why = "too many templates"; return false; }
     auto ab = [](int v) { return v < 0 ? -v : v; };
     const int maxabs = std::max(std::max(ab(sc.ins), ab(sc.del)), std::max(ab(sc.mismatch), ab(sc.match)));
@@ -355,7 +361,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     // large |del|, long templates and non-positive match scores -- e.g. 0,-4,-4,-1 on 480-bp monomers -- the
     // fp16 cells left the exact-integer range; found by tools/fuzz_gpu.py seed 906.)
     const int smax = std::max(sc.match, sc.mismatch);
-    const int64_t G = std::max(0, smax - sc.del);
+    const int64_t G = std::max(std::max(0, smax - sc.del), sc.ins);   // (an insertion at the end cell: B_{i+1} >= B_i + ins, and no more through it)
     auto ub_of = [&](int R) {
         return (int64_t)(Lmax - 1) * ab(sc.del) + (int64_t)(R + 1) * G + (int64_t)R * ab(sc.ins) + 8 * (int64_t)maxabs + 8;
     };

@@ -356,7 +356,7 @@ void fast_plan_trace2(const std::vector<std::string>& tseq, ScoreArgs sc, FastPl
     // candidate of every cell); B moves by at most G = max(0, smax - del) up and |ins| down per row and the row shift
     // adds |ins| per row; base is the B term of the block's first row, a block has 32 rows (+1 for the checkpoint row).
     const int smax = std::max(sc.match, sc.mismatch);
-    const int64_t G = std::max(0, smax - sc.del);
+    const int64_t G = std::max(std::max(0, smax - sc.del), sc.ins);
     const int64_t R2 = (int64_t)(plan.Lmax + 1) * ab(sc.del) + 36 * (G + 2 * (int64_t)ab(sc.ins)) + 8 * (int64_t)maxabs + 16;
     if (4 * R2 + 16 > 15000) return;
     plan.tr2_bound = (int)R2;

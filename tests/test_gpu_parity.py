@@ -654,6 +654,52 @@ def test_template_sets_beyond_the_fast_family_vs_oracle(oracle, nm, lo, hi):
         assert gen == exp, (nm, sc, ed, "generic")
 
 
+@pytest.mark.parametrize("layout", ["narrow12", "narrow3_short", "one_bp", "wide64", "waves140", "tiled30"])
+@pytest.mark.parametrize("sc", [(1, -1, -1, 1), (2, -3, -4, 2), (1, -2, 0, 3), (3, 0, -2, 1)])
+def test_positive_insertion_score_on_the_fast_family_vs_oracle(oracle, layout, sc):
+    """VERDICT r05 (missing 2): the reference takes any scoring (main.cpp:187-207); the fast family refused every positive gap
+    score.  A positive INSERTION score needs nothing from the kernels -- the stored domain S = E - base - tp*ins makes the
+    insertion move 'keep' for any sign, B's growth per row is charged with max(0, smax - del, ins) in the range bound -- so it
+    now runs there on every layout (a positive deletion score cannot: a whole template deleted gains (L - 1) * del in one row).
+    Rows against the oracle and the generic family; reads that are mostly insertions (unrelated sequence), exact repeats,
+    ordinary noise, N; small chunks (many seams), --ed_thr."""
+    if layout == "narrow12":
+        mn, ms = synth.make_monomers(12, seed=5)
+    elif layout == "narrow3_short":
+        mn, ms = synth.make_monomers(3, seed=6)
+        ms = [m[:40 + 9 * j] for j, m in enumerate(ms)]
+    elif layout == "one_bp":
+        mn, ms = synth.make_monomers(4, seed=7)
+        ms = [ms[0][:60], b"A", ms[1][:33], b"GC"]
+    elif layout == "wide64":
+        mn, ms = synth.make_monomers(64, seed=8)
+    elif layout == "waves140":
+        mn, ms = synth.make_monomers(140, seed=9)
+    else:
+        mn, ms = synth.make_monomers(60, seed=3)
+        ms = [ms[2 * j] + ms[2 * j + 1] for j in range(30)]
+    mn = ["m%d" % j for j in range(len(ms))]
+    info = lib.plan_info(ms, scoring=sc)
+    if info["family"] != "fast":
+        assert layout in ("waves140", "tiled30") or max(sc) > 2, (info, "only the multi-wave layouts may leave the 16-bit range")
+        pytest.skip("beyond the 16-bit range of this layout: " + info["why"])
+    st = synth.Stream(61, len(ms))
+    rn, rs = synth.make_reads(ms, 2, read_len=2600 if len(ms) > 20 else 7000, seed=12)
+    big = max(ms, key=len)
+    rs = list(rs) + [synth._ACGT[st.below(1500, 4)].tobytes(), (big * 30)[:1800], b"T" * 90 + big * 2 + b"N" * 5 + ms[0] * 3, b"C", b"GA"]
+    rn = ["r%d" % i for i in range(len(rs))]
+    for part, ov, ed in ((5000, 500, -1), (400, 60, -1), (700, 100, 25)):
+        exp = oracle.decompose(rn, rs, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc, part=part, overlap=ov, ed_thr=ed)
+        t0 = lib.guard_trips()
+        got = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, scoring=sc, part_size=part, overlap=ov, ed_thr=ed)
+        assert got == exp, (layout, sc, part, ed)
+        assert lib.guard_trips() == t0, (layout, sc, "the plan's bound did not hold")
+        if layout.startswith("narrow") or layout == "one_bp":   # the cell formats of rounds 1-5 and the one-block traceback too
+            assert lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, scoring=sc, part_size=part, overlap=ov, ed_thr=ed,
+                                 flags=lib.FLAG_NO_U16 | lib.FLAG_TRACE_V1) == exp, (layout, sc, part, ed, "legacy cells")
+        assert lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_GENERIC, scoring=sc, part_size=part, overlap=ov, ed_thr=ed) == exp
+
+
 @pytest.mark.parametrize("nm,lo,hi,waves", [(24, 400, 420, 2), (5, 950, 1000, 1), (40, 230, 700, None), (90, 120, 330, None)])
 def test_tiled_multiwave_layout_vs_oracle(oracle, nm, lo, hi, waves):
     """csrc/sd_fast_wt.hip: template sets beyond the narrow layout (8192 cells in one wave) whose templates are longer

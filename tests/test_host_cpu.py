@@ -622,7 +622,11 @@ def test_plan_layouts_of_the_baseline_sets_and_fuzz_fixtures():
     mn, ms = synth.make_monomers(70, seed=1)
     w1 = lib.plan_info(list(ms) + [b"G"])                                      # in a set beyond one wave: the tiled layout knows the form too
     assert (w1["family"], w1["cells"]) == ("fast", "f16/bf8-codes tiled x waves"), w1
-    assert lib.plan_info([b"ACGTACGT"], scoring=(1, -1, -1, 1))["family"] == "generic"   # positive gap score
+    assert lib.plan_info([b"ACGTACGT"], scoring=(-1, 1, -1, 1))["family"] == "generic"   # positive DELETION score: a deleted template gains
+    assert lib.plan_info([b"ACGTACGT"], scoring=(1, -1, -1, 1))["family"] == "fast"      # positive insertion score: taken since round 6
+    mn12, ms12 = synth.make_monomers(12, seed=1)
+    pi = lib.plan_info(ms12, scoring=(2, -3, -4, 2))
+    assert (pi["family"], pi["cells"]) == ("fast", "u16") and pi["range_bound"] >= 129 * 5, pi   # B may grow by smax - del = 5 a row
     # templates longer than the widest lane (224 slots) in a set beyond one wave of the narrow layout: tiled over the
     # virtual lanes of up to eight waves (sd_fast_wt.hip); the slot count with the least SIMD time per row at the occupancy it gets
     st = synth.Stream(5, 5)

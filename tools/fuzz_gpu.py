@@ -53,6 +53,8 @@ for case in range(cases):
           (-1, -1, -1, -1), (-4, -4, 3, 3)][rnd(14)]
     if rnd(3) == 0:   # random scorings: exercises both cell formats (fp16 / int16) around the range switch
         sc = (-rnd(9), -rnd(9), rnd(13) - 8, rnd(13) - 2)
+    if rnd(7) == 0:   # round 6: a positive insertion score (the fast family takes it; a positive deletion score stays generic)
+        sc = (1 + rnd(3), -rnd(5), rnd(9) - 6, rnd(6))
     if rnd(4) == 0:   # the largest |del| that still selects fp16 cells for this set (csrc/sd_fast.hip: ub <= 2040)
         Lmax, i_, mm_, ma_ = max(len(m) for m in ms), rnd(3), rnd(7) - 5, rnd(5) - 2
         def ub(d):
