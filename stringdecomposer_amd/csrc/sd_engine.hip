@@ -1185,6 +1185,12 @@ static int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char* errbu
         SD_HIP(hipEventRecord(e->ev_run1, ts));
         SD_HIP(hipGetLastError());
     } catch (const HipFail& f) {
+        // sd_scan_compact takes its range from (device ticket counter - the host's count of tickets handed out): a launch
+        // that was rejected, or a kernel that died before every workgroup drew its ticket, leaves the two apart for the
+        // life of the workspace -- later launches would then wait on counts nobody publishes.  After any error the
+        // workspace is dropped: the next run allocates and zeroes a new one and counts from zero.
+        e->d_scanws.free_();
+        e->scan_tickets = 0;
         set_err(errbuf, errlen, f.msg);
         return SD_ERR_HIP;
     }
@@ -1939,7 +1945,9 @@ static int run_chunk_batches(const std::vector<ReadView>& reads, const std::vect
     const int rc2 = pipe.drain();
     if (rc == SD_OK) rc = rc2;
     if (rc) err = pipe.eb;
-    if (rc == SD_OK && busy_rc) { rc = busy_rc; err = busy_err; }
+    // an undefined symbol in the share is the reference's own diagnostic (main.cpp:335): it is what the caller sees, also
+    // when the device run over those bytes failed as well
+    if (busy_rc) { rc = busy_rc; err = busy_err; }
     if (timing)
         std::fprintf(stderr, "[sd timing] host work under the device: %.2f ms\n", t_busy * 1e3);
     if (timing)
@@ -2905,7 +2913,7 @@ int sd_range_assemble_write(sd_range_asm* h, const char* path, int64_t offset, i
     const double t0 = now_s();
     // file_bytes >= 0: every rank creates the file if it is not there and sets its size (the same value on every rank,
     // so the order of the ranks does not matter and no rank waits for another before it writes)
-    const int fd = file_bytes >= 0 ? ::open(path, O_WRONLY | O_CREAT, 0644) : ::open(path, O_WRONLY);
+    const int fd = file_bytes >= 0 ? ::open(path, O_WRONLY | O_CREAT, 0666) : ::open(path, O_WRONLY);
     if (fd < 0) { set_err(errbuf, errlen, std::string("cannot write ") + path); return SD_ERR_IO; }
     if (file_bytes >= 0 && ::ftruncate(fd, (off_t)file_bytes) != 0) {
         ::close(fd);

@@ -132,6 +132,21 @@ def _assemble_by_ranks(dist, rank, ws, make, raw_tsv_out=None, stats=None, refus
     from . import lib
     failure, a, edge = None, None, None
     t0 = time.perf_counter()
+    # Every rank writes its own byte range of `raw_tsv_out`: that is one file only where the ranks see one file system.  On
+    # a multi-node launch without a shared output directory rank 0's file would keep zero-filled holes and the job would
+    # still report success.  So rank 0 leaves a token beside the output before the DP, the token travels with
+    # the edges, every rank looks for it after that exchange and says what it found in the exchange of the text sizes: if
+    # any rank did not see it, the texts are gathered on rank 0, which writes the file alone -- as in rounds 1-4.
+    token, probe = None, None
+    if raw_tsv_out is not None:
+        probe = raw_tsv_out + ".ranks-share-this-directory"
+        if rank == 0:
+            try:
+                token = os.urandom(16).hex()
+                with open(probe, "w") as f:
+                    f.write(token)
+            except OSError:
+                token = None
     try:
         a = make()
         edge = a.edge
@@ -139,9 +154,18 @@ def _assemble_by_ranks(dist, rank, ws, make, raw_tsv_out=None, stats=None, refus
         failure = _status_of(e)
     t1 = time.perf_counter()
     box = [None] * ws
-    dist.all_gather_object(box, (failure, edge))
+    dist.all_gather_object(box, (failure, edge, token))
     t2 = time.perf_counter()
     first = next((b[0] for b in box if b[0] is not None), None)
+    sees_file = True
+    if raw_tsv_out is not None:
+        try:
+            with open(probe) as f:
+                sees_file = box[0][2] is not None and f.read() == box[0][2]
+        except OSError:
+            sees_file = False
+        if os.environ.get("SD_SHARD_FAKE_UNSHARED") == str(rank):   # (test hook: this rank behaves as if on another node)
+            sees_file = False
     try:
         if first is not None:
             raise lib.SdError(*first)
@@ -164,14 +188,34 @@ def _assemble_by_ranks(dist, rank, ws, make, raw_tsv_out=None, stats=None, refus
             failure = _status_of(e)
         t3 = time.perf_counter()
         sizes = [None] * ws
-        dist.all_gather_object(sizes, (failure, n))
+        dist.all_gather_object(sizes, (failure, n, sees_file))
         first = next((b[0] for b in sizes if b[0] is not None), None)
         if first is not None:
             raise lib.SdError(*first)
+        shared = all(b[2] for b in sizes)
         sizes = [b[1] for b in sizes]
         t4 = time.perf_counter()
         text = None
-        if raw_tsv_out is not None:
+        if raw_tsv_out is not None and not shared:
+            # not one file system: the texts travel to rank 0, which writes the whole file
+            mine = None
+            try:
+                mine = a.bytes()
+            except Exception as e:
+                failure = _status_of(e)
+            _raise_first(dist, ws, failure)
+            got = [None] * ws if rank == 0 else None
+            dist.gather_object(mine, got, dst=0)
+            if rank == 0:
+                try:
+                    with open(raw_tsv_out, "wb") as f:
+                        f.write(b"".join(got))
+                except Exception as e:
+                    failure = _status_of(e)
+            _raise_first(dist, ws, failure)
+            if stats is not None:
+                stats["gathered_because_not_one_file_system"] = True
+        elif raw_tsv_out is not None:
             try:
                 a.write(raw_tsv_out, sum(sizes[:rank]), sum(sizes))
             except Exception as e:
@@ -196,6 +240,11 @@ def _assemble_by_ranks(dist, rank, ws, make, raw_tsv_out=None, stats=None, refus
     finally:
         if a is not None:
             a.close()
+        if probe is not None and rank == 0:
+            try:
+                os.remove(probe)
+            except OSError:
+                pass
 
 
 def decompose_sharded(read_names, read_seqs, mono_names, mono_seqs, dist=None, range_fn=None, **params):

@@ -616,3 +616,46 @@ def test_a_failure_of_one_rank_behind_the_edge_exchange_is_raised_on_every_rank(
         assert p.exitcode == 0
     assert [r[1] for r in res] == ["err", "err"], res
     assert all(r[2][0] == lib.SD_ERR_INTERNAL and "MemoryError" in r[2][1] for r in res)
+
+
+def _unshared_worker(rank, ws, port, q, tmp):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(ws),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ["SD_SHARD_FAKE_UNSHARED"] = "1"      # rank 1 behaves as if its output directory were another node's
+    dist = shard.init_process_group("gloo")
+    st = {}
+    raw = os.path.join(tmp, "raw.tsv")
+    ok = shard.decompose_files_sharded(os.path.join(tmp, "r.fa"), os.path.join(tmp, "m.fa"), raw, dist,
+                                       range_fn=_seam_files_fn, part_size=_SEAM_PART, overlap=_SEAM_OV, threads=2,
+                                       assemble_stats=st)
+    q.put((rank, ok, st.get("gathered_because_not_one_file_system", False)))
+    dist.destroy_process_group()
+
+
+def test_ranks_that_do_not_share_the_output_directory_gather_on_rank_0(tmp_path):
+    """every rank writes its own byte range of the raw TSV, which is one file only on one file system.  A rank
+    that does not find rank 0's token beside the output makes ALL ranks send their texts to rank 0 instead (decided in
+    the exchange of the text sizes, before anybody writes): same bytes, no holes, no silent success."""
+    from stringdecomposer_amd import lib
+    with open(tmp_path / "r.fa", "w") as f:
+        for i, n in enumerate(_SEAM_READS):
+            f.write(">r%d\n%s\n" % (i, "A" * n))
+    with open(tmp_path / "m.fa", "w") as f:
+        for i in range(3):
+            f.write(">m%d\nACGT\n" % i)
+    ws, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_unshared_worker, args=(r, ws, port, q, str(tmp_path))) for r in range(ws)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(ws))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    recs, off = _seam_job()
+    want = lib.assemble_tsv(["r%d" % i for i in range(len(_SEAM_READS))], _SEAM_READS, ["m0", "m1", "m2"], recs, off,
+                            part_size=_SEAM_PART, overlap=_SEAM_OV, threads=2)
+    assert (tmp_path / "raw.tsv").read_bytes() == want
+    assert all(r[2] for r in res), res
+    assert not [f for f in os.listdir(tmp_path) if "ranks-share" in f]
