@@ -391,6 +391,9 @@ int32_t sd_pack_bases(const char* seq, int64_t n, uint32_t* words, uint32_t* nma
  * ENOSPC as SD_ERR_IO instead of dying of SIGBUS.  out (may be NULL): [0] bytes written, [1] 1 on tmpfs / ramfs. */
 int sd_write_parts_selftest(const char* path, int32_t n_parts, int64_t part_bytes, int32_t threads,
                             int32_t fail_reserve, int64_t out[2]);
+/* Host only (CPU test): the pipeline-cache key (which jobs share cached engines) and the batch planner (how a job is cut
+ * into device batches) against their contracts, without a device; SD_OK, or SD_ERR_INTERNAL with the broken property. */
+int sd_pipeline_logic_selftest(char* errbuf, size_t errlen);
 /* Rates of the host stages alone (no device): out[0] = chunk table + 2-bit packing, bp/s; out[1] = per-read
  * assembly (chunk offsets, seam merge) + raw TSV text of one synthetic record per 171 bases, bp/s; out[2] =
  * TSV rows/s; out[3] = bytes of text per pass.  p->threads host threads, `iters` passes over the reads. */

@@ -25,6 +25,7 @@ SD_ERR_SYMBOL = 255
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_FAST = 0, 1, 2
 
 EXPORTS = [
+    "sd_pipeline_logic_selftest",
     "sd_params_default", "sd_version", "sd_device_count", "sd_free", "sd_decompose_files",
     "sd_decompose", "sd_engine_create", "sd_engine_destroy", "sd_engine_load_reads",
     "sd_engine_run", "sd_engine_fetch", "sd_engine_assemble", "sd_engine_timings",
