@@ -469,10 +469,14 @@ static void engine_alloc_batch(sd_engine* e, int64_t nck) {
             // the homopolymer pass in its pruned form (distances, bounds, full alignments of the possible two best only)
             if (homo && per >= 3 && (int64_t)e->ident_cap * per < ((int64_t)1 << 32) && !(e->p.reserved[1] & SD_FLAG_NO_IDENT_PRUNE)) {
                 e->d_icand.alloc((size_t)e->ident_cap * per);
-                e->d_icandcnt.alloc(1);
+                e->d_icandcnt.alloc(64);
                 a.cand_list = e->d_icand.p;
                 a.cand_cnt = e->d_icandcnt.p;
                 a.grid_cand = e->n_cu * 3;
+                e->d_ick2.alloc((size_t)a.grid_cand * 256 * (size_t)a.cap_short * (size_t)a.K);
+                e->d_ickpos2.alloc((size_t)a.grid_cand * 256 * (size_t)a.cap_short);
+                a.ck_cand = e->d_ick2.p;
+                a.ckpos_cand = e->d_ickpos2.p;
             }
         };
         fill_args(e->ia_plain, false);
@@ -817,20 +821,50 @@ extern "C++" int engine_run2(sd_engine* e, hipStream_t st, hipStream_t ts, char*
                         SD_HIP(hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming));
                         e->ev_slice.push_back(ev);
                     }
+                    // the candidate stage of slice s on its own stream, beside the kernels of slice s + 1 (per-slice counter,
+                    // per-slice region of the list, its own checkpoint workspace)
+                    const bool side = e->ident_mode == 2 && e->ia_homo.cand_list && e->slice_end.size() <= 64 && !getenv("SD_IDENT_CAND_INLINE");
+                    if (side) {
+                        if (!e->cand_st) SD_HIP(hipStreamCreateWithFlags(&e->cand_st, hipStreamNonBlocking));
+                        while (e->ev_cand.size() < e->slice_end.size()) {
+                            hipEvent_t ev;
+                            SD_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                            e->ev_cand.push_back(ev);
+                        }
+                        SD_HIP(hipMemsetAsync(e->d_icandcnt.p, 0, 64 * sizeof(int), ts));
+                    }
                     int c_lo = 0;
+                    bool on_side = false;
                     for (size_t sl = 0; sl < e->slice_end.size(); ++sl) {
                         const int c_hi = e->slice_end[sl];
                         e->ia_plain.rec_lo = e->ia_homo.rec_lo = e->d_roff.p + c_lo;
                         e->ia_plain.rec_hi = e->ia_homo.rec_hi = e->d_roff.p + c_hi;
                         sd::launch_ident(ts, e->ia_plain);
-                        if (e->ident_mode == 2) sd::launch_ident_pruned(ts, e->ia_homo);
-                        SD_HIP(hipEventRecord(e->ev_slice[sl], ts));
+                        bool rec_on_side = false;
+                        if (e->ident_mode == 2) {
+                            e->ia_homo.cand_cnt = e->ia_homo.cand_list ? e->d_icandcnt.p + (side ? sl : 0) : nullptr;
+                            if (side) {
+                                if (sd::launch_ident_pruned_front(ts, e->ia_homo)) {
+                                    SD_HIP(hipEventRecord(e->ev_cand[sl], ts));
+                                    SD_HIP(hipStreamWaitEvent(e->cand_st, e->ev_cand[sl], 0));
+                                    sd::launch_ident_pruned_back(e->cand_st, e->ia_homo);
+                                    rec_on_side = on_side = true;
+                                }
+                            } else {
+                                sd::launch_ident_pruned(ts, e->ia_homo);
+                            }
+                        }
+                        SD_HIP(hipEventRecord(e->ev_slice[sl], rec_on_side ? e->cand_st : ts));
                         c_lo = c_hi;
                     }
+                    if (on_side) SD_HIP(hipStreamWaitEvent(ts, e->ev_slice.back(), 0));   // what follows on ts follows the last candidates
                 } else {
                     e->ia_plain.rec_lo = e->ia_homo.rec_lo = e->ia_plain.rec_hi = e->ia_homo.rec_hi = nullptr;
                     sd::launch_ident(ts, e->ia_plain);
-                    if (e->ident_mode == 2) sd::launch_ident_pruned(ts, e->ia_homo);
+                    if (e->ident_mode == 2) {
+                        e->ia_homo.cand_cnt = e->ia_homo.cand_list ? e->d_icandcnt.p : nullptr;
+                        sd::launch_ident_pruned(ts, e->ia_homo);
+                    }
                 }
                 SD_HIP(hipEventRecord(e->ev_id1, ts));
             }

@@ -39,10 +39,13 @@ __global__ __launch_bounds__(256, 3) void sd_ident_pairs(IdentArgs a, int use_li
     const int64_t n_pairs = use_list == 2 ? (int64_t)*a.cand_cnt : n_rec * a.T;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    uint32_t* ckl = reinterpret_cast<uint32_t*>(a.ck) + (size_t)blockIdx.x * (size_t)cap * K * 4 * 256 + threadIdx.x;
-    int* ckp = a.ckpos + (size_t)blockIdx.x * (size_t)cap * 256 + threadIdx.x;
+    void* ckbase = (use_list == 2 && a.ck_cand) ? a.ck_cand : a.ck;
+    int* ckpbase = (use_list == 2 && a.ckpos_cand) ? a.ckpos_cand : a.ckpos;
+    uint32_t* ckl = reinterpret_cast<uint32_t*>(ckbase) + (size_t)blockIdx.x * (size_t)cap * K * 4 * 256 + threadIdx.x;
+    int* ckp = ckpbase + (size_t)blockIdx.x * (size_t)cap * 256 + threadIdx.x;
+    const uint32_t* clist = a.cand_list ? a.cand_list + r_lo * a.T : nullptr;   // this launch's region of the candidate list
     for (int64_t p = gid; p < n_pairs; p += stride) {
-        const int64_t pp = use_list == 2 ? (int64_t)a.cand_list[p] : p;
+        const int64_t pp = use_list == 2 ? (int64_t)clist[p] : p;
         const int64_t xl = pp / a.T;
         const int tq = (int)(pp - xl * a.T);
         const int64_t x = use_list == 1 ? (int64_t)a.long_list[xl] : use_list == 2 ? xl : r_lo + xl;
@@ -131,9 +134,11 @@ __global__ __launch_bounds__(256) void sd_ident_select(IdentArgs a) {
     if (n_tot > a.rec_cap || n_tot > a.dense_cap) return;
     const int64_t r_lo = a.rec_lo ? *a.rec_lo : 0;
     const int64_t n_rec = (a.rec_hi ? *a.rec_hi : n_tot) - r_lo;
+    uint32_t* clist = a.cand_list + r_lo * a.T;
     const int lane = threadIdx.x & 63;
     const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const bool two = a.T <= 128;     // the common case (up to 64 monomers): a lane's two pairs stay in registers between the passes
     for (int64_t xl = wid; xl < n_rec; xl += nw) {
         const int64_t x = r_lo + xl;
         const DevRec rec = a.dense[x];
@@ -141,12 +146,15 @@ __global__ __launch_bounds__(256) void sd_ident_select(IdentArgs a) {
         if (ql <= 0 || ql > a.short_max) continue;   // (nothing computed / the long launch aligns every pair in full)
         // top two lower bounds over the T pairs (a duplicate of the maximum counts twice)
         double m1 = -1.0, m2 = -1.0;
-        for (int t = lane; t < a.T; t += 64) {
+        uint32_t w2[2] = {IDENT_NONE, IDENT_NONE};
+        double ub2[2] = {2.0, 2.0};
+        int ml2[2] = {0, 0};
+        for (int t = lane, k = 0; t < a.T; t += 64, ++k) {
             const uint32_t w = a.out[x * a.T + t];
-            double lb = 2.0, ub = 2.0;   // not encoded: above everything, so that L2 cannot be trusted beyond what is known
+            double lb = -1.0, ub = 2.0;   // not encoded: its lower bound is unknown (it must not raise L2) and it is a candidate
             int ml = 0;
             if (w != IDENT_NONE) ident_bounds((int)(w >> 16), (int)(w & 0xffffu), a.tlen[t], lb, ub, ml);
-            else lb = -1.0;              // (its lower bound is unknown: it must not raise L2)
+            if (two && k < 2) { w2[k] = w; ub2[k] = ub; ml2[k] = ml; }
             if (lb > m1) { m2 = m1; m1 = lb; } else if (lb > m2) m2 = lb;
         }
 #pragma unroll
@@ -157,34 +165,36 @@ __global__ __launch_bounds__(256) void sd_ident_select(IdentArgs a) {
             m1 = hi; m2 = lo;
         }
         const double L2 = m2 * (1.0 - 1e-12);
-        for (int t0 = 0; t0 < a.T; t0 += 64) {
+        for (int t0 = 0, k = 0; t0 < a.T; t0 += 64, ++k) {
             const int t = t0 + lane;
             bool cand = false;
-            uint32_t keep = 0;
             if (t < a.T) {
-                const uint32_t w = a.out[x * a.T + t];
-                if (w == IDENT_NONE) cand = true;
+                uint32_t w;
+                double ub;
+                int ml;
+                if (two) { w = w2[k & 1]; ub = ub2[k & 1]; ml = ml2[k & 1]; }
                 else {
-                    double lb, ub; int ml;
-                    ident_bounds((int)(w >> 16), (int)(w & 0xffffu), a.tlen[t], lb, ub, ml);
-                    cand = ub >= L2;
-                    keep = (w & 0xffff0000u) | (uint32_t)ml;
+                    w = a.out[x * a.T + t];
+                    double lb = -1.0;
+                    ub = 2.0; ml = 0;
+                    if (w != IDENT_NONE) ident_bounds((int)(w >> 16), (int)(w & 0xffffu), a.tlen[t], lb, ub, ml);
                 }
-                if (!cand) a.out[x * a.T + t] = keep;
+                cand = w == IDENT_NONE || ub >= L2;
+                if (!cand) a.out[x * a.T + t] = (w & 0xffff0000u) | (uint32_t)ml;
             }
             const unsigned long long bm = __ballot(cand);
             if (bm) {
                 int base = 0;
                 if (lane == 0) base = atomicAdd(a.cand_cnt, __popcll(bm));
                 base = __shfl(base, 0);
-                if (cand) a.cand_list[base + __popcll(bm & ((1ull << lane) - 1ull))] = (uint32_t)(x * a.T + t);
+                if (cand) clist[base + __popcll(bm & ((1ull << lane) - 1ull))] = (uint32_t)(x * a.T + t);
             }
         }
     }
 }
 
 size_t ident_ck_lanes(const IdentArgs& a) {
-    return std::max(std::max((size_t)a.grid_short, (size_t)a.grid_cand) * 256 * (size_t)a.cap_short,
+    return std::max(std::max((size_t)a.grid_short, a.ck_cand ? (size_t)0 : (size_t)a.grid_cand) * 256 * (size_t)a.cap_short,
                     (size_t)a.grid_long * 256 * (size_t)a.cap_long);
 }
 
@@ -208,18 +218,16 @@ void launch_ident(hipStream_t st, const IdentArgs& a) {
 #undef SD_ID
 }
 
-void launch_ident_pruned(hipStream_t st, const IdentArgs& a) {
-    if (!a.homo || a.T < 3 || !a.cand_list || !a.cand_cnt) { launch_ident(st, a); return; }
+bool launch_ident_pruned_front(hipStream_t st, const IdentArgs& a) {
+    if (!a.homo || a.T < 3 || !a.cand_list || !a.cand_cnt) { launch_ident(st, a); return false; }
     const size_t eq_bytes = (size_t)a.Tmask * 5 * (size_t)a.K * 8;
     const size_t lds = eq_bytes <= 60 * 1024 ? eq_bytes : 0;
     (void)hipMemsetAsync(a.long_cnt, 0, sizeof(int), st);
-    (void)hipMemsetAsync(a.cand_cnt, 0, sizeof(int), st);
 #define SD_IDP(KK)                                                                                                 \
     {                                                                                                              \
         hipLaunchKernelGGL(sd_ident_dist<KK>, dim3(a.grid_short), dim3(256), lds, st, a);                           \
         hipLaunchKernelGGL(sd_ident_pairs<KK>, dim3(a.grid_long), dim3(256), lds, st, a, 1, a.cap_long);            \
         hipLaunchKernelGGL(sd_ident_select, dim3(a.grid_short), dim3(256), 0, st, a);                               \
-        hipLaunchKernelGGL(sd_ident_pairs<KK>, dim3(a.grid_cand), dim3(256), lds, st, a, 2, a.cap_short);           \
     }
     switch (a.K) {
         case 1: SD_IDP(1) break;
@@ -230,6 +238,25 @@ void launch_ident_pruned(hipStream_t st, const IdentArgs& a) {
         default: SD_IDP(8) break;
     }
 #undef SD_IDP
+    return true;
+}
+
+void launch_ident_pruned_back(hipStream_t st, const IdentArgs& a) {
+    const size_t eq_bytes = (size_t)a.Tmask * 5 * (size_t)a.K * 8;
+    const size_t lds = eq_bytes <= 60 * 1024 ? eq_bytes : 0;
+    switch (a.K) {
+        case 1: hipLaunchKernelGGL(sd_ident_pairs<1>, dim3(a.grid_cand), dim3(256), lds, st, a, 2, a.cap_short); break;
+        case 2: hipLaunchKernelGGL(sd_ident_pairs<2>, dim3(a.grid_cand), dim3(256), lds, st, a, 2, a.cap_short); break;
+        case 3: hipLaunchKernelGGL(sd_ident_pairs<3>, dim3(a.grid_cand), dim3(256), lds, st, a, 2, a.cap_short); break;
+        case 4: hipLaunchKernelGGL(sd_ident_pairs<4>, dim3(a.grid_cand), dim3(256), lds, st, a, 2, a.cap_short); break;
+        case 6: hipLaunchKernelGGL(sd_ident_pairs<6>, dim3(a.grid_cand), dim3(256), lds, st, a, 2, a.cap_short); break;
+        default: hipLaunchKernelGGL(sd_ident_pairs<8>, dim3(a.grid_cand), dim3(256), lds, st, a, 2, a.cap_short); break;
+    }
+}
+
+void launch_ident_pruned(hipStream_t st, const IdentArgs& a) {
+    if (a.cand_cnt && a.homo && a.T >= 3 && a.cand_list) (void)hipMemsetAsync(a.cand_cnt, 0, sizeof(int), st);
+    if (launch_ident_pruned_front(st, a)) launch_ident_pruned_back(st, a);
 }
 
 }  // namespace sd

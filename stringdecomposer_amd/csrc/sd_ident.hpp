@@ -38,9 +38,12 @@ struct IdentArgs {
     // Pruned homopolymer pass (launch_ident_pruned; round 6): the post-processing reports only the two best templates of the
     // homopolymer-compressed alignments (main.py:137-146), so every pair first gets its distance alone, the identity bounds
     // that follow from it pick the pairs that can be among a record's two best, and only those are aligned in full.
-    uint32_t* cand_list = nullptr;  // rec_cap * T entries: output index (record * T + template) of a pair to align in full
-    int* cand_cnt = nullptr;        // zeroed by launch_ident_pruned
+    uint32_t* cand_list = nullptr;  // rec_cap * T entries: output index (record * T + template) of a pair to align in full; a launch
+                                    // over the records [r_lo, r_hi) uses the region that starts at r_lo * T (at most T per record)
+    int* cand_cnt = nullptr;        // this launch's counter (the caller zeroes it: launch_ident_pruned does, or once per run)
     int grid_cand = 0;
+    void* ck_cand = nullptr;        // checkpoint workspace of the candidate stage when it runs beside the next launch's kernels
+    int* ckpos_cand = nullptr;      // (launch_ident_pruned_back on a stream of its own); null: ck / ckpos
 };
 constexpr uint32_t IDENT_NONE = 0xffffffffu;
 
@@ -49,6 +52,11 @@ void launch_ident(hipStream_t st, const IdentArgs& a);
 // the pairs that cannot be among a record's two best hold (dist << 16 | the FEWEST matches the distance allows) -- an
 // identity strictly below the record's second best, so the stable sort of main.py:145 never sees them in its first two
 void launch_ident_pruned(hipStream_t st, const IdentArgs& a);
+// the same in two parts, for a caller that runs the candidate stage beside the next slice's kernels: front = distances, the
+// long segments in full, bounds + selection (cand_cnt zeroed by the caller before); back = the full alignments of the list
+// (any stream that waits for the front; workspace ck_cand / ckpos_cand).  False: this launch is not pruned (front did everything).
+bool launch_ident_pruned_front(hipStream_t st, const IdentArgs& a);
+void launch_ident_pruned_back(hipStream_t st, const IdentArgs& a);
 // bytes of checkpoint workspace (ck) and ints of ckpos for the two launches of launch_ident
 size_t ident_ck_lanes(const IdentArgs& a);
 

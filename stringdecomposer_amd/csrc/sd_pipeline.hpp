@@ -313,7 +313,9 @@ struct sd_engine {
     DevBuf<uint4> d_ick;
     DevBuf<uint32_t> d_ident, d_identh;
     DevBuf<uint32_t> d_icand;      // pruned homopolymer pass: pairs to align in full (sd_ident.hpp: IdentArgs::cand_list)
-    DevBuf<int> d_icandcnt;
+    DevBuf<int> d_icandcnt;        // one counter per identity slice (64)
+    DevBuf<uint4> d_ick2;          // checkpoint workspace of the candidate stage (it runs beside the next slice's kernels)
+    DevBuf<int> d_ickpos2;
     uint32_t* h_ident = nullptr;                 // pinned blocks from g_pinpool, owned until a sink takes them
     uint32_t* h_identh = nullptr;
     size_t h_ident_bytes = 0, h_identh_bytes = 0;
@@ -329,6 +331,10 @@ struct sd_engine {
     // fill 47.6 instead of 22.6 ms) and the hand-over still in pieces.
     std::vector<int> slice_end;
     std::vector<hipEvent_t> ev_slice;
+    // pruned homopolymer pass of a sliced run: the full alignments of a slice's candidates (a few waves: one wave's latency,
+    // 0.4 ms, whatever their number) run on a stream of their own beside the NEXT slice's kernels
+    hipStream_t cand_st = nullptr;
+    std::vector<hipEvent_t> ev_cand;
     hipEvent_t ev_dp = nullptr;          // DP + compaction done, record offsets and guard flag on the host
     bool sliced_run = false;             // the last run launched its identities in slices
 
@@ -349,6 +355,8 @@ struct sd_engine {
         for (hipEvent_t e : {ev_run0, ev_run1, ev_cmp0, ev_cmp1, ev_in, ev_id0, ev_id1, ev_dp})
             if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_slice) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_cand) (void)hipEventDestroy(e);
+        if (cand_st) (void)hipStreamDestroy(cand_st);
         g_pinpool.give(h_ident, h_ident_bytes);
         g_pinpool.give(h_identh, h_identh_bytes);
     }
@@ -359,7 +367,7 @@ struct sd_engine {
                d_fckbase.bytes() + d_in.bytes() +
                d_B.bytes() + d_argB.bytes() + d_cnt.bytes() + d_recs.bytes() + d_dense.bytes() +
                d_roff.bytes() + d_recchunk.bytes() + d_ilong.bytes() + d_ick.bytes() + d_ickpos.bytes() +
-               d_ident.bytes() + d_identh.bytes() + d_icand.bytes();
+               d_ident.bytes() + d_identh.bytes() + d_icand.bytes() + d_ick2.bytes() + d_ickpos2.bytes();
     }
 };
 
