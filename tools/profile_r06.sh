@@ -24,3 +24,8 @@ python bench.py --config c5 --scaling strong --steps 5 --warmup 1 --no-cpu-basel
 python bench.py --config c4-second-best --steps 6 --warmup 2 > $O/bench_c4_second_best.json 2> $O/bench_c4_second_best.err
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4sb -o c4 -- python3 $R/bench.py --config c4-second-best --steps 4 --warmup 1 --no-cpu-baseline > $O/stats_c4sb.log 2>&1)
 find $O -name "*.csv" | wc -l
+SD_TIMING=1 python bench.py --config c4-second-best --steps 2 --warmup 3 --no-cpu-baseline 2>&1 | grep "sd timing" | grep -v "FASTA\|chunk table\|pipeline from\|batch plan\|identities on\|of which" | tail -14 > $O/c4_second_best_timeline.txt
+for s in 9601 9602 9603; do python tools/fuzz_gpu.py 500 $s $O/fuzz.txt > /dev/null 2>&1; done
+python tools/fuzz_final.py 80 9611 $O/fuzz_final.txt > /dev/null 2>&1
+for s in 21 22; do python tools/fuzz_stream.py 50 $s $O/fuzz_stream.txt > /dev/null 2>&1; done
+cat $O/fuzz*.txt
