@@ -234,14 +234,38 @@ def bench_c4_second_best(args):
             except Exception:
                 pass
         ident_s = acc["ident_ms"] / K / 1e3
-        roofline = {"kernel": "sd_ident_pairs<3> (2 launches per step: plain and homopolymer-compressed templates)",
+        # Round 6: the homopolymer-compressed pairs get their distance alone first; only those whose identity bounds reach a
+        # record's two best are aligned in full.  The committed per-pair figures (profiles/ident_traffic.json) are those of a
+        # FULL alignment, plain and compressed; profiles/r06_ident_pmc.json holds the instructions and bytes per step of
+        # every kernel of the pruned form, taken on this workload.
+        homo_pairs, homo_full = acc.get("homo_pairs", 0.0) / K, acc.get("homo_full_pairs", 0.0) / K
+        pruned = None
+        pj6 = os.path.join(ROOT, "profiles", "r06_ident_pmc.json")
+        if homo_pairs > 0 and os.path.isfile(pj6):
+            with open(pj6) as f:
+                p6 = json.load(f)
+            if p6.get("pairs_per_step") == pairs:
+                tot = sum(v["SQ_INSTS_VALU_per_step"] for v in p6["kernels"].values())
+                hb = sum(v.get("hbm_bytes_per_step", 0.0) for v in p6["kernels"].values())
+                pruned = {"wave_insts_per_step": tot, "issue_frac": tot / ident_s / 1e9 / VALU_PEAK_GINST if ident_s > 0 else None,
+                          "hbm_bytes_per_step": hb, "hbm_bytes_per_pair": hb / pairs, "traffic_over_algorithmic": hb / pairs / (171 / 4.0 + 4.0),
+                          "per_kernel": p6["kernels"], "source": "profiles/r06_ident_pmc.json (rocprofv3 --pmc, separate passes, this workload)"}
+        roofline = {"kernel": "sd_ident_pairs<3> (plain: every pair in full) + sd_ident_dist<3> / sd_ident_select / sd_ident_pairs<3> on the "
+                              "selected pairs (homopolymer-compressed), per identity slice",
                     "pairs_per_step": pairs, "ident_ms_per_step": ident_s * 1e3,
+                    "homopolymer_pairs_per_step": homo_pairs, "homopolymer_pairs_aligned_in_full": homo_full,
+                    "homopolymer_pairs_skipped_frac": None if homo_pairs <= 0 else 1.0 - homo_full / homo_pairs,
+                    "pruned_form": pruned,
                     "pairs_per_s_in_kernel": pairs / ident_s if ident_s > 0 else None,
                     "algorithmic_bytes_per_pair": 171 / 4.0 + 4.0,
                     "traffic_bytes_per_pair": bytes_pp,
                     "traffic_source": None if bytes_pp is None else "committed profile profiles/ident_traffic.json (rocprofv3 --pmc "
                     "FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE doubled for 16-B-per-lane reads)"}
-        if insts_pp and ident_s > 0:
+        if pruned is not None and pruned["issue_frac"] is not None:
+            roofline.update({"bound": "valu", "achieved": pruned["wave_insts_per_step"] / ident_s / 1e9, "peak": VALU_PEAK_GINST,
+                             "unit": "G wave-inst/s", "frac": pruned["issue_frac"], "traffic_bytes_per_pair": pruned["hbm_bytes_per_pair"],
+                             "insts_source": pruned["source"]})
+        elif insts_pp and ident_s > 0 and homo_pairs <= 0:
             ach = insts_pp * pairs / ident_s / 1e9
             roofline.update({"bound": "valu", "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "G wave-inst/s",
                              "frac": ach / VALU_PEAK_GINST, "wave_insts_per_pair": insts_pp,

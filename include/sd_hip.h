@@ -132,7 +132,8 @@ int sd_run_files_range(const char* reads_fa, const char* monomers_fa, const sd_p
  * in-stream, [5] device batches, [6] DP rows, [7] pack + enqueue, [8] waits for the device, [9] raw text,
  * [10] post-processing, [11] file writes, [12] text-based identities (0 when they all came in-stream), [13] final /
  * _alt text, [14] whole call, [15] device / pinned allocations, [16] engine / pipeline set-up, [17] per-read assembly,
- * [18..23] 0.  Measurement only (bench.py, tools/). */
+ * [18] homopolymer-compressed pairs of the job (--second-best), [19] those of them that were aligned in full (the pruned pass
+ * aligns only the pairs whose identity bounds reach a record's two best), [20..23] 0.  Measurement only (bench.py, tools/). */
 void sd_last_run_stats(double out[24]);
 /* Batches of this process that were repeated with integer cells because the fp16 range guard of a fill tripped
  * (0 unless sd_params.reserved[2] lowers the limit, or the layout plan's range bound is wrong). */

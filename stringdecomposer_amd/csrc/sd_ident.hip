@@ -130,12 +130,27 @@ __global__ __launch_bounds__(256, 4) void sd_ident_dist(IdentArgs a) {
 // does not reach it is strictly below the record's two best and keeps (d, fewest matches); the others go on the list.
 // (A pair the distance pass could not encode -- IDENT_NONE -- is a candidate: the full kernel decides.)
 __global__ __launch_bounds__(256) void sd_ident_select(IdentArgs a) {
+    // A wave collects the candidates of the records it goes through in LDS and takes ONE range of the list for all of them:
+    // with an atomicAdd per record and half-wave, 20 000 of them per launch met on one counter and the launch took 240 us
+    // for 23 M instructions (profiles/r06_ident_pmc.json before this change).
+    constexpr int BUF = 1024;
+    __shared__ uint32_t cbuf[4][BUF];
     const int64_t n_tot = *a.total;
     if (n_tot > a.rec_cap || n_tot > a.dense_cap) return;
     const int64_t r_lo = a.rec_lo ? *a.rec_lo : 0;
     const int64_t n_rec = (a.rec_hi ? *a.rec_hi : n_tot) - r_lo;
     uint32_t* clist = a.cand_list + r_lo * a.T;
     const int lane = threadIdx.x & 63;
+    uint32_t* buf = cbuf[threadIdx.x >> 6];
+    int nbuf = 0;   // wave-uniform
+    auto flush = [&]() {
+        if (nbuf == 0) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.cand_cnt, nbuf);
+        base = __shfl(base, 0);
+        for (int k = lane; k < nbuf; k += 64) clist[base + k] = buf[k];
+        nbuf = 0;
+    };
     const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const bool two = a.T <= 128;     // the common case (up to 64 monomers): a lane's two pairs stay in registers between the passes
@@ -144,6 +159,7 @@ __global__ __launch_bounds__(256) void sd_ident_select(IdentArgs a) {
         const DevRec rec = a.dense[x];
         const int ql = rec.end - rec.start + 1;
         if (ql <= 0 || ql > a.short_max) continue;   // (nothing computed / the long launch aligns every pair in full)
+        if (nbuf + a.T > BUF) flush();
         // top two lower bounds over the T pairs (a duplicate of the maximum counts twice)
         double m1 = -1.0, m2 = -1.0;
         uint32_t w2[2] = {IDENT_NONE, IDENT_NONE};
@@ -165,6 +181,7 @@ __global__ __launch_bounds__(256) void sd_ident_select(IdentArgs a) {
             m1 = hi; m2 = lo;
         }
         const double L2 = m2 * (1.0 - 1e-12);
+        const bool direct = a.T > BUF;   // (a record with more templates than the buffer holds: straight to the list)
         for (int t0 = 0, k = 0; t0 < a.T; t0 += 64, ++k) {
             const int t = t0 + lane;
             bool cand = false;
@@ -184,13 +201,20 @@ __global__ __launch_bounds__(256) void sd_ident_select(IdentArgs a) {
             }
             const unsigned long long bm = __ballot(cand);
             if (bm) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(a.cand_cnt, __popcll(bm));
-                base = __shfl(base, 0);
-                if (cand) clist[base + __popcll(bm & ((1ull << lane) - 1ull))] = (uint32_t)(x * a.T + t);
+                const int n = __popcll(bm), at = __popcll(bm & ((1ull << lane) - 1ull));
+                if (direct) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(a.cand_cnt, n);
+                    base = __shfl(base, 0);
+                    if (cand) clist[base + at] = (uint32_t)(x * a.T + t);
+                } else {
+                    if (cand) buf[nbuf + at] = (uint32_t)(x * a.T + t);
+                    nbuf += n;
+                }
             }
         }
     }
+    flush();
 }
 
 size_t ident_ck_lanes(const IdentArgs& a) {

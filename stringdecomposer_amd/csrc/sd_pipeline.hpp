@@ -436,6 +436,7 @@ struct Pipeline {
     // accumulated over all batches: HIP-event kernel times (ms) and host stage times (s)
     double fill_ms = 0, trace_ms = 0, compact_ms = 0, run_ms = 0, ident_ms = 0;
     int64_t ident_pairs = 0;
+    int64_t homo_pairs = 0, homo_full_pairs = 0;   // homopolymer-compressed pairs of the job / those aligned in full (pruned pass)
     double pack_s = 0, wait_s = 0, sink_s = 0;
     int64_t launches = 0, batches = 0, rows = 0;
 
@@ -452,6 +453,7 @@ struct Pipeline {
         mlen.assign(mono_lens, mono_lens + n_mono);
         fill_ms = trace_ms = compact_ms = run_ms = ident_ms = 0;
         ident_pairs = 0;
+        homo_pairs = homo_full_pairs = 0;
         pack_s = wait_s = sink_s = 0;
         launches = batches = rows = 0;
         eb[0] = 0;
@@ -679,6 +681,13 @@ struct Pipeline {
             float im = 0.f;
             if (hipEventElapsedTime(&im, e->ev_id0, e->ev_id1) == hipSuccess) ident_ms += im;
             if (e->ident_valid) ident_pairs += total * (e->ident_mode == 2 ? 2 * (int64_t)e->iT : 1);
+            // pruned homopolymer pass: the pairs that were aligned in full (one counter per identity slice)
+            if (e->ident_valid && e->ident_mode == 2 && e->ia_homo.cand_list && e->d_icandcnt.p) {
+                int cnt[64];
+                if (hipMemcpy(cnt, e->d_icandcnt.p, sizeof cnt, hipMemcpyDeviceToHost) == hipSuccess)
+                    for (size_t sl = 0; sl < std::max<size_t>(1, e->sliced_run ? e->slice_end.size() : 1) && sl < 64; ++sl) homo_full_pairs += cnt[sl];
+                homo_pairs += total * (int64_t)e->iT;
+            }
         }
         if (sliced) return rc;
         sink_slot = k;

@@ -544,7 +544,7 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
         const double v[24] = {pipe.fill_ms, pipe.trace_ms, pipe.compact_ms, pipe.ident_ms, (double)pipe.ident_pairs,
                               (double)pipe.batches, (double)pipe.rows, pipe.pack_s * 1e3, pipe.wait_s * 1e3, t_fmt * 1e3,
                               t_post * 1e3, t_io * 1e3, pp.t_identity * 1e3, pp.t_format * 1e3, (now_s() - t_begin) * 1e3,
-                              (double)g_alloc_ns.load() / 1e6, t_setup * 1e3, pipe.sink_s * 1e3, 0, 0, 0, 0, 0, 0};
+                              (double)g_alloc_ns.load() / 1e6, t_setup * 1e3, pipe.sink_s * 1e3, (double)pipe.homo_pairs, (double)pipe.homo_full_pairs, 0, 0, 0, 0};
         std::memcpy(g_last_run, v, sizeof v);
     }
     if (timing) {

@@ -343,7 +343,7 @@ def last_run_stats():
     L.sd_last_run_stats(v)
     keys = ("fill_ms", "trace_ms", "compact_ms", "ident_ms", "ident_pairs", "batches", "rows", "pack_ms", "wait_ms",
             "raw_text_ms", "post_ms", "io_ms", "text_identity_ms", "final_text_ms", "total_ms", "alloc_ms", "setup_ms",
-            "assemble_ms")
+            "assemble_ms", "homo_pairs", "homo_full_pairs")
     return dict(zip(keys, [float(x) for x in v]))
 
 
