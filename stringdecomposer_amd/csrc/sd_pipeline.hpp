@@ -85,7 +85,10 @@ struct AllocTimer {
 // signal_async_handler() failed to set the handler!" on the last queue, then nothing; round 6, found by running two tests of
 // the GPU suite on their own; rounds 1-5 had the same calls).  So nothing is handed back to the runtime on a hot path any
 // more: a block that is replaced goes to its pool where one exists, else on this list, which sd_release_cache() empties --
-// the caller's statement that the device is idle.  Buffers grow by doubling, so the list stays below what is in use.
+// AFTER it has destroyed the cached pipelines and their streams.  (Emptying the list at the start of a job, with nothing in
+// flight anywhere, was tried and hangs in the same way: what the wait cannot cope with is the NUMBER of queues the process
+// holds -- two cached pipelines are a dozen streams -- not work on them.)  Buffers grow by doubling, so the list stays below
+// what is in use; a long-lived process that goes through many parameter sets calls sd_release_cache() now and then.
 struct DeferredFrees {
     std::mutex m;
     std::vector<void*> dev, host;
