@@ -585,6 +585,27 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
         plan.P = P;
         plan.P4 = (P + 3) & ~3;
     }
+    // the floor level every read symbol needs on its own (round 6): per lane and symbol b the last slot q >= 1 whose table
+    // value exceeds every earlier one of the lane -- floor_slots is the maximum over the five symbols; the narrow u16 fills
+    // pick one of three unrolled slot loops per ROW by the row's symbol (sd_fast_fill: FLS)
+    for (int b = 0; b < 5; ++b) plan.floor_sym[b] = 1;
+    plan.table_nonneg = std::min(sc.match, sc.mismatch) - sc.del - sc.ins >= 0;
+    if (!wide)
+        for (int j = 0; j < T; ++j) {
+            const std::string& sq = tseq[(size_t)j];
+            const std::vector<int>& bj = bnd[(size_t)j];
+            for (size_t u = 0; u + 1 < bj.size(); ++u)
+                for (int b = 0; b < 5; ++b) {
+                    int run = code_of(sq[(size_t)bj[u]]) == b ? sc.match : sc.mismatch;
+                    for (int q = 1; bj[u] + q < bj[u + 1]; ++q) {
+                        const int val = code_of(sq[(size_t)(bj[u] + q)]) == b ? sc.match : sc.mismatch;
+                        if (val > run) { run = val; plan.floor_sym[b] = std::max(plan.floor_sym[b], q); }
+                    }
+                }
+        }
+    if (getenv("SD_PLAN_DEBUG"))
+        std::fprintf(stderr, "[sd plan] P = %d: floor slots %d; per read symbol A C G T N: %d %d %d %d %d\n", P, plan.floor_slots,
+                     plan.floor_sym[0], plan.floor_sym[1], plan.floor_sym[2], plan.floor_sym[3], plan.floor_sym[4]);
     plan.T = T;
     plan.split = split;
     plan.Lmax = Lmax;
@@ -855,8 +876,10 @@ void launch_fast_fill(const FastPlan& plan, hipStream_t st, const ChunkDesc* chu
     // FastPlan::full_floor (SD_FLAG_FULL_FLOOR) keeps the full kernel (developer A/B and the parity test of the two)
     const bool has1 = ((plan.Hx >> 10) & 1) != 0;   // 1-bp templates: the full-floor kernels carry the FLC_ONE form
     if (!plan.full_floor && !has1 &&
-        (plan.u16 ? launch_fast_fill_fl_u16(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
-                                            argV, ckpt, ckbase, queue, order, cendoff, crank)
+        (plan.u16 ? (launch_fast_fill_fl_u16(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
+                                             argV, ckpt, ckbase, queue, order, cendoff, crank) ||
+                     launch_fast_fill_fl_u16s(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
+                                              argV, ckpt, ckbase, queue, order, cendoff, crank))
          : plan.f16 ? launch_fast_fill_fl(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, B,
                                           argV, ckpt, ckbase, queue, order, cendoff, crank)
                     : launch_fast_fill_fl_i16(plan, st, grid, nw, lds, chunks, n_chunks, bases2, nmask, table, lane_consts, sc,

@@ -61,6 +61,8 @@ struct FastPlan {
     int range_bound = 0;       // proven bound on |stored cell| between two rebases (fp16 formats need <= 2040)
     bool full_floor = false;   // launch the fills that take the start-term maximum in every slot (SD_FLAG_FULL_FLOOR: A/B, parity test)
     int floor_slots = 0;  // last slot of a lane whose diagonal input needs the max with the start term (see sd_fast_fill)
+    int floor_sym[5] = {0, 0, 0, 0, 0};   // the same per read symbol (A C G T N); floor_slots = their maximum
+    bool table_nonneg = false;            // every table value (mm - del - ins) >= 0: the fills may apply the floor in place (sd_fast_fill: FLS)
     uint32_t bf8_match = 0, bf8_mismatch = 0;   // multi-wave wide layout: the two table values as bf8 bytes (f16) or int8 bytes (integer cells)
     std::vector<int32_t> vlane0;         // first virtual lane of template j
     std::vector<uint32_t> table;         // narrow: [5][P4/4][64][4] packed int16 (mm - del - ins), NEG on padding
@@ -144,6 +146,17 @@ bool launch_fast_fill_fl_long_u16(const FastPlan& plan, hipStream_t st, int grid
                                   const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
                                   int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
                                   const uint32_t* crank);
+// the u16 kernels with ONE floor level for every row (scorings with a negative table value: sd_fast_fl_u16s.hip)
+bool launch_fast_fill_fl_u16s(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
+                              int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                              const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
+                              int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
+                              const uint32_t* crank);
+bool launch_fast_fill_fl_long_u16s(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
+                                   int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
+                                   const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,
+                                   int32_t* ckbase, int* queue, const int* order, const uint32_t* cendoff,
+                                   const uint32_t* crank);
 void launch_fast_fill_full_u16(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t lds, const ChunkDesc* chunks,
                                int n_chunks, const uint32_t* bases2, const uint32_t* nmask, const uint32_t* table,
                                const uint32_t* lane_consts, ScoreArgs sc, int32_t* B, int32_t* argV, uint32_t* ckpt,

@@ -43,7 +43,15 @@ namespace sd {
 //   * a rebase shifts the real planes only (per-half add of the masked shift).
 // ONE: the set has 1-bp templates (FLC_ONE lanes end at slot 0); instantiated for the full-floor kernels of
 // sd_fast.hip only -- as a run-time branch in every kernel it cost the C2 fill 3 % (12.3 against 11.9 ms, same box)
-template <int P, bool RANKED, int CF, int FL = P, bool ONE = false>
+// FLS > 0 (round 6, u16 cells): the floor level of a template set is the maximum over the five read symbols, and single symbols
+// are often far below it (C2's set: A 16, C 15, G 10, T 6), so a ROW takes the floor in the first FL, FL - FLS or FL - 2 FLS
+// slots by its read symbol (Hx bits 22..31: two bits per symbol, 0 = FL).  Three copies of the slot loop behind a scalar
+// branch were built first and lost 13 %: the register allocator gives the three loops different registers and joins them
+// with 27 moves per row.  Instead the floors are applied IN PLACE before the one slot loop, L[q-1] = max(L[q-1], KB), two
+// scalar branches skipping the upper groups.  That also raises the "keep" operand of slot q-1 to KB, which changes nothing
+// while every table value is >= 0: S'[q-1] >= S'[0] >= KB + tbl[0] >= KB anyway (the launchers check tmin >= 0; scorings
+// whose mismatch costs more than a deletion plus an insertion take the one-level kernels).
+template <int P, bool RANKED, int CF, int FL = P, bool ONE = false, int FLS = 0>
 __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
     const ChunkDesc* __restrict__ chunks, int n_chunks, const uint32_t* __restrict__ bases2,
     const uint32_t* __restrict__ nmask, const uint32_t* __restrict__ table,
@@ -287,7 +295,8 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
 #pragma unroll
     for (int q = 1; q < P; ++q) L[q] = CO::mx(L[q - 1], CO::add(tb[q], ins2));
     }
-    load_table(rs.code(1), L[P - 1]);
+    int rcur = rs.code(1);   // read symbol of the row the loop is about to fill
+    load_table(rcur, L[P - 1]);
     rs.advance(1);
     std::conditional_t<U16, U16Guard<P>, F16Guard<P>> guard;
     if constexpr (F16) {
@@ -374,13 +383,28 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
         // software-pipelined over the slots so that no packed op consumes the result of the
         // instruction right before it (gfx950 needs a wait state there)
         if constexpr (HRED) {
+            if constexpr (FLS > 0) {
+                constexpr int FL2 = FL - 2 * FLS > 1 ? FL - 2 * FLS : 1, FL1 = FL - FLS > FL2 ? FL - FLS : FL2;
+                const int lv = (Hx >> (22 + 2 * rcur)) & 3;   // scalar: the level of this row's read symbol
+#pragma unroll
+                for (int q = 1; q <= FL2 && q < P; ++q) L[q - 1] = CO::mx(L[q - 1], KB);
+                if (lv <= 1) {
+#pragma unroll
+                    for (int q = FL2 + 1; q <= FL1 && q < P; ++q) L[q - 1] = CO::mx(L[q - 1], KB);
+                }
+                if (lv == 0) {
+#pragma unroll
+                    for (int q = FL1 + 1; q <= FL && q < P; ++q) L[q - 1] = CO::mx(L[q - 1], KB);
+                }
+            }
+            const uint32_t w0f = FLS > 0 ? (U16 ? (L[0] & notStart) : bfi(startMask, NEGC, L[0])) : w0;   // (slot 0's keep operand, after the in-place floor)
 #pragma unroll
             for (int s = 0; s < P + 4; ++s) {
                 if (s >= 4) {
                     const int q = s - 4;
                     // slot 0 (HRED): the old carry K joins the chain here, so that the last slot is the
                     // lane total without a separate max(L[P-1], K) at the end of the row
-                    L[q] = q == 0 ? CO::mx3(v_[0], w0, K) : CO::mx3(L[q - 1], v_[q], L[q]);
+                    L[q] = q == 0 ? CO::mx3(v_[0], w0f, K) : CO::mx3(L[q - 1], v_[q], L[q]);
                 }
                 if (s >= 2 && s - 2 < P) {
                     const int q = s - 2;
@@ -393,7 +417,7 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
                     // else KB + tbl[q] is already below what the chain carries from an earlier slot.  The plan
                     // finds the last such slot over all lanes and symbols (FastPlan::floor_slots <= FL).
                     if (q == 0) u_[q] = KB;
-                    else if (q <= FL) u_[q] = CO::mx(L[q - 1], KB);
+                    else if (FLS == 0 && q <= FL) u_[q] = CO::mx(L[q - 1], KB);
                     else u_[q] = L[q - 1];
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -422,7 +446,8 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
             __builtin_amdgcn_sched_barrier(0);
         }
         }
-        load_table(rs.code(i + 1), L[P - 1]);  // unconditional (clamped): keeps tb[] out of phi copies
+        rcur = rs.code(i + 1);
+        load_table(rcur, L[P - 1]);  // unconditional (clamped): keeps tb[] out of phi copies
         rs.advance(i + 1);
         uint32_t a = HRED ? L[P - 1] : CO::mx(L[P - 1], K);  // fp16 / u16: K already joined the chain
         // a 1-bp template ends in slot 0: the pads behind a k = 0 cell keep their old value when the cell's falls

@@ -15,6 +15,9 @@
 #include "sd_fast_fill.hpp"
 
 // (sd_fast_fl_u16.hip compiles this file again for the biased-u16 cell format: SD_FL_CF = CF_U16, its own entry names)
+#ifndef SD_FL_STEP
+#define SD_FL_STEP 0      /* one floor level for every row (fp16 cells); the u16 units set 4: three levels by read symbol */
+#endif
 #ifndef SD_FL_CF
 #define SD_FL_CF CF_F16
 #define SD_FL_ENTRY launch_fast_fill_fl
@@ -37,13 +40,22 @@ bool SD_FL_ENTRY(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t 
     for (int c : {12, 16, 20, 24, 28})
         if (plan.floor_slots <= c && c + 2 < plan.P) { fl = c; break; }
     if (fl == 0) return false;
+    if (const char* ev = getenv("SD_EXP_FL")) fl = atoi(ev);   // developer timing experiment: a level below floor_slots gives WRONG rows
     const bool ranked = cendoff != nullptr;
+    // the level of every read symbol (two bits each from bit 22 of Hx): 0 = FL, 1 = FL - step, 2 = FL - 2 steps
+    int hx = plan.Hx;
+    if (SD_FL_STEP > 0)
+        for (int b = 0; b < 5; ++b) {
+            int lv = 0;
+            while (lv < 2 && fl - (lv + 1) * SD_FL_STEP >= std::max(1, plan.floor_sym[b])) ++lv;
+            hx |= lv << (22 + 2 * b);
+        }
 #define SD_FL_K(PP, RK, FF)                                                                           \
     {                                                                                                \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, SD_FL_CF, FF>),     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sd_fast_fill<PP, RK, SD_FL_CF, FF, false, SD_FL_STEP>),     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-        hipLaunchKernelGGL((sd_fast_fill<PP, RK, SD_FL_CF, FF>), dim3(grid), dim3(nw * 64), lds,  \
-                           st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, plan.Hx, B,   \
+        hipLaunchKernelGGL((sd_fast_fill<PP, RK, SD_FL_CF, FF, false, SD_FL_STEP>), dim3(grid), dim3(nw * 64), lds,  \
+                           st, chunks, n_chunks, bases2, nmask, table, lane_consts, sc, hx, B,   \
                            argV, ckpt, ckbase, queue, order, cendoff, crank);                        \
         return true;                                                                                 \
     }
