@@ -44,8 +44,8 @@ namespace sd {
 // ONE: the set has 1-bp templates (FLC_ONE lanes end at slot 0); instantiated for the full-floor kernels of
 // sd_fast.hip only -- as a run-time branch in every kernel it cost the C2 fill 3 % (12.3 against 11.9 ms, same box)
 // FLS > 0 (round 6, u16 cells): the floor level of a template set is the maximum over the five read symbols, and single symbols
-// are often far below it (C2's set: A 16, C 15, G 10, T 6), so a ROW takes the floor in the first FL, FL - FLS or FL - 2 FLS
-// slots by its read symbol (Hx bits 22..31: two bits per symbol, 0 = FL).  Three copies of the slot loop behind a scalar
+// are often far below it (C2's set: A 16, C 15, G 10, T 6), so a ROW takes the floor in the first FL, FL - FLS, FL - 2 FLS or
+// FL - 3 FLS slots by its read symbol (Hx bits 22..31: two bits per symbol, 0 = FL).  Three copies of the slot loop behind a scalar
 // branch were built first and lost 13 %: the register allocator gives the three loops different registers and joins them
 // with 27 moves per row.  Instead the floors are applied IN PLACE before the one slot loop, L[q-1] = max(L[q-1], KB), two
 // scalar branches skipping the upper groups.  That also raises the "keep" operand of slot q-1 to KB, which changes nothing
@@ -384,10 +384,18 @@ __global__ __launch_bounds__(SD_FILL_NW_MAX * 64, 4) void sd_fast_fill(
         // instruction right before it (gfx950 needs a wait state there)
         if constexpr (HRED) {
             if constexpr (FLS > 0) {
-                constexpr int FL2 = FL - 2 * FLS > 1 ? FL - 2 * FLS : 1, FL1 = FL - FLS > FL2 ? FL - FLS : FL2;
+                // four levels: FL, FL - FLS, FL - 2 FLS, FL - 3 FLS (not below 1); the floors of a level's group are skipped
+                // by the rows whose symbol needs fewer
+                constexpr int FL3 = FL - 3 * FLS > 1 ? FL - 3 * FLS : 1;
+                constexpr int FL2 = FL - 2 * FLS > FL3 ? FL - 2 * FLS : FL3;
+                constexpr int FL1 = FL - FLS > FL2 ? FL - FLS : FL2;
                 const int lv = (Hx >> (22 + 2 * rcur)) & 3;   // scalar: the level of this row's read symbol
 #pragma unroll
-                for (int q = 1; q <= FL2 && q < P; ++q) L[q - 1] = CO::mx(L[q - 1], KB);
+                for (int q = 1; q <= FL3 && q < P; ++q) L[q - 1] = CO::mx(L[q - 1], KB);
+                if (lv <= 2) {
+#pragma unroll
+                    for (int q = FL3 + 1; q <= FL2 && q < P; ++q) L[q - 1] = CO::mx(L[q - 1], KB);
+                }
                 if (lv <= 1) {
 #pragma unroll
                     for (int q = FL2 + 1; q <= FL1 && q < P; ++q) L[q - 1] = CO::mx(L[q - 1], KB);

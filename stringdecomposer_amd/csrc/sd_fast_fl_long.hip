@@ -23,12 +23,12 @@ bool SD_FL_ENTRY_LONG(const FastPlan& plan, hipStream_t st, int grid, int nw, si
     const int fl = plan.floor_slots <= 16 ? 16 : plan.floor_slots <= 24 ? 24 : plan.floor_slots <= 32 ? 32 : 0;
     if (fl == 0) return false;
     const bool ranked = cendoff != nullptr;
-    // the level of every read symbol (two bits each from bit 22 of Hx): 0 = FL, 1 = FL - step, 2 = FL - 2 steps
+    // the level of every read symbol (two bits each from bit 22 of Hx): 0 = FL, 1 = FL - step, 2 = FL - 2 steps, 3 = FL - 3 steps
     int hx = plan.Hx;
     if (SD_FL_STEP > 0)
         for (int b = 0; b < 5; ++b) {
             int lv = 0;
-            while (lv < 2 && fl - (lv + 1) * SD_FL_STEP >= std::max(1, plan.floor_sym[b])) ++lv;
+            while (lv < 3 && fl - (lv + 1) * SD_FL_STEP >= std::max(1, plan.floor_sym[b])) ++lv;
             hx |= lv << (22 + 2 * b);
         }
 #define SD_FL_K(PP, RK, FF)                                                                           \
