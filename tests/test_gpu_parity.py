@@ -873,6 +873,35 @@ def test_fill_without_dominated_start_maxima(oracle, name):
         assert uni == exp
 
 
+@pytest.mark.parametrize("sc", [(-1, -1, -1, 1), (-2, -3, -4, 2), (-1, -1, -3, 1), (-1, -2, -5, 2), (1, -1, -1, 1)])
+def test_floor_level_by_read_symbol_equals_one_level_and_oracle(oracle, sc):
+    """Round 6: the narrow u16 fill takes the start-term floor in the first FL, FL - 4, FL - 8 or FL - 12 slots of a lane by the
+    ROW's read symbol, applied in place in front of the slot loop (sd_fast_fill<..., FLS>) -- valid while every table value
+    mm - del - ins is >= 0; scorings with a negative one ((-1,-1,-3,1): a mismatch costs more than a deletion plus an
+    insertion) take the one-level kernels.  Same rows either way, and the oracle's: sets whose symbols need very different
+    levels (a base that is missing from a monomer's first lanes, homopolymer prefixes), reads rich in one symbol, N."""
+    mn, ms = _late_base_monomers()
+    st = synth.Stream(91, 2)
+    rn, rs = synth.make_reads([m.replace(b"N", b"A") for m in ms], 3, read_len=8000, seed=17)
+    rs = list(rs) + [b"T" * 400 + ms[2] * 8 + b"G" * 300, synth._ACGT[st.below(3000, 2)].tobytes(),        # two-letter read
+                     (ms[0] + b"N" + ms[5]) * 6, synth._ACGT[st.below(2500, 4)].tobytes()]
+    rn = ["r%d" % i for i in range(len(rs))]
+    info = lib.plan_info(ms, scoring=sc)
+    assert (info["family"], info["cells"]) == ("fast", "u16"), info
+    exp = oracle.decompose(rn, rs, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc)
+    got = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, scoring=sc)
+    assert got == exp, sc
+    os.environ["SD_FILL_ONE_LEVEL"] = "1"
+    try:
+        one = lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, scoring=sc)
+    finally:
+        del os.environ["SD_FILL_ONE_LEVEL"]
+    assert one == exp, (sc, "one floor level")
+    for ed, part in ((35, 5000), (-1, 333)):
+        assert lib.decompose(rn, rs, mn, ms, kernel=lib.KERNEL_FAST, scoring=sc, ed_thr=ed, part_size=part, overlap=77) == \
+            oracle.decompose(rn, rs, mn, ms, threads=min(32, os.cpu_count() or 1), sc=sc, ed_thr=ed, part=part, overlap=77), (sc, ed, part)
+
+
 def test_plan_choices_do_not_change_rows():
     """Lane boundaries moved by the plan, the slot count it picks among three, and the kernels that leave out
     dominated start-term maxima are pure optimisations: on random template sets (2-23 monomers of 100-200 bp, with
