@@ -590,7 +590,7 @@ bool fast_plan_build(const std::vector<std::string>& tseq, ScoreArgs sc, int max
     // pick one of three unrolled slot loops per ROW by the row's symbol (sd_fast_fill: FLS)
     for (int b = 0; b < 5; ++b) plan.floor_sym[b] = 1;
     plan.table_nonneg = std::min(sc.match, sc.mismatch) - sc.del - sc.ins >= 0;
-    if (!wide)
+    if (!plan.filter_only)
         for (int j = 0; j < T; ++j) {
             const std::string& sq = tseq[(size_t)j];
             const std::vector<int>& bj = bnd[(size_t)j];
