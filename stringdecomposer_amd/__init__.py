@@ -25,3 +25,28 @@ def prefer_queue_thread_dispatch():
             warnings.warn("AMD_DIRECT_DISPATCH chosen after the HIP runtime initialised: it may have no effect")
         _os.environ["AMD_DIRECT_DISPATCH"] = "0"
     return _os.environ["AMD_DIRECT_DISPATCH"]
+
+
+def leave_without_teardown(rc):
+    """End the process without the interpreter's and the HIP runtime's tear-down (0.1 s of a 0.3-s job: streams,
+    events, 4+ GB of device buffers handed back one by one) -- for entry points that OWN their process
+    (bin/stringdecomposer).  Nothing that was written is lost, whether or not the caller closed it: the exit handlers
+    run (coverage, tracing tools), every Python file object that is still open is flushed (found through the collector,
+    so a file a caller forgot to close is covered too), logging is shut down, and the C stdio buffers of every native
+    library are flushed; bytes handed to write()/pwrite() or stored through a shared mapping are the kernel's already.
+    The process's memory goes back to the driver either way."""
+    import atexit
+    import ctypes
+    import gc
+    import io
+    import logging
+    atexit._run_exitfuncs()
+    logging.shutdown()
+    for o in gc.get_objects():
+        try:
+            if isinstance(o, io.IOBase) and not o.closed and o.writable():
+                o.flush()
+        except Exception:                # a broken pipe on stdout must not turn into a traceback here
+            pass
+    ctypes.CDLL(None).fflush(None)
+    _os._exit(rc if isinstance(rc, int) else (0 if rc is None else 1))

@@ -1092,3 +1092,30 @@ def test_pipeline_cache_key_and_batch_planner_contracts():
     err = C.create_string_buffer(1024)
     rc = L.sd_pipeline_logic_selftest(err, C.c_size_t(1024))
     assert rc == lib.SD_OK, err.value.decode()
+
+
+def test_fast_exit_of_the_launcher_loses_no_output(tmp_path):
+    """VERDICT r05 (weak 12): bin/stringdecomposer leaves without the runtime's tear-down.  What it leaves through
+    (stringdecomposer_amd.leave_without_teardown) must not depend on every output having been closed: exit handlers run, open
+    Python files (text and binary, never closed here) and the C stdio buffers are flushed, the exit code is the caller's."""
+    import subprocess
+    import sys
+    out = tmp_path / "o"
+    code = (
+        "import sys, atexit, ctypes\n"
+        "sys.path.insert(0, %r)\n"
+        "import stringdecomposer_amd as s\n"
+        "f = open(sys.argv[1] + '.txt', 'w'); f.write('x' * 1000)\n"
+        "g = open(sys.argv[1] + '.bin', 'wb'); g.write(b'y' * 10)\n"
+        "atexit.register(lambda: open(sys.argv[1] + '.atexit', 'w').write('ran'))\n"
+        "libc = ctypes.CDLL(None); libc.fopen.restype = ctypes.c_void_p\n"
+        "h = libc.fopen((sys.argv[1] + '.c').encode(), b'w'); libc.fputs(b'stdio', ctypes.c_void_p(h))\n"
+        "print('tail of stdout', end='')\n"
+        "s.leave_without_teardown(7)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code, str(out)], capture_output=True, timeout=120)
+    assert r.returncode == 7, r.stderr.decode()[-500:]
+    assert r.stdout == b"tail of stdout"
+    assert open(str(out) + ".txt").read() == "x" * 1000
+    assert open(str(out) + ".bin", "rb").read() == b"y" * 10
+    assert open(str(out) + ".atexit").read() == "ran"
+    assert open(str(out) + ".c").read() == "stdio"
