@@ -194,10 +194,12 @@ static int run_files_impl(const char* reads_fa, const char* monomers_fa, const s
                 for (int64_t at = 0; at < want && !pre_stop.load(std::memory_order_relaxed); at += step) {
                     const int64_t n = std::min(step, want - at);
                     if (::fallocate(fa, 0, (off_t)at, (off_t)n) != 0) break;   // (no space: write_parts reports it)
-                    pre_done.store(at + n, std::memory_order_release);
+                    // (page tables first, then the range is handed to the writer: write_alt unmaps what it has written, and
+                    // an madvise still walking a range that has left the mapping could meet somebody else's pages there)
 #ifdef MADV_POPULATE_WRITE
                     if (alt_map) (void)::madvise(alt_map + at, (size_t)n, MADV_POPULATE_WRITE);
 #endif
+                    pre_done.store(at + n, std::memory_order_release);
                 }
                 if (getenv("SD_TIMING"))
                     std::fprintf(stderr, "[sd timing] _alt pages reserved ahead: %lld of %lld bytes in %.1f ms (from %.1f ms into the job)\n",
