@@ -16,6 +16,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """SD_TEST_ORDER=reverse | shuffle:<seed> runs the collected tests in another order (developer switch: the hipHostFree hang
+    of rounds 1-5 only showed when two tests ran in an order the suite does not use; see DESIGN section 0, "found on the way")."""
+    order = os.environ.get("SD_TEST_ORDER", "")
+    if order == "reverse":
+        items.reverse()
+    elif order.startswith("shuffle:"):
+        import random
+        random.Random(int(order.split(":", 1)[1])).shuffle(items)
+
+
 def case_names(include_errors=False, include_edthr=False):
     out = []
     for n in sorted(os.listdir(CASES)):
