@@ -516,6 +516,8 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=200,
                     help="reads of the benchmark set the reference CPU path is timed on and compared with (200 x 50 kb = 10 Mbp: "
                          "~25 s of `dp -t 8`)")
+    ap.add_argument("--sustain-seconds", type=float, default=8.0,
+                    help="N = 1: after the timed region, the same steps for about this long (reported as `sustained`; 0 = skip)")
     ap.add_argument("--timed-only", action="store_true",
                     help="only the timed region (no second pipe mode, no device-resident repeat): for profilers, so "
                          "that per-kernel averages are those of the timed launches")
@@ -645,6 +647,16 @@ def main():
         odt, _, od, _ = timed_steps(om, args.steps, min(args.warmup, 1), False)
         other = {"pipe_mode": om, "bp_per_s": bp_rank * K / odt, "ms_per_step": odt / K * 1e3,
                  "kernel_event_ms_per_step": {"fill": od["fill_ms"] / K, "traceback": od["trace_ms"] / K}}
+
+    # ---- the headline's steps again, for seconds instead of K steps (secondary figure: does the rate of the 0.3-s timed
+    # region hold at the clocks and temperatures of a long job?  It also keeps the GPU busy for long enough that a sampler
+    # beside the process -- the driver's gpu_busy -- sees it: the other legs of this script are mostly the CPU baseline) ----
+    sustained = None
+    if ws == 1 and not args.timed_only and args.sustain_seconds > 0:
+        S = int(min(5000, max(K, round(args.sustain_seconds / max(dt / K, 1e-6)))))
+        sdt, srows, _, _ = timed_steps(args.pipe_mode, S, 1, False)
+        sustained = {"steps": S, "seconds": round(sdt, 3), "ms_per_step": sdt / S * 1e3, "bp_per_s": bp_rank * S / sdt,
+                     "vs_timed_region": (dt / K) / (sdt / S), "same_rows_as_headline": srows == rows_out}
 
     # ---- the same K steps with the batch already packed and resident in HBM, one launch per kernel, no
     # overlap: clean per-kernel HIP-event times (device_resident; NOT the headline) ------------------
@@ -868,6 +880,7 @@ def main():
                              "note": "wall ms of the host stages of one step; process_cpu_ms = CPU time of all host "
                                      "threads of this rank per step (user + system)"},
         "other_pipe_mode": other,
+        "sustained": sustained,
         "amd_direct_dispatch": AMD_DIRECT_DISPATCH,
         # batches repeated with integer cells because the fp16 range guard tripped: must be 0 (checked below)
         "f16_guard_trips": lib.guard_trips(),

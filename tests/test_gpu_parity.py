@@ -1015,7 +1015,8 @@ def test_bench_line_contract():
     warmup / ms_per_step / scaling / dtype / data / config.workload / roofline / cpu_baseline); small workload."""
     import json
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--reads", "120",
-                        "--cpu-sample-reads", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+                        "--cpu-sample-reads", "2", "--sustain-seconds", "1.5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -1035,6 +1036,8 @@ def test_bench_line_contract():
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["parity_on_sample"] is True and c["cores"] >= 1 and c["value"] > 0
     assert j["other_pipe_mode"]["pipe_mode"] == 0 and j["device_resident"]["bp_per_s"] > 0
+    su = j["sustained"]   # the headline's steps for seconds instead of K steps: same rows, a rate of the same order
+    assert su["same_rows_as_headline"] is True and su["steps"] >= 3 and 1.0 < su["seconds"] < 60 and 0.3 < su["vs_timed_region"] < 3
     # three batches in flight, one engine each (the timed loop keeps two later steps outstanding)
     assert j["hbm_workspace_bytes"] == 3 * j["hbm_workspace_per_engine_bytes"] and "3 batches in flight" in j["timed_region"]
 
