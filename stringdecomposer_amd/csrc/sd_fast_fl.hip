@@ -40,7 +40,6 @@ bool SD_FL_ENTRY(const FastPlan& plan, hipStream_t st, int grid, int nw, size_t 
     for (int c : {12, 16, 20, 24, 28})
         if (plan.floor_slots <= c && c + 2 < plan.P) { fl = c; break; }
     if (fl == 0) return false;
-    if (const char* ev = getenv("SD_EXP_FL")) fl = atoi(ev);   // developer timing experiment: a level below floor_slots gives WRONG rows
     const bool ranked = cendoff != nullptr;
     // the level of every read symbol (two bits each from bit 22 of Hx): 0 = FL, 1 = FL - step, 2 = FL - 2 steps, 3 = FL - 3 steps
     int hx = plan.Hx;
